@@ -1,0 +1,133 @@
+/* mantagpu.h -- C ABI of the MI355X-native Groth16 prove hot path (libmantagpu.so).
+ *
+ * This is the drop-in boundary for ONE path of Manta-Network/manta-rs: the body of
+ *     manta_crypto::arkworks::groth16::Groth16::<E>::prove      (manta-crypto/src/arkworks/groth16.rs:589-600)
+ * i.e. `ArkGroth16::prove(&context.proving_key, compiler, &mut SizedRng(rng))` and the arkworks 0.3
+ * primitives underneath it (ark-ec VariableBaseMSM, ark-poly Radix2EvaluationDomain, ark-groth16
+ * R1CStoQAP::witness_map + create_proof). Everything else in manta-rs keeps calling arkworks.
+ * INTEGRATION.md shows the Rust `extern "C"` block and the replacement body of `prove`.
+ *
+ * Conventions (same as arkworks' in-memory data, so the Rust side passes slices without conversion):
+ *   - field element  = little-endian u64 limbs (4 for Fr and BN254 Fq, 6 for BLS12-381 Fq), Montgomery
+ *     form with R = 2^(64*limbs)  [ark-ff Fp256/Fp384 `.0.0`]
+ *   - MSM scalars    = 4 x u64 canonical integers [`Fr::into_repr()`], unless a call says "mont"
+ *   - affine point   = x || y (G2: x.c0 x.c1 y.c0 y.c1); infinity = all limbs zero (the shim writes
+ *     zeros for `GroupAffine{infinity: true}`; (0,0) is never on either curve)
+ *   - proof bytes    = arkworks canonical compressed A || B || C (128 B BN254, 192 B BLS12-381),
+ *     byte-identical to `proof_as_bytes` (manta-crypto/src/arkworks/groth16.rs:186-195)
+ *   - every function returns 0 on success; any non-zero maps to the reference's opaque unit `Error`
+ *     (groth16.rs:50-60). No exceptions, no abort. mg_strerror()/mg_last_error() give detail.
+ *   - one process per GPU; objects belong to the HIP device current at creation. All entry points are
+ *     re-entrant; `mg_groth16_prove` may be called concurrently on one context (the reference's
+ *     `prove` takes `&ProvingContext`, groth16.rs:589-596).
+ *   - the library never retains host pointers after a call returns.
+ */
+#ifndef MANTAGPU_H
+#define MANTAGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MG_BN254 = 0, MG_BLS12_381 = 1 } mg_curve_t;
+
+enum {
+    MG_SUCCESS = 0,
+    MG_ERROR_INVALID_ARGUMENT = 1,
+    MG_ERROR_HIP = 2,
+    MG_ERROR_OUT_OF_MEMORY = 3,
+    MG_ERROR_DOMAIN_TOO_LARGE = 4, /* ark-relations SynthesisError::PolynomialDegreeTooLarge */
+    MG_ERROR_STATE = 5
+};
+
+typedef struct mg_bases mg_bases;     /* a static vector of curve points resident in HBM */
+typedef struct mg_msm_job mg_msm_job; /* an MSM in flight */
+typedef struct mg_ctx mg_ctx;         /* device-resident ProvingContext (+ R1CS matrices) */
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+int mg_init(int device);                /* hipSetDevice + engine warm-up; optional */
+const char *mg_strerror(int status);
+const char *mg_last_error(void);        /* thread-local detail of the last failure */
+int mg_device_count(int *count);
+/* Raw HBM buffers, for hosts without a HIP binding (tests, bench). */
+int mg_malloc(void **dptr, size_t bytes);
+int mg_free(void *dptr);
+int mg_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
+int mg_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
+int mg_device_synchronize(void);
+
+/* ---- variable-base MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars)
+ *      (ark-ec 0.3.0 msm/variable_base.rs; called 5x per proof from ark-groth16 create_proof, reached
+ *      from manta-crypto/src/arkworks/groth16.rs:597) ------------------------------------------------ */
+/* Register `n` affine points (host pointer, or device pointer if on_device). group = 1 (G1) or 2 (G2).
+ * precompute_window_bits > 0 additionally stores 2^(c*w)*P for every window (HBM for speed: all
+ * windows then share one bucket set and no doubling chain remains); 0 = plain bases. */
+int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, int on_device,
+                    int precompute_window_bits, mg_bases **out);
+void mg_bases_destroy(mg_bases *bases);
+size_t mg_bases_device_bytes(const mg_bases *bases);
+/* Host-to-host convenience: result = sum_i scalars[i] * bases[i], i < n <= len(bases).
+ * scalars: n x 4 u64 canonical. out: affine Montgomery (infinity = zeros). */
+int mg_msm(const mg_bases *bases, const uint64_t *scalars_canonical, size_t n, uint64_t *out_affine_mont);
+/* Scalars already resident in HBM (the timed path). scalars_mont != 0: scalars are Montgomery Fr and
+ * `into_repr` is applied on the device. window_bits = 0 lets the library choose. */
+int mg_msm_launch(const mg_bases *bases, const uint64_t *d_scalars, size_t n, int scalars_mont, int window_bits,
+                  mg_msm_job **job);
+int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine_mont); /* waits, folds, frees the job */
+/* sum of the registered points themselves (multi-GPU partial-point reduction, tests) */
+int mg_points_sum(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, uint64_t *out_affine_mont);
+/* [k_i] * base for n canonical scalars in HBM -> n affine points in HBM (fixed-base batch multiply:
+ * synthetic base generation; key generation as in ark-groth16 generate_parameters) */
+int mg_fixed_base_mul(mg_curve_t curve, int group, const uint64_t *base_affine_mont, const uint64_t *d_scalars,
+                      size_t n, uint64_t *d_out_affine_mont);
+/* arkworks canonical serialisation of one affine point (compressed: 32/48/64/96 B) */
+int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine_mont, int compressed, uint8_t *out);
+
+/* ---- radix-2 NTT over Fr: replaces ark_poly::Radix2EvaluationDomain::{fft,ifft,coset_fft,
+ *      coset_ifft}_in_place (ark-poly 0.3.0; used 7x per proof by R1CStoQAP::witness_map) ------------ */
+/* data: 2^log_n Montgomery Fr elements, natural order in and out, transformed in place. */
+int mg_ntt(mg_curve_t curve, uint64_t *data_mont, unsigned log_n, int inverse, int coset);
+int mg_ntt_device(mg_curve_t curve, uint64_t *d_data_mont, unsigned log_n, int inverse, int coset);
+
+/* ---- Groth16 proving context: replaces ProvingContext<E>{proving_key} (groth16.rs:216-245) +
+ *      ark_groth16::create_proof ----------------------------------------------------------------------- */
+typedef struct {
+    uint64_t n_vars;   /* V: instance + witness variables (len of a_query) */
+    uint64_t n_inputs; /* P: instance variables incl. the constant one */
+    uint64_t h_len;    /* len(h_query): D-1 (ark setup) or D (MPC keys, mpc.rs:372-377) */
+    const uint64_t *alpha_g1, *beta_g1, *delta_g1; /* G1 affine */
+    const uint64_t *beta_g2, *delta_g2;            /* G2 affine */
+    const uint64_t *a_query;    /* V   x G1 */
+    const uint64_t *b_g1_query; /* V   x G1 */
+    const uint64_t *b_g2_query; /* V   x G2 */
+    const uint64_t *h_query;    /* h_len x G1 */
+    const uint64_t *l_query;    /* V-P x G1 */
+} mg_pk_view;
+
+typedef struct {
+    const uint32_t *row_ptr; /* m+1 */
+    const uint32_t *col;     /* nnz  */
+    const uint64_t *val;     /* nnz x 4, Montgomery Fr */
+    uint64_t nnz;
+} mg_csr;
+
+/* Uploads and re-lays the proving key once (lifetime = the Rust ProvingContext). */
+int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
+/* Once per circuit shape: the matrices of `cs.to_matrices()` (identical for every proof of a shape). */
+int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t num_constraints);
+/* One proof. z = instance || witness (V x 4 u64 Montgomery), r, s = the two blinding scalars drawn by
+ * the shim with the reference's own RNG in create_random_proof's order (Montgomery).
+ * proof_out: 128 B (BN254) / 192 B (BLS12-381). */
+int mg_groth16_prove(const mg_ctx *ctx, const uint64_t *z_mont, const uint64_t r_mont[4], const uint64_t s_mont[4],
+                     uint8_t *proof_out);
+/* h = R1CStoQAP::witness_map(z): D x 4 u64 Montgomery coefficients (tests / parity) */
+int mg_witness_map(const mg_ctx *ctx, const uint64_t *z_mont, uint64_t *h_out_mont);
+uint64_t mg_ctx_domain_size(const mg_ctx *ctx);
+void mg_ctx_destroy(mg_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

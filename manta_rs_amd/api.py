@@ -1,0 +1,342 @@
+"""ctypes binding of libmantagpu.so + the Python mirror of the reference's prover interface.
+
+Every call goes through the C ABI declared in include/mantagpu.h -- the same entry points the Rust
+shim of INTEGRATION.md binds. There is no CPU path here: if the shared library (built by
+`__graft_entry__.build()` / `make -C manta_rs_amd/csrc`) is absent, import raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmantagpu.so")
+
+BN254, BLS12_381 = 0, 1
+FQ_LIMBS = {BN254: 4, BLS12_381: 6}
+
+
+class MantaGpuError(RuntimeError):
+    """Mirror of the reference's opaque unit `Error` (manta-crypto/src/arkworks/groth16.rs:50-60),
+    carrying the status code and the library's detail string."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        detail = LIB.mg_last_error().decode() if status == 2 else ""
+        super().__init__(f"{where}: {LIB.mg_strerror(status).decode()} ({status}) {detail}")
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MI355X HIP library is the product and there is no CPU fallback. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C manta_rs_amd/csrc`).")
+    try:  # share torch's HIP runtime if torch is (or will be) in this process
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib.mg_strerror.restype = ctypes.c_char_p
+    lib.mg_last_error.restype = ctypes.c_char_p
+    lib.mg_bases_device_bytes.restype = ctypes.c_size_t
+    lib.mg_ctx_domain_size.restype = ctypes.c_uint64
+    return lib
+
+
+LIB = _load()
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+EXPORTS = [
+    "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
+    "mg_memcpy_d2h", "mg_device_synchronize", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
+    "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_point_serialize", "mg_ntt",
+    "mg_ntt_device", "mg_ctx_create", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_witness_map", "mg_ctx_domain_size",
+    "mg_ctx_destroy",
+]
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise MantaGpuError(rc, where)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def init(device=0):
+    _chk(LIB.mg_init(int(device)), "mg_init")
+
+
+def device_count():
+    c = ctypes.c_int(0)
+    _chk(LIB.mg_device_count(ctypes.byref(c)), "mg_device_count")
+    return c.value
+
+
+def synchronize():
+    _chk(LIB.mg_device_synchronize(), "mg_device_synchronize")
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned by the library's HIP runtime."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        ptr = _vp()
+        _chk(LIB.mg_malloc(ctypes.byref(ptr), _sz(self.nbytes)), "mg_malloc")
+        self.ptr = ptr
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        _chk(LIB.mg_memcpy_h2d(b.ptr, _p(arr), _sz(arr.nbytes)), "mg_memcpy_h2d")
+        return b
+
+    def to_numpy(self, dtype=np.uint64, shape=None):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _chk(LIB.mg_memcpy_d2h(_p(out), self.ptr, _sz(self.nbytes)), "mg_memcpy_d2h")
+        return out if shape is None else out.reshape(shape)
+
+    def offset(self, nbytes):
+        return _vp(self.ptr.value + int(nbytes))
+
+    def free(self):
+        if self.ptr is not None and self.ptr.value:
+            LIB.mg_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def affine_limbs(curve, group):
+    return 2 * FQ_LIMBS[curve] * (2 if group == 2 else 1)
+
+
+class Bases:
+    """A static vector of curve points resident in HBM (the `bases: &[G::Affine]` argument of
+    `VariableBaseMSM::multi_scalar_mul`, made persistent because proving-key queries never change)."""
+
+    def __init__(self, curve, group, points, precompute_window_bits=0, on_device=False):
+        self.curve, self.group = curve, group
+        h = _vp()
+        if on_device:
+            ptr, n = points
+            _chk(LIB.mg_bases_create(curve, group, ptr, _sz(n), 1, int(precompute_window_bits), ctypes.byref(h)),
+                 "mg_bases_create")
+            self.n = n
+        else:
+            pts = _u64(points)
+            assert pts.ndim == 2 and pts.shape[1] == affine_limbs(curve, group), pts.shape
+            self.n = pts.shape[0]
+            _chk(LIB.mg_bases_create(curve, group, _p(pts), _sz(self.n), 0, int(precompute_window_bits),
+                                     ctypes.byref(h)), "mg_bases_create")
+        self.handle = h
+
+    def device_bytes(self):
+        return LIB.mg_bases_device_bytes(self.handle)
+
+    def close(self):
+        if self.handle is not None:
+            LIB.mg_bases_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MsmJob:
+    def __init__(self, bases, handle):
+        self.bases, self.handle = bases, handle
+
+    def finish(self):
+        out = np.zeros(affine_limbs(self.bases.curve, self.bases.group), dtype=np.uint64)
+        _chk(LIB.mg_msm_finish(self.handle, _p(out)), "mg_msm_finish")
+        self.handle = None
+        return out
+
+
+class VariableBaseMSM:
+    """Mirror of ark_ec::msm::VariableBaseMSM (ark-ec 0.3.0; call sites in ark-groth16 create_proof,
+    reached from manta-crypto/src/arkworks/groth16.rs:597)."""
+
+    @staticmethod
+    def multi_scalar_mul(bases: Bases, scalars) -> np.ndarray:
+        """scalars: (n,4) uint64 canonical (`into_repr`). Returns the affine result (Montgomery limbs,
+        infinity = zeros). Like arkworks, zips to the shorter of bases/scalars."""
+        sc = _u64(scalars)
+        out = np.zeros(affine_limbs(bases.curve, bases.group), dtype=np.uint64)
+        _chk(LIB.mg_msm(bases.handle, _p(sc), _sz(sc.shape[0]), _p(out)), "mg_msm")
+        return out
+
+    @staticmethod
+    def launch(bases: Bases, d_scalars, n, scalars_mont=False, window_bits=0) -> MsmJob:
+        """Scalars already in HBM (DeviceBuffer or raw pointer); returns a job to `finish()`."""
+        ptr = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else d_scalars
+        h = _vp()
+        _chk(LIB.mg_msm_launch(bases.handle, ptr, _sz(n), int(scalars_mont), int(window_bits), ctypes.byref(h)),
+             "mg_msm_launch")
+        return MsmJob(bases, h)
+
+
+def points_sum(curve, group, points):
+    pts = _u64(points)
+    out = np.zeros(affine_limbs(curve, group), dtype=np.uint64)
+    _chk(LIB.mg_points_sum(curve, group, _p(pts), _sz(pts.shape[0]), _p(out)), "mg_points_sum")
+    return out
+
+
+def fixed_base_mul(curve, group, base, d_scalars: DeviceBuffer, n) -> DeviceBuffer:
+    out = DeviceBuffer(n * affine_limbs(curve, group) * 8)
+    _chk(LIB.mg_fixed_base_mul(curve, group, _p(_u64(base)), d_scalars.ptr, _sz(n), out.ptr), "mg_fixed_base_mul")
+    return out
+
+
+def point_serialize(curve, group, point, compressed=True):
+    nb = FQ_LIMBS[curve] * 8 * (2 if group == 2 else 1) * (1 if compressed else 2)
+    out = ctypes.create_string_buffer(nb)
+    _chk(LIB.mg_point_serialize(curve, group, _p(_u64(point)), int(compressed), out), "mg_point_serialize")
+    return out.raw
+
+
+class Radix2EvaluationDomain:
+    """Mirror of ark_poly::Radix2EvaluationDomain<Fr> (ark-poly 0.3.0)."""
+
+    def __init__(self, curve, size):
+        self.curve = curve
+        self.log_size = max(0, (int(size) - 1).bit_length())
+        self.size = 1 << self.log_size
+
+    def _run(self, data, inverse, coset):
+        d = np.array(data, dtype=np.uint64, copy=True)
+        assert d.shape == (self.size, 4)
+        _chk(LIB.mg_ntt(self.curve, _p(d), self.log_size, int(inverse), int(coset)), "mg_ntt")
+        return d
+
+    def fft(self, data):
+        return self._run(data, False, False)
+
+    def ifft(self, data):
+        return self._run(data, True, False)
+
+    def coset_fft(self, data):
+        return self._run(data, False, True)
+
+    def coset_ifft(self, data):
+        return self._run(data, True, True)
+
+    def fft_device(self, dbuf: DeviceBuffer, inverse=False, coset=False):
+        _chk(LIB.mg_ntt_device(self.curve, dbuf.ptr, self.log_size, int(inverse), int(coset)), "mg_ntt_device")
+
+
+# ------------------------------------------------------------------------------------------------ Groth16
+class _PkView(ctypes.Structure):
+    _fields_ = [("n_vars", ctypes.c_uint64), ("n_inputs", ctypes.c_uint64), ("h_len", ctypes.c_uint64)] + [
+        (k, _vp) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2", "a_query", "b_g1_query",
+                           "b_g2_query", "h_query", "l_query")]
+
+
+class _Csr(ctypes.Structure):
+    _fields_ = [("row_ptr", _vp), ("col", _vp), ("val", _vp), ("nnz", ctypes.c_uint64)]
+
+
+class R1CS:
+    """Mirror of manta_crypto::arkworks::constraint::R1CS<F> as the prover sees it: the matrices of
+    `cs.to_matrices()` and the full assignment z = instance || witness (Montgomery Fr)."""
+
+    def __init__(self, curve, A, B, C, num_constraints, num_instance, z):
+        self.curve, self.A, self.B, self.C = curve, A, B, C
+        self.num_constraints, self.num_instance = int(num_constraints), int(num_instance)
+        self.z = _u64(z)
+
+    @classmethod
+    def from_circuit(cls, c):
+        return cls(c.curve, c.A, c.B, c.C, c.m, c.P, c.z)
+
+
+class ProvingContext:
+    """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
+    device-resident proving key; created once, shared by every proof of the shape."""
+
+    def __init__(self, curve, pk):
+        """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
+        b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P."""
+        self.curve = curve
+        self._keep = [_u64(getattr(pk, k)) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2",
+                                                     "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
+        v = _PkView(pk.V, pk.P, self._keep[8].shape[0], *[_p(a) for a in self._keep])
+        h = _vp()
+        _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")
+        self._keep = None  # the library copied everything
+        self.handle = h
+        self._shape = None
+
+    def set_r1cs(self, r1cs: R1CS):
+        ms = []
+        for M in (r1cs.A, r1cs.B, r1cs.C):
+            rp = np.ascontiguousarray(M.row_ptr, dtype=np.uint32)
+            col = np.ascontiguousarray(M.col, dtype=np.uint32)
+            val = _u64(M.val)
+            ms.append((rp, col, val, _Csr(_p(rp), _p(col), _p(val), len(col))))
+        _chk(LIB.mg_ctx_set_r1cs(self.handle, ctypes.byref(ms[0][3]), ctypes.byref(ms[1][3]), ctypes.byref(ms[2][3]),
+                                 ctypes.c_uint64(r1cs.num_constraints)), "mg_ctx_set_r1cs")
+        self._shape = (r1cs.num_constraints, r1cs.num_instance)
+
+    @property
+    def domain_size(self):
+        return LIB.mg_ctx_domain_size(self.handle)
+
+    def witness_map(self, z):
+        h = np.zeros((self.domain_size, 4), dtype=np.uint64)
+        _chk(LIB.mg_witness_map(self.handle, _p(_u64(z)), _p(h)), "mg_witness_map")
+        return h
+
+    def close(self):
+        if self.handle is not None:
+            LIB.mg_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+PROOF_BYTES = {BN254: 128, BLS12_381: 192}
+
+
+class Groth16:
+    """Mirror of `impl ProofSystem for Groth16<E>` (manta-crypto/src/arkworks/groth16.rs:548-610), prove only."""
+
+    @staticmethod
+    def prove(context: ProvingContext, compiler: R1CS, rng) -> bytes:
+        """`rng` supplies the two blinding scalars exactly where ark-groth16's create_random_proof draws
+        them: r = Fr::rand(rng); s = Fr::rand(rng) -- `rng()` must return one Montgomery Fr element
+        (4 x u64) per call. Returns the arkworks canonical compressed proof bytes."""
+        if context._shape != (compiler.num_constraints, compiler.num_instance):
+            context.set_r1cs(compiler)
+        r = _u64(rng())
+        s = _u64(rng())
+        return Groth16.prove_with_randomness(context, compiler.z, r, s)
+
+    @staticmethod
+    def prove_with_randomness(context: ProvingContext, z, r, s) -> bytes:
+        out = ctypes.create_string_buffer(PROOF_BYTES[context.curve])
+        _chk(LIB.mg_groth16_prove(context.handle, _p(_u64(z)), _p(_u64(r)), _p(_u64(s)), out), "mg_groth16_prove")
+        return out.raw

@@ -1,0 +1,145 @@
+// Device-side short-Weierstrass (a = 0) group arithmetic for gfx950, generic over the coordinate
+// field F (Fp<Fq> for G1, Fp2<Fq> for G2).
+//
+// Replaces (on the GPU) ark-ec ^0.3.0 `short_weierstrass_jacobian` add/double/mixed-add used inside
+// VariableBaseMSM (reference call site
+// manta-crypto/src/arkworks/groth16.rs:597). Group elements are unique, so the GPU is free to use a
+// different coordinate system: bucket accumulators use XYZZ ("extended Jacobian": x = X/ZZ,
+// y = Y/ZZZ, ZZ^3 = ZZZ^2), whose mixed add is 8M+2S vs 7M+4S and needs no Z inversion trickery.
+// Exceptional cases (infinity, P+P, P+(-P)) are handled exactly: real proving keys contain infinity
+// entries and repeated bases (SURVEY.md section 7 "Hard parts").
+//
+// Memory formats: affine = x || y (Montgomery limbs), infinity = all zero (b != 0 so (0,0) is never
+// on the curve); XYZZ = X || Y || ZZ || ZZZ, infinity <=> ZZ == 0.
+#pragma once
+#include "fp_dev.h"
+
+namespace mg {
+
+template <class F> struct Affine {
+    F x, y;
+    MG_DEV bool is_inf() const { return x.is_zero() & y.is_zero(); }
+    static MG_DEV Affine load(const u32 *p) { return Affine{F::load(p), F::load(p + F::N)}; }
+    MG_DEV void store(u32 *p) const {
+        x.store(p);
+        y.store(p + F::N);
+    }
+    static constexpr int WORDS = 2 * F::N;
+};
+
+template <class F> struct XYZZ {
+    F x, y, zz, zzz;
+    static constexpr int WORDS = 4 * F::N;
+    MG_DEV bool is_inf() const { return zz.is_zero(); }
+    static MG_DEV XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
+    static MG_DEV XYZZ from_affine(const Affine<F> &a) {
+        if (a.is_inf()) return inf();
+        return XYZZ{a.x, a.y, F::one(), F::one()};
+    }
+    static MG_DEV XYZZ load(const u32 *p) {
+        return XYZZ{F::load(p), F::load(p + F::N), F::load(p + 2 * F::N), F::load(p + 3 * F::N)};
+    }
+    MG_DEV void store(u32 *p) const {
+        x.store(p);
+        y.store(p + F::N);
+        zz.store(p + 2 * F::N);
+        zzz.store(p + 3 * F::N);
+    }
+    static MG_DEV XYZZ shfl(const XYZZ &a, int src) {
+        return XYZZ{F::shfl(a.x, src), F::shfl(a.y, src), F::shfl(a.zz, src), F::shfl(a.zzz, src)};
+    }
+    static MG_DEV XYZZ select(bool c, const XYZZ &a, const XYZZ &b) {
+        return XYZZ{F::select(c, a.x, b.x), F::select(c, a.y, b.y), F::select(c, a.zz, b.zz), F::select(c, a.zzz, b.zzz)};
+    }
+
+    // 2*(affine) -- mdbl-2008-s-1
+    static MG_DEV XYZZ dbl_affine(const Affine<F> &p) {
+        F U = F::dbl(p.y);
+        F V = F::sqr(U);
+        F W = F::mul(U, V);
+        F S = F::mul(p.x, V);
+        F X2 = F::sqr(p.x);
+        F M = F::add(F::dbl(X2), X2);
+        F X3 = F::sub(F::sqr(M), F::dbl(S));
+        F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        return XYZZ{X3, Y3, V, W};
+    }
+    // dbl-2008-s-1
+    static MG_DEV XYZZ dbl(const XYZZ &p) {
+        if (p.is_inf()) return p;
+        F U = F::dbl(p.y);
+        F V = F::sqr(U);
+        F W = F::mul(U, V);
+        F S = F::mul(p.x, V);
+        F X2 = F::sqr(p.x);
+        F M = F::add(F::dbl(X2), X2);
+        F X3 = F::sub(F::sqr(M), F::dbl(S));
+        F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        return XYZZ{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+    }
+    // acc += (neg ? -q : q), q affine -- madd-2008-s with exact exceptional cases
+    MG_DEV void madd(const Affine<F> &q_in, bool neg) {
+        if (q_in.is_inf()) return;
+        Affine<F> q = q_in;
+        if (neg) q.y = F::neg(q.y);
+        if (is_inf()) {
+            x = q.x;
+            y = q.y;
+            zz = F::one();
+            zzz = F::one();
+            return;
+        }
+        F U2 = F::mul(q.x, zz);
+        F S2 = F::mul(q.y, zzz);
+        F P = F::sub(U2, x);
+        F R = F::sub(S2, y);
+        if (P.is_zero()) {
+            if (R.is_zero())
+                *this = dbl_affine(q);
+            else
+                *this = inf();
+            return;
+        }
+        F PP = F::sqr(P);
+        F PPP = F::mul(P, PP);
+        F Q = F::mul(x, PP);
+        F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(y, PPP));
+        x = X3;
+        y = Y3;
+        zz = F::mul(zz, PP);
+        zzz = F::mul(zzz, PPP);
+    }
+    // acc += o -- add-2008-s with exact exceptional cases
+    MG_DEV void add(const XYZZ &o) {
+        if (o.is_inf()) return;
+        if (is_inf()) {
+            *this = o;
+            return;
+        }
+        F U1 = F::mul(x, o.zz);
+        F U2 = F::mul(o.x, zz);
+        F S1 = F::mul(y, o.zzz);
+        F S2 = F::mul(o.y, zzz);
+        F P = F::sub(U2, U1);
+        F R = F::sub(S2, S1);
+        if (P.is_zero()) {
+            if (R.is_zero())
+                *this = dbl(*this);
+            else
+                *this = inf();
+            return;
+        }
+        F PP = F::sqr(P);
+        F PPP = F::mul(P, PP);
+        F Q = F::mul(U1, PP);
+        F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+        F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+        x = X3;
+        y = Y3;
+        zz = F::mul(F::mul(zz, o.zz), PP);
+        zzz = F::mul(F::mul(zzz, o.zzz), PPP);
+    }
+};
+
+} // namespace mg

@@ -1,0 +1,133 @@
+// Host-side runtime interfaces of the MI355X Groth16 hot path (one process per GPU; every object
+// below lives on the current HIP device). Curve/group-specific code sits behind GroupEngine so the
+// C ABI (include/mantagpu.h) can dispatch on (curve, group) at run time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <vector>
+
+namespace mg {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_HIP = 2, MG_ERR_OOM = 3, MG_ERR_DOMAIN = 4, MG_ERR_STATE = 5 };
+
+#define MG_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            mg::set_last_hip_error(e_, #expr, __FILE__, __LINE__);                                                \
+            return (e_ == hipErrorOutOfMemory) ? mg::MG_ERR_OOM : mg::MG_ERR_HIP;                                 \
+        }                                                                                                         \
+    } while (0)
+void set_last_hip_error(hipError_t e, const char *expr, const char *file, int line);
+const char *last_error_string();
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T *as() { return (T *)p; }
+};
+
+// Pippenger plan. Signed digits of c bits, B = 2^(c-1) buckets per bucket-window.
+struct MsmPlan {
+    int c = 0;       // window bits
+    int W = 0;       // windows = ceil((scalar_bits+1)/c)
+    u32 B = 0;       // buckets per window
+    int Wb = 0;      // bucket windows: W (plain) or 1 (bases precomputed for every window)
+    bool precomp = false;
+    u32 L = 0;       // sorted entries per thread in the chunk-accumulate kernel
+};
+
+// A static set of bases resident in HBM (a proving-key query, or a caller-registered vector).
+struct BaseSet {
+    int curve = 0, group = 1;
+    size_t n = 0;
+    u32 *d_pts = nullptr; // affine AoS; with precompute: W tables of n points, table w = 2^(c w) * P
+    int pre_c = 0, pre_W = 0; // 0 = no precompute
+    size_t bytes = 0;
+};
+
+// Per-call scratch for one MSM (device + pinned host staging). Pooled per engine.
+struct MsmWorkspace {
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, buckets, pkeys[2], ppts[2], redA, redS, redP, misc;
+    void *h_stage = nullptr; // pinned
+    size_t h_stage_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    // host-side description of what was staged (filled by msm_launch, consumed by msm_finish)
+    MsmPlan plan;
+    u32 T1 = 0, nP = 0;
+    int pending = 0;
+    ~MsmWorkspace();
+};
+
+// Opaque host point (XYZZ, 64-bit limbs) big enough for G2/BLS12-381.
+struct HostPoint {
+    u64 w[4 * 12];
+};
+
+class GroupEngine {
+  public:
+    virtual ~GroupEngine() {}
+    virtual int curve() const = 0;
+    virtual int group() const = 0;
+    virtual int affine_words() const = 0; // u32 per affine point
+    virtual int xyzz_words() const = 0;
+    virtual int scalar_bits() const = 0;
+
+    // bases: affine Montgomery AoS (host or device pointer). precompute_c > 0 builds 2^(c w) tables.
+    virtual int bases_create(const u32 *pts, size_t n, bool src_on_device, int precompute_c, BaseSet **out) = 0;
+    virtual void bases_destroy(BaseSet *) = 0;
+
+    virtual MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override) const = 0;
+    // Enqueue the whole MSM on ws->stream: scalars are device-resident (canonical, or Montgomery if
+    // scalars_mont), n <= bs->n. Result is staged to pinned memory; call msm_finish to fold it.
+    virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
+                           MsmWorkspace *ws) = 0;
+    // Waits for the stream, folds the staged partial points on the host. out = XYZZ host point.
+    virtual int msm_finish(MsmWorkspace *ws, HostPoint *out) = 0;
+
+    // host-point helpers (type-erased)
+    virtual void hp_set_inf(HostPoint *p) const = 0;
+    virtual void hp_from_affine(HostPoint *p, const u32 *affine_words) const = 0;
+    virtual void hp_add(HostPoint *acc, const HostPoint *o) const = 0;
+    virtual void hp_neg(HostPoint *p) const = 0;
+    virtual void hp_mul(HostPoint *p, const u64 *k4) const = 0; // p = [k]p, k canonical 4x u64
+    virtual void hp_to_affine(const HostPoint *p, u32 *affine_words) const = 0;
+    virtual void hp_serialize(const HostPoint *p, unsigned char *out, bool compressed) const = 0;
+    virtual int point_bytes(bool compressed) const = 0;
+
+    // [k_i] * base for a batch of canonical scalars (device), result affine (device). Used for
+    // synthetic base generation and key generation (fixed-base batch multiplication).
+    virtual int fixed_base_mul(const u32 *base_affine_host, const u32 *d_scalars, size_t n, u32 *d_out_affine,
+                               hipStream_t s) = 0;
+    // sum of affine points (device) -> host point
+    virtual int sum_affine(const u32 *d_pts, size_t n, HostPoint *out) = 0;
+
+    MsmWorkspace *ws_acquire();
+    void ws_release(MsmWorkspace *);
+
+  protected:
+    std::mutex ws_mu_;
+    std::vector<MsmWorkspace *> ws_free_;
+};
+
+GroupEngine *make_engine_bn254_g1();
+GroupEngine *make_engine_bn254_g2();
+GroupEngine *make_engine_bls381_g1();
+GroupEngine *make_engine_bls381_g2();
+GroupEngine *get_engine(int curve, int group); // cached singleton per (curve, group)
+
+// radix sort of (key,val) pairs, keys < 2^end_bit (sort.hip; hipCUB device-wide radix sort)
+size_t sort_pairs_temp_bytes(size_t n);
+int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_out, size_t n, int end_bit,
+               void *tmp, size_t tmp_bytes, hipStream_t s);
+
+} // namespace mg

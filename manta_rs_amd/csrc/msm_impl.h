@@ -1,0 +1,629 @@
+// Pippenger variable-base MSM on gfx950 -- kernels and host orchestration, templated on the curve
+// and group. Instantiated once per (curve, group) in msm_<curve>_<group>.hip.
+//
+// Replaces ark-ec ^0.3.0 `VariableBaseMSM::multi_scalar_mul` (4x G1 + 1x G2 per proof, SURVEY.md rows
+// a-7/a-8; reached from manta-crypto/src/arkworks/groth16.rs:597). The result is the same group
+// element; the schedule is GPU-native and differs from arkworks' on purpose:
+//
+//   K5 digits      scalar -> W signed c-bit digits -> (bucket key, base index|sign) pairs, coalesced
+//   K6 sort        one device-wide radix sort of the n*W pairs by bucket key (sort.hip)
+//   K7a chunks     every lane walks L consecutive sorted pairs, mixed-adding gathered bases into an
+//                  XYZZ accumulator kept in VGPRs; bucket runs that start and end inside the chunk are
+//                  stored straight to their bucket, the chunk's first/last run become "partials"
+//   K7b merge      partials (still sorted by key) are combined by a wavefront-wide segmented scan
+//                  (shuffles, no LDS, no atomics), 64 -> 2 per wave and level, until one wave is left
+//   K8 reduce      sum_k (k+1) B_k per bucket window as wavefront suffix-scan + reduction per 64-bucket
+//                  tile, two levels; <= a few dozen points per window go to the host
+//   K9 (host)      fold those points, Horner over windows (none when the bases carry precomputed
+//                  2^(c w) multiples: all windows then share ONE bucket set and no doubling is left)
+//
+// Load balance never depends on the scalar distribution: work is split by sorted position, not by
+// bucket, so a witness that is 25 % ones (one giant bucket) costs the same as uniform scalars.
+// No global atomics on points; every bucket is written exactly once; results are deterministic.
+#pragma once
+#include "ec_dev.h"
+#include "engine.h"
+#include "host_ec.h"
+#include "params_gen.h"
+#include <cstdio>
+#include <cstring>
+
+namespace mg {
+
+static constexpr u32 KEY_INVALID_BIT = 0x80000000u; // never used as a key; INVALID = Wb*B (sorts last)
+
+// --------------------------------------------------------------------------------------------
+// K5: digits
+// --------------------------------------------------------------------------------------------
+MG_DEV u32 limb_at(const u32 (&s)[8], int i) { // dynamic index without scratch
+    u32 r = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r = (i == j) ? s[j] : r;
+    return r;
+}
+template <class FrC>
+__global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
+                                                     int precomp, u32 tstride, int mont, u32 invalid,
+                                                     u32 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 s[8];
+    {
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + (size_t)i * 8);
+        uint4 a = p[0], b = p[1];
+        s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b.x, s[5] = b.y, s[6] = b.z, s[7] = b.w;
+    }
+    if (mont) { // ark-ff into_repr on the device
+        Fp<FrC> f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = s[j];
+        f = Fp<FrC>::from_mont(f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = f.v[j];
+    }
+    u32 carry = 0;
+    const u32 mask = (1u << c) - 1;
+    for (int w = 0; w < W; ++w) {
+        const int start = w * c;
+        const int limb = start >> 5, off = start & 31;
+        u64 v = limb < 8 ? (u64)limb_at(s, limb) : 0;
+        if (limb + 1 < 8) v |= (u64)limb_at(s, limb + 1) << 32;
+        u32 d = ((u32)(v >> off) & mask) + carry;
+        u32 neg = 0;
+        carry = 0;
+        if (d > B) {
+            d = (1u << c) - d;
+            neg = 1;
+            carry = 1;
+        }
+        const size_t o = (size_t)w * n + i;
+        if (d == 0) {
+            keys[o] = invalid;
+            vals[o] = 0;
+        } else {
+            keys[o] = precomp ? (d - 1) : ((u32)w * B + d - 1);
+            vals[o] = (precomp ? ((u32)w * tstride + i) : i) | (neg << 31);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K7a: chunk accumulate
+// --------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+                                                         u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
+                                                         u32 *__restrict__ buckets, u32 *__restrict__ pkeys,
+                                                         u32 *__restrict__ ppts, u32 T) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const size_t begin = (size_t)t * L;
+    size_t end = begin + L;
+    if (end > M) end = M;
+    u32 cur = keys[begin];
+    if (cur == invalid) {
+        pkeys[2 * t] = invalid;
+        pkeys[2 * t + 1] = invalid;
+        return;
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    bool first = true;
+    for (size_t j = begin; j < end; ++j) {
+        const u32 k = keys[j];
+        if (k != cur) {
+            if (first) {
+                pkeys[2 * t] = cur;
+                acc.store(ppts + (size_t)(2 * t) * XYZZ<F>::WORDS);
+                first = false;
+            } else {
+                acc.store(buckets + (size_t)cur * XYZZ<F>::WORDS);
+            }
+            acc = XYZZ<F>::inf();
+            cur = k;
+            if (k == invalid) break;
+        }
+        const u32 v = vals[j];
+        const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * Affine<F>::WORDS);
+        acc.madd(p, (v >> 31) != 0);
+    }
+    if (first) { // the whole chunk is one run
+        pkeys[2 * t] = cur;
+        acc.store(ppts + (size_t)(2 * t) * XYZZ<F>::WORDS);
+        pkeys[2 * t + 1] = cur;
+        XYZZ<F>::inf().store(ppts + (size_t)(2 * t + 1) * XYZZ<F>::WORDS);
+    } else {
+        pkeys[2 * t + 1] = cur; // may be `invalid` (then the point is never read as a summand)
+        acc.store(ppts + (size_t)(2 * t + 1) * XYZZ<F>::WORDS);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K7b: wavefront segmented merge of partials
+// --------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void merge_partials(const u32 *__restrict__ pkeys, const u32 *__restrict__ ppts,
+                                                      u32 cnt, u32 invalid, int final_level,
+                                                      u32 *__restrict__ buckets, u32 *__restrict__ okeys,
+                                                      u32 *__restrict__ opts, u32 n_waves) {
+    const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_waves) return;
+    const u32 e = wave * 64 + lane;
+    u32 key = invalid;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (e < cnt) {
+        key = pkeys[e];
+        if (key != invalid) acc = XYZZ<F>::load(ppts + (size_t)e * XYZZ<F>::WORDS);
+    }
+    // inclusive segmented scan (Hillis-Steele); keys are sorted so "key at distance d equal" <=> same run
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 nk = __shfl_up(key, d, 64);
+        const bool take = (lane >= d) && (nk == key) && (key != invalid);
+        if (!__any(take)) break;
+        const XYZZ<F> o = XYZZ<F>::shfl(acc, lane - d < 0 ? lane : lane - d);
+        if (take) acc.add(o);
+    }
+    const u32 next_key = __shfl_down(key, 1, 64);
+    const bool seg_end = (lane == 63) || (next_key != key);
+    const u32 key0 = __shfl(key, 0, 64), key63 = __shfl(key, 63, 64);
+    if (!seg_end || key == invalid) {
+        // nothing to emit from this lane -- but a wave whose last run is `invalid` must still mark it
+        if (!final_level && lane == 63 && key == invalid) {
+            okeys[2 * wave + 1] = invalid;
+            if (key0 == invalid) okeys[2 * wave] = invalid;
+        }
+        return;
+    }
+    if (final_level) {
+        acc.store(buckets + (size_t)key * XYZZ<F>::WORDS);
+        return;
+    }
+    const bool is_first = (key == key0), is_last = (key == key63);
+    if (is_first) {
+        okeys[2 * wave] = key;
+        acc.store(opts + (size_t)(2 * wave) * XYZZ<F>::WORDS);
+        if (is_last) { // whole wave is one run
+            okeys[2 * wave + 1] = key;
+            XYZZ<F>::inf().store(opts + (size_t)(2 * wave + 1) * XYZZ<F>::WORDS);
+        }
+    } else if (is_last) {
+        okeys[2 * wave + 1] = key;
+        acc.store(opts + (size_t)(2 * wave + 1) * XYZZ<F>::WORDS);
+    } else {
+        acc.store(buckets + (size_t)key * XYZZ<F>::WORDS);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// K8: per-tile weighted sum. For the 64 items X_0..X_63 of a tile (missing items = infinity):
+//   A = sum_j X_j,  S = sum_j (j+1) X_j  -- via suffix scan (acc_j = sum_{i>=j} X_i) then sum of acc_j.
+// --------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/,
+                                                   u32 item_off, u32 n_items, u32 tiles_per_seg, u32 n_waves,
+                                                   u32 *__restrict__ outA, u32 *__restrict__ outS) {
+    const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= n_waves) return;
+    const u32 seg = wave / tiles_per_seg, tile = wave % tiles_per_seg;
+    const u32 idx = tile * 64 + lane;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (idx < n_items) acc = XYZZ<F>::load(in + ((size_t)seg * seg_stride + item_off + idx) * XYZZ<F>::WORDS);
+    for (int d = 1; d < 64; d <<= 1) { // suffix scan
+        const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+        if (lane + d < 64) acc.add(o);
+    }
+    if (lane == 0) acc.store(outA + (size_t)wave * XYZZ<F>::WORDS);
+    if (outS) {
+        for (int d = 32; d >= 1; d >>= 1) { // tree sum of the suffix sums
+            const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+            if (lane < d) acc.add(o);
+        }
+        if (lane == 0) acc.store(outS + (size_t)wave * XYZZ<F>::WORDS);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// precompute: table[w*n + i] = 2^(c w) * P_i (affine). Two kernels: doubling chains into XYZZ, then
+// batched conversion to affine with Montgomery's trick (one Fermat inversion per KB points).
+// --------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void precompute_chain(const u32 *__restrict__ base, u32 n, int c, int W,
+                                                        u32 *__restrict__ xyzz_out /* (W-1)*n */) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<F> p = XYZZ<F>::from_affine(Affine<F>::load(base + (size_t)i * Affine<F>::WORDS));
+    for (int w = 1; w < W; ++w) {
+        for (int k = 0; k < c; ++k) p = XYZZ<F>::dbl(p);
+        p.store(xyzz_out + ((size_t)(w - 1) * n + i) * XYZZ<F>::WORDS);
+    }
+}
+template <class F> struct FieldInv; // Fermat inversion on the device (slow, one-off use only)
+template <class C> struct FieldInv<Fp<C>> {
+    static __device__ Fp<C> inv(const Fp<C> &a) { return Fp<C>::inv(a); }
+};
+template <class C> struct FieldInv<Fp2<C>> {
+    static __device__ Fp2<C> inv(const Fp2<C> &a) {
+        typedef Fp<C> B;
+        B n = B::inv(B::add(B::sqr(a.c0), B::sqr(a.c1)));
+        return Fp2<C>{B::mul(a.c0, n), B::neg(B::mul(a.c1, n))};
+    }
+};
+template <class F, int KB>
+__global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restrict__ xyzz, size_t n,
+                                                            u32 *__restrict__ aff) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t b0 = t * KB;
+    if (b0 >= n) return;
+    // prefix products of d_k = zz*zzz (1 for infinity) are parked in the affine output's x slot
+    F run = F::one();
+    for (int k = 0; k < KB && b0 + k < n; ++k) {
+        const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
+        F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
+        F d = zz.is_zero() ? F::one() : F::mul(zz, zzz);
+        run.store(aff + (b0 + k) * Affine<F>::WORDS); // prefix before k
+        run = F::mul(run, d);
+    }
+    F inv = FieldInv<F>::inv(run);
+    int last = KB - 1;
+    if (b0 + KB > n) last = (int)(n - b0) - 1;
+    for (int k = last; k >= 0; --k) {
+        const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
+        u32 *dst = aff + (b0 + k) * Affine<F>::WORDS;
+        F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
+        if (zz.is_zero()) {
+            F::zero().store(dst);
+            F::zero().store(dst + F::N);
+            continue;
+        }
+        F pre = F::load(dst);
+        F dinv = F::mul(inv, pre); // 1/(zz*zzz)
+        inv = F::mul(inv, F::mul(zz, zzz));
+        F x = F::load(src), y = F::load(src + F::N);
+        F izz = F::mul(dinv, zzz), izzz = F::mul(dinv, zz);
+        F::mul(x, izz).store(dst);
+        F::mul(y, izzz).store(dst + F::N);
+    }
+}
+
+// [k_i] * base, k canonical; output XYZZ (converted by xyzz_to_affine_batch)
+template <class F>
+__global__ __launch_bounds__(256) void fixed_base_mul_kernel(const u32 *__restrict__ base_aff,
+                                                             const u32 *__restrict__ scalars, size_t n,
+                                                             u32 *__restrict__ out_xyzz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<F> b = Affine<F>::load(base_aff);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int limb = 7; limb >= 0; --limb) {
+        const u32 w = scalars[i * 8 + limb];
+        for (int bit = 31; bit >= 0; --bit) {
+            acc = XYZZ<F>::dbl(acc);
+            if ((w >> bit) & 1) acc.madd(b, false);
+        }
+    }
+    acc.store(out_xyzz + i * XYZZ<F>::WORDS);
+}
+
+// per-thread partial sums of affine points (strided), output XYZZ partials
+template <class F>
+__global__ __launch_bounds__(256) void sum_affine_kernel(const u32 *__restrict__ pts, size_t n, u32 T,
+                                                         u32 *__restrict__ out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = t; i < n; i += T) acc.madd(Affine<F>::load(pts + i * Affine<F>::WORDS), false);
+    acc.store(out + (size_t)t * XYZZ<F>::WORDS);
+}
+
+// --------------------------------------------------------------------------------------------
+// host orchestration
+// --------------------------------------------------------------------------------------------
+template <class Curve, int GROUP> struct GT;
+template <class Curve> struct GT<Curve, 1> {
+    typedef Fp<typename Curve::Fq> F;
+    typedef host::HFp<typename Curve::Fq> HF;
+};
+template <class Curve> struct GT<Curve, 2> {
+    typedef Fp2<typename Curve::Fq> F;
+    typedef host::HFp2<typename Curve::Fq> HF;
+};
+
+static inline u32 cdiv(size_t a, size_t b) { return (u32)((a + b - 1) / b); }
+
+template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public GroupEngine {
+  public:
+    typedef typename GT<Curve, GROUP>::F F;
+    typedef typename GT<Curve, GROUP>::HF HF;
+    typedef host::HPoint<HF> HP;
+    typedef typename Curve::Fr FrC;
+    static constexpr int AW = Affine<F>::WORDS, XW = XYZZ<F>::WORDS;
+    static_assert(sizeof(HP) <= sizeof(HostPoint), "HostPoint too small");
+
+    int curve() const override { return CURVE_ID; }
+    int group() const override { return GROUP; }
+    int affine_words() const override { return AW; }
+    int xyzz_words() const override { return XW; }
+    int scalar_bits() const override { return FrC::BITS; }
+    int point_bytes(bool compressed) const override { return compressed ? HF::BYTES : 2 * HF::BYTES; }
+
+    static HP &hp(HostPoint *p) { return *reinterpret_cast<HP *>(p); }
+    static const HP &hp(const HostPoint *p) { return *reinterpret_cast<const HP *>(p); }
+    void hp_set_inf(HostPoint *p) const override { hp(p) = HP::inf(); }
+    void hp_from_affine(HostPoint *p, const u32 *w) const override { hp(p) = HP::from_affine_words(w); }
+    void hp_add(HostPoint *a, const HostPoint *o) const override { hp(a) = HP::add(hp(a), hp(o)); }
+    void hp_neg(HostPoint *p) const override { hp(p) = hp(p).neg(); }
+    void hp_mul(HostPoint *p, const u64 *k4) const override { hp(p) = HP::mul(hp(p), k4, 4); }
+    void hp_to_affine(const HostPoint *p, u32 *w) const override { hp(p).to_affine_words(w); }
+    void hp_serialize(const HostPoint *p, unsigned char *out, bool compressed) const override {
+        hp(p).serialize(out, compressed);
+    }
+
+    // ---------------------------------------------------------------- bases
+    int bases_create(const u32 *pts, size_t n, bool src_on_device, int pre_c, BaseSet **out) override {
+        if (!pts || !n || !out) return MG_ERR_ARG;
+        BaseSet *bs = new BaseSet();
+        bs->curve = CURVE_ID;
+        bs->group = GROUP;
+        bs->n = n;
+        int W = 1;
+        if (pre_c > 0) {
+            W = (FrC::BITS + 1 + pre_c - 1) / pre_c;
+            bs->pre_c = pre_c;
+            bs->pre_W = W;
+        }
+        bs->bytes = (size_t)W * n * AW * 4;
+        hipError_t e = hipMalloc((void **)&bs->d_pts, bs->bytes);
+        if (e != hipSuccess) {
+            delete bs;
+            set_last_hip_error(e, "hipMalloc(bases)", __FILE__, __LINE__);
+            return MG_ERR_OOM;
+        }
+        e = hipMemcpy(bs->d_pts, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            bases_destroy(bs);
+            set_last_hip_error(e, "hipMemcpy(bases)", __FILE__, __LINE__);
+            return MG_ERR_HIP;
+        }
+        if (W > 1) {
+            u32 *tmp = nullptr;
+            const size_t cnt = (size_t)(W - 1) * n;
+            e = hipMalloc((void **)&tmp, cnt * XW * 4);
+            if (e != hipSuccess) {
+                bases_destroy(bs);
+                set_last_hip_error(e, "hipMalloc(precompute tmp)", __FILE__, __LINE__);
+                return MG_ERR_OOM;
+            }
+            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, bs->d_pts, (u32)n, pre_c,
+                               W, tmp);
+            constexpr int KB = 16;
+            hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(cnt, KB), 256)), dim3(256), 0, 0, tmp,
+                               cnt, bs->d_pts + n * AW);
+            e = hipDeviceSynchronize();
+            hipFree(tmp);
+            if (e != hipSuccess) {
+                bases_destroy(bs);
+                set_last_hip_error(e, "precompute kernels", __FILE__, __LINE__);
+                return MG_ERR_HIP;
+            }
+        }
+        *out = bs;
+        return MG_OK;
+    }
+    void bases_destroy(BaseSet *bs) override {
+        if (!bs) return;
+        if (bs->d_pts) hipFree(bs->d_pts);
+        delete bs;
+    }
+
+    // ---------------------------------------------------------------- plan
+    MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override) const override {
+        MsmPlan p;
+        if (bs->pre_c > 0) {
+            p.c = bs->pre_c;
+            p.W = bs->pre_W;
+            p.precomp = true;
+            p.Wb = 1;
+        } else {
+            int lg = 0;
+            while (((size_t)1 << lg) < n) ++lg;
+            int c = c_override > 0 ? c_override : (lg <= 8 ? 5 : lg <= 12 ? 8 : lg <= 15 ? 10 : lg <= 18 ? 12 : 14);
+            p.c = c;
+            p.W = (FrC::BITS + 1 + c - 1) / c;
+            p.Wb = p.W;
+        }
+        p.B = 1u << (p.c - 1);
+        // entries per lane: aim at >= ~128k lanes of work, 8 <= L <= 64
+        const size_t M = n * (size_t)p.W;
+        size_t L = M / (128 * 1024);
+        if (L < 8) L = 8;
+        if (L > 64) L = 64;
+        p.L = (u32)L;
+        return p;
+    }
+
+    // ---------------------------------------------------------------- launch
+    int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
+                   MsmWorkspace *ws) override {
+        if (!bs || !d_scalars || !ws || n == 0 || n > bs->n) return MG_ERR_ARG;
+        if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
+        const MsmPlan pl = plan_for(bs, n, c_override);
+        hipStream_t s = ws->stream;
+        const size_t M = n * (size_t)pl.W;
+        if (M >= (1ull << 31)) return MG_ERR_ARG;
+        const u32 nb = (u32)pl.Wb * pl.B; // real buckets; key nb = INVALID
+        const u32 invalid = nb;
+        int rc;
+        if ((rc = ws->keys_in.reserve(M * 4)) || (rc = ws->keys_out.reserve(M * 4)) ||
+            (rc = ws->vals_in.reserve(M * 4)) || (rc = ws->vals_out.reserve(M * 4)))
+            return rc;
+        const size_t tmpb = sort_pairs_temp_bytes(M);
+        if ((rc = ws->sort_tmp.reserve(tmpb))) return rc;
+        if ((rc = ws->buckets.reserve((size_t)(nb + 1) * XW * 4))) return rc;
+        const u32 T = cdiv(M, pl.L);
+        if ((rc = ws->pkeys[0].reserve((size_t)2 * T * 4)) || (rc = ws->ppts[0].reserve((size_t)2 * T * XW * 4)))
+            return rc;
+        const u32 waves1 = cdiv((size_t)2 * T, 64);
+        if ((rc = ws->pkeys[1].reserve((size_t)2 * waves1 * 4)) ||
+            (rc = ws->ppts[1].reserve((size_t)2 * waves1 * XW * 4)))
+            return rc;
+
+        // with precomputed tables the base index is w*stride + i: table w starts bs->n points after w-1
+        if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
+        hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
+                           pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalars_mont ? 1 : 0, invalid,
+                           ws->keys_in.as<u32>(), ws->vals_in.as<u32>());
+        int end_bit = 1;
+        while ((1u << end_bit) <= invalid) ++end_bit;
+        if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
+                             ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s)))
+            return rc;
+        MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
+        hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+                           ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, ws->buckets.as<u32>(),
+                           ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T);
+        u32 cnt = 2 * T;
+        int src = 0;
+        for (;;) {
+            const u32 waves = cdiv(cnt, 64);
+            const int fin = waves == 1;
+            hipLaunchKernelGGL((merge_partials<F>), dim3(cdiv(waves, 4)), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
+                               ws->ppts[src].as<u32>(), cnt, invalid, fin, ws->buckets.as<u32>(),
+                               ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves);
+            if (fin) break;
+            cnt = 2 * waves;
+            src ^= 1;
+        }
+        // ---- bucket reduce
+        const u32 segs = (u32)pl.Wb;
+        const u32 T0 = cdiv(pl.B, 64);
+        if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)))
+            return rc;
+        hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                           pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>());
+        u32 T1 = 0, nP = 0;
+        size_t stage_pts;
+        if (T0 == 1) {
+            // window sum = S0[seg]
+            stage_pts = segs;
+            if ((rc = stage_reserve(ws, stage_pts * XW * 4))) return rc;
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW * 4, hipMemcpyDeviceToHost, s));
+        } else {
+            T1 = cdiv(T0 - 1, 64); // level 1 over A0[1..T0-1]
+            nP = cdiv(T0, 64);     // plain sums of S0[0..T0-1]
+            if ((rc = ws->misc.reserve((size_t)segs * (2 * T1 + nP) * XW * 4))) return rc;
+            u32 *A1 = ws->misc.as<u32>();
+            u32 *S1 = A1 + (size_t)segs * T1 * XW;
+            u32 *P0 = S1 + (size_t)segs * T1 * XW;
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T1, 4)), dim3(256), 0, s,
+                               ws->redA.as<u32>(), T0, 1u, T0 - 1, T1, segs * T1, A1, S1);
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * nP, 4)), dim3(256), 0, s,
+                               ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr);
+            stage_pts = (size_t)segs * (2 * T1 + nP);
+            if ((rc = stage_reserve(ws, stage_pts * XW * 4))) return rc;
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW * 4, hipMemcpyDeviceToHost, s));
+        }
+        MG_HIP(hipEventRecord(ws->done, s));
+        MG_HIP(hipGetLastError());
+        ws->plan = pl;
+        ws->T1 = T1;
+        ws->nP = nP;
+        ws->pending = 1;
+        return MG_OK;
+    }
+
+    static int stage_reserve(MsmWorkspace *ws, size_t bytes) {
+        if (ws->h_stage_cap >= bytes) return MG_OK;
+        if (ws->h_stage) hipHostFree(ws->h_stage);
+        ws->h_stage = nullptr;
+        ws->h_stage_cap = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes;
+        MG_HIP(hipHostMalloc(&ws->h_stage, cap, hipHostMallocDefault));
+        ws->h_stage_cap = cap;
+        return MG_OK;
+    }
+
+    // ---------------------------------------------------------------- finish (host fold)
+    int msm_finish(MsmWorkspace *ws, HostPoint *out) override {
+        if (!ws || !ws->pending) return MG_ERR_STATE;
+        MG_HIP(hipEventSynchronize(ws->done));
+        ws->pending = 0;
+        const MsmPlan &pl = ws->plan;
+        const u32 segs = (u32)pl.Wb, T1 = ws->T1, nP = ws->nP;
+        const u32 *st = (const u32 *)ws->h_stage;
+        HP total = HP::inf();
+        for (int w = (int)segs - 1; w >= 0; --w) {
+            HP win;
+            if (T1 == 0) {
+                win = HP::from_xyzz_words(st + (size_t)w * XW);
+            } else {
+                const u32 *A1 = st + ((size_t)w * T1) * XW;
+                const u32 *S1 = st + ((size_t)segs * T1 + (size_t)w * T1) * XW;
+                const u32 *P0 = st + ((size_t)segs * 2 * T1 + (size_t)w * nP) * XW;
+                // X = sum_{t>=1} t*A0[t] = sum_u ( S1[u] + 64*u*A1[u] )
+                HP sumS = HP::inf(), run = HP::inf(), uA = HP::inf();
+                for (int u = (int)T1 - 1; u >= 0; --u) {
+                    sumS = HP::add(sumS, HP::from_xyzz_words(S1 + (size_t)u * XW));
+                    if (u >= 1) {
+                        run = HP::add(run, HP::from_xyzz_words(A1 + (size_t)u * XW));
+                        uA = HP::add(uA, run); // sum_u u*A1[u]
+                    }
+                }
+                HP X = HP::add(sumS, HP::mul_pow2(uA, 6));
+                HP sumP = HP::inf();
+                for (u32 u = 0; u < nP; ++u) sumP = HP::add(sumP, HP::from_xyzz_words(P0 + (size_t)u * XW));
+                win = HP::add(sumP, HP::mul_pow2(X, 6));
+            }
+            if (w != (int)segs - 1) total = HP::mul_pow2(total, (unsigned)pl.c);
+            total = HP::add(total, win);
+        }
+        hp(out) = total;
+        return MG_OK;
+    }
+
+    // ---------------------------------------------------------------- fixed-base batch mul
+    int fixed_base_mul(const u32 *base_affine_host, const u32 *d_scalars, size_t n, u32 *d_out_affine,
+                       hipStream_t s) override {
+        u32 *d_base = nullptr, *tmp = nullptr;
+        MG_HIP(hipMalloc((void **)&d_base, AW * 4));
+        hipError_t e = hipMalloc((void **)&tmp, n * XW * 4);
+        if (e != hipSuccess) {
+            hipFree(d_base);
+            set_last_hip_error(e, "hipMalloc(fixed_base tmp)", __FILE__, __LINE__);
+            return MG_ERR_OOM;
+        }
+        hipMemcpyAsync(d_base, base_affine_host, AW * 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL((fixed_base_mul_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
+        constexpr int KB = 16;
+        hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, s, tmp, n,
+                           d_out_affine);
+        e = hipStreamSynchronize(s);
+        hipFree(d_base);
+        hipFree(tmp);
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "fixed_base_mul", __FILE__, __LINE__);
+            return MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+
+    int sum_affine(const u32 *d_pts, size_t n, HostPoint *out) override {
+        const u32 T = n < 4096 ? (u32)(n ? n : 1) : 4096;
+        u32 *tmp = nullptr;
+        MG_HIP(hipMalloc((void **)&tmp, (size_t)T * XW * 4));
+        hipLaunchKernelGGL((sum_affine_kernel<F>), dim3(cdiv(T, 256)), dim3(256), 0, 0, d_pts, n, T, tmp);
+        std::vector<u32> h((size_t)T * XW);
+        hipError_t e = hipMemcpy(h.data(), tmp, h.size() * 4, hipMemcpyDeviceToHost);
+        hipFree(tmp);
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "sum_affine", __FILE__, __LINE__);
+            return MG_ERR_HIP;
+        }
+        HP acc = HP::inf();
+        for (u32 t = 0; t < T; ++t) acc = HP::add(acc, HP::from_xyzz_words(h.data() + (size_t)t * XW));
+        hp(out) = acc;
+        return MG_OK;
+    }
+};
+
+} // namespace mg

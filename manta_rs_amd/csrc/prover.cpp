@@ -1,0 +1,339 @@
+// Groth16 prover on one MI355X: device-resident proving key + R1CS, witness map on the GPU,
+// five MSMs on five HIP streams, serial assembly on the host.
+//
+// Replaces ark-groth16 ^0.3.0 `create_proof` (prover.rs) + `R1CStoQAP::witness_map` (r1cs_to_qap.rs),
+// reached from manta-crypto/src/arkworks/groth16.rs:597; restated from SURVEY.md section 3.2 / App. B.1:
+//   h     = witness_map(z)
+//   h_acc = MSM(h_query, h)              l_acc = MSM(l_query, z[P..])
+//   g_a   = r*delta_g1 + a_query[0] + MSM(a_query[1..], z[1..]) + alpha_g1
+//   g1_b  = s*delta_g1 + b_g1_query[0] + MSM(b_g1_query[1..], z[1..]) + beta_g1      (only if r != 0)
+//   g2_b  = s*delta_g2 + b_g2_query[0] + MSM(b_g2_query[1..], z[1..]) + beta_g2
+//   g_c   = s*g_a + r*g1_b - (r s)*delta_g1 + l_acc + h_acc
+//   proof = (g_a, g2_b, g_c) as arkworks canonical compressed bytes.
+// An unsatisfied witness is not an error (ark-groth16 only debug_asserts it): a non-verifying proof
+// comes back, exactly like the reference in release builds.
+#include "prover.h"
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace mg {
+
+FrEngine *get_ntt_engine(int curve) {
+    static std::mutex mu;
+    static FrEngine *tab[2] = {nullptr, nullptr};
+    if (curve < 0 || curve > 1) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    if (!tab[curve]) tab[curve] = curve == 0 ? make_fr_engine_bn254() : make_fr_engine_bls381();
+    return tab[curve];
+}
+
+namespace {
+
+struct ProveWs { // per-call device scratch for the witness map
+    DevBuf z, a, b, c;
+    hipStream_t stream = nullptr;
+    hipEvent_t z_ready = nullptr, h_ready = nullptr;
+    ~ProveWs() {
+        z.release();
+        a.release();
+        b.release();
+        c.release();
+        if (z_ready) hipEventDestroy(z_ready);
+        if (h_ready) hipEventDestroy(h_ready);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+class ProverImpl : public Prover {
+  public:
+    int curve_ = 0;
+    FrEngine *fr_ = nullptr;
+    GroupEngine *g1_ = nullptr, *g2_ = nullptr;
+    u64 V_ = 0, P_ = 0, h_len_ = 0, m_ = 0;
+    unsigned log_d_ = 0;
+    bool have_r1cs_ = false;
+    BaseSet *a_bs_ = nullptr, *b1_bs_ = nullptr, *b2_bs_ = nullptr, *h_bs_ = nullptr, *l_bs_ = nullptr;
+    HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
+    DevCsr A_, B_, C_;
+    std::mutex mu_;
+    std::vector<ProveWs *> ws_free_;
+
+    ~ProverImpl() override {
+        if (a_bs_) g1_->bases_destroy(a_bs_);
+        if (b1_bs_) g1_->bases_destroy(b1_bs_);
+        if (h_bs_) g1_->bases_destroy(h_bs_);
+        if (l_bs_) g1_->bases_destroy(l_bs_);
+        if (b2_bs_) g2_->bases_destroy(b2_bs_);
+        free_csr(A_);
+        free_csr(B_);
+        free_csr(C_);
+        for (ProveWs *w : ws_free_) delete w;
+    }
+    static void free_csr(DevCsr &M) {
+        if (M.row_ptr) hipFree(M.row_ptr);
+        if (M.col) hipFree(M.col);
+        if (M.val) hipFree(M.val);
+        M = DevCsr();
+    }
+    u64 domain_size() const override { return have_r1cs_ ? (u64)1 << log_d_ : 0; }
+
+    // window bits for precomputed tables, by MSM length (HBM is plentiful: trade table size for fewer
+    // buckets to fold and no doubling chain -- tuned on MI355X)
+    static int pre_c_for(u64 n) {
+        if (n <= (1u << 10)) return 7;
+        if (n <= (1u << 13)) return 9;
+        if (n <= (1u << 16)) return 11;
+        if (n <= (1u << 18)) return 13;
+        return 16;
+    }
+
+    int init(int curve, const mg_pk_view *pk) {
+        curve_ = curve;
+        fr_ = get_ntt_engine(curve);
+        g1_ = get_engine(curve, 1);
+        g2_ = get_engine(curve, 2);
+        if (!fr_ || !g1_ || !g2_) return MG_ERR_ARG;
+        V_ = pk->n_vars;
+        P_ = pk->n_inputs;
+        h_len_ = pk->h_len;
+        if (V_ < 2 || P_ < 1 || P_ >= V_ || h_len_ < 1) return MG_ERR_ARG;
+        if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2 || !pk->a_query ||
+            !pk->b_g1_query || !pk->b_g2_query || !pk->h_query || !pk->l_query)
+            return MG_ERR_ARG;
+        const size_t w1 = (size_t)g1_->affine_words(), w2 = (size_t)g2_->affine_words();
+        g1_->hp_from_affine(&alpha_g1_, (const u32 *)pk->alpha_g1);
+        g1_->hp_from_affine(&beta_g1_, (const u32 *)pk->beta_g1);
+        g1_->hp_from_affine(&delta_g1_, (const u32 *)pk->delta_g1);
+        g2_->hp_from_affine(&beta_g2_, (const u32 *)pk->beta_g2);
+        g2_->hp_from_affine(&delta_g2_, (const u32 *)pk->delta_g2);
+        g1_->hp_from_affine(&a0_, (const u32 *)pk->a_query);
+        g1_->hp_from_affine(&b1_0_, (const u32 *)pk->b_g1_query);
+        g2_->hp_from_affine(&b2_0_, (const u32 *)pk->b_g2_query);
+        int rc;
+        const int c_z = pre_c_for(V_ - 1);
+        if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, c_z, &a_bs_))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, c_z, &b1_bs_))) return rc;
+        if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, c_z, &b2_bs_))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, pre_c_for(V_ - P_), &l_bs_))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->h_query, h_len_, false, pre_c_for(h_len_), &h_bs_))) return rc;
+        return MG_OK;
+    }
+
+    static int upload_csr(const mg_csr *src, u64 m, u64 n_vars, DevCsr &dst) {
+        if (!src->row_ptr || (src->nnz && (!src->col || !src->val))) return MG_ERR_ARG;
+        if (src->row_ptr[m] != src->nnz) return MG_ERR_ARG;
+        for (u64 k = 0; k < src->nnz; ++k)
+            if (src->col[k] >= n_vars) return MG_ERR_ARG;
+        free_csr(dst);
+        dst.nnz = src->nnz;
+        MG_HIP(hipMalloc((void **)&dst.row_ptr, (m + 1) * 4));
+        MG_HIP(hipMalloc((void **)&dst.col, (src->nnz ? src->nnz : 1) * 4));
+        MG_HIP(hipMalloc((void **)&dst.val, (src->nnz ? src->nnz : 1) * 32));
+        MG_HIP(hipMemcpy(dst.row_ptr, src->row_ptr, (m + 1) * 4, hipMemcpyHostToDevice));
+        if (src->nnz) {
+            MG_HIP(hipMemcpy(dst.col, src->col, src->nnz * 4, hipMemcpyHostToDevice));
+            MG_HIP(hipMemcpy(dst.val, src->val, src->nnz * 32, hipMemcpyHostToDevice));
+        }
+        return MG_OK;
+    }
+
+    int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) override {
+        std::lock_guard<std::mutex> g(mu_);
+        if (m == 0 || m + P_ > ((u64)1 << 32)) return MG_ERR_ARG;
+        unsigned lg = 0;
+        while (((u64)1 << lg) < m + P_) ++lg; // GeneralEvaluationDomain::new(m + P) -> next power of two
+        if ((int)lg > fr_->two_adicity()) return MG_ERR_DOMAIN;
+        int rc;
+        if ((rc = upload_csr(a, m, V_, A_)) || (rc = upload_csr(b, m, V_, B_)) || (rc = upload_csr(c, m, V_, C_)))
+            return rc;
+        m_ = m;
+        log_d_ = lg;
+        have_r1cs_ = true;
+        return MG_OK;
+    }
+
+    ProveWs *ws_acquire() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (!ws_free_.empty()) {
+                ProveWs *w = ws_free_.back();
+                ws_free_.pop_back();
+                return w;
+            }
+        }
+        ProveWs *w = new ProveWs();
+        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess) {
+            delete w;
+            return nullptr;
+        }
+        return w;
+    }
+    void ws_release(ProveWs *w) {
+        std::lock_guard<std::mutex> g(mu_);
+        ws_free_.push_back(w);
+    }
+
+    // enqueue H2D(z) + witness map on w->stream; h ends up in w->a
+    int launch_witness_map(ProveWs *w, const uint64_t *z) {
+        const size_t D = (size_t)1 << log_d_;
+        int rc;
+        if ((rc = w->z.reserve(V_ * 32)) || (rc = w->a.reserve(D * 32)) || (rc = w->b.reserve(D * 32)) ||
+            (rc = w->c.reserve(D * 32)))
+            return rc;
+        hipStream_t s = w->stream;
+        MG_HIP(hipMemcpyAsync(w->z.p, z, V_ * 32, hipMemcpyHostToDevice, s));
+        MG_HIP(hipEventRecord(w->z_ready, s));
+        MG_HIP(hipMemsetAsync(w->a.p, 0, D * 32, s));
+        MG_HIP(hipMemsetAsync(w->b.p, 0, D * 32, s));
+        MG_HIP(hipMemsetAsync(w->c.p, 0, D * 32, s));
+        u32 *a = w->a.as<u32>(), *b = w->b.as<u32>(), *c = w->c.as<u32>(), *zz = w->z.as<u32>();
+        if ((rc = fr_->spmv(A_, zz, a, m_, s)) || (rc = fr_->spmv(B_, zz, b, m_, s)) ||
+            (rc = fr_->spmv(C_, zz, c, m_, s)))
+            return rc;
+        // input-consistency rows: a[m + j] = z_j for j < P (mpc.rs:299-312)
+        MG_HIP(hipMemcpyAsync(a + (size_t)m_ * 8, zz, P_ * 32, hipMemcpyDeviceToDevice, s));
+        if ((rc = fr_->transform(a, log_d_, true, false, s)) || (rc = fr_->transform(b, log_d_, true, false, s)) ||
+            (rc = fr_->transform(a, log_d_, false, true, s)) || (rc = fr_->transform(b, log_d_, false, true, s)) ||
+            (rc = fr_->transform(c, log_d_, true, false, s)) || (rc = fr_->transform(c, log_d_, false, true, s)) ||
+            (rc = fr_->qap_pointwise(a, b, c, log_d_, s)) || (rc = fr_->transform(a, log_d_, true, true, s)))
+            return rc;
+        MG_HIP(hipEventRecord(w->h_ready, s));
+        return MG_OK;
+    }
+
+    int witness_map_host(const uint64_t *z, uint64_t *h_out) override {
+        if (!have_r1cs_) return MG_ERR_STATE;
+        ProveWs *w = ws_acquire();
+        if (!w) return MG_ERR_HIP;
+        int rc = launch_witness_map(w, z);
+        if (!rc) {
+            hipError_t e = hipMemcpyAsync(h_out, w->a.p, ((size_t)1 << log_d_) * 32, hipMemcpyDeviceToHost, w->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+            if (e != hipSuccess) {
+                set_last_hip_error(e, "witness_map_host", __FILE__, __LINE__);
+                rc = MG_ERR_HIP;
+            }
+        } else {
+            hipStreamSynchronize(w->stream);
+        }
+        ws_release(w);
+        return rc;
+    }
+
+    int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
+        if (!have_r1cs_) return MG_ERR_STATE;
+        ProveWs *w = ws_acquire();
+        if (!w) return MG_ERR_HIP;
+        MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        GroupEngine *me[5] = {g1_, g1_, g2_, g1_, g1_}; // a, b_g1, b_g2, l, h
+        int rc = launch_witness_map(w, z);
+        bool r_zero = (r[0] | r[1] | r[2] | r[3]) == 0;
+        const size_t D = (size_t)1 << log_d_;
+        const u32 *dz = w->z.as<u32>();
+        if (!rc) {
+            for (int i = 0; i < 5 && !rc; ++i) {
+                if (i == 1 && r_zero) continue; // g1_b skipped iff r == 0 (App. B.1)
+                mw[i] = me[i]->ws_acquire();
+                if (!mw[i]) rc = MG_ERR_HIP;
+            }
+        }
+        if (!rc) {
+            hipStreamWaitEvent(mw[0]->stream, w->z_ready, 0);
+            rc = g1_->msm_launch(a_bs_, dz + 8, V_ - 1, true, 0, mw[0]);
+        }
+        if (!rc && mw[1]) {
+            hipStreamWaitEvent(mw[1]->stream, w->z_ready, 0);
+            rc = g1_->msm_launch(b1_bs_, dz + 8, V_ - 1, true, 0, mw[1]);
+        }
+        if (!rc) {
+            hipStreamWaitEvent(mw[2]->stream, w->z_ready, 0);
+            rc = g2_->msm_launch(b2_bs_, dz + 8, V_ - 1, true, 0, mw[2]);
+        }
+        if (!rc) {
+            hipStreamWaitEvent(mw[3]->stream, w->z_ready, 0);
+            rc = g1_->msm_launch(l_bs_, dz + (size_t)P_ * 8, V_ - P_, true, 0, mw[3]);
+        }
+        if (!rc) {
+            hipStreamWaitEvent(mw[4]->stream, w->h_ready, 0);
+            const size_t hl = h_len_ < D ? h_len_ : D; // multi_scalar_mul zips to the shorter
+            rc = g1_->msm_launch(h_bs_, w->a.as<u32>(), hl, true, 0, mw[4]);
+        }
+        HostPoint res[5];
+        for (int i = 0; i < 5; ++i) {
+            if (!mw[i]) continue;
+            if (mw[i]->pending) {
+                int rc2 = me[i]->msm_finish(mw[i], &res[i]);
+                if (!rc) rc = rc2;
+            } else {
+                hipStreamSynchronize(mw[i]->stream);
+            }
+            me[i]->ws_release(mw[i]);
+        }
+        hipStreamSynchronize(w->stream);
+        ws_release(w);
+        if (rc) return rc;
+
+        // ---- serial assembly on the host
+        u64 rc4[4], sc4[4], rs_m[4], rs4[4];
+        fr_->fr_to_canonical(r, rc4);
+        fr_->fr_to_canonical(s, sc4);
+        fr_->fr_mul(r, s, rs_m);
+        fr_->fr_to_canonical(rs_m, rs4);
+        HostPoint g_a = res[0], t;
+        g1_->hp_add(&g_a, &a0_);
+        t = delta_g1_;
+        g1_->hp_mul(&t, rc4);
+        g1_->hp_add(&g_a, &t);
+        g1_->hp_add(&g_a, &alpha_g1_);
+        HostPoint g1_b;
+        g1_->hp_set_inf(&g1_b);
+        if (!r_zero) {
+            g1_b = res[1];
+            g1_->hp_add(&g1_b, &b1_0_);
+            t = delta_g1_;
+            g1_->hp_mul(&t, sc4);
+            g1_->hp_add(&g1_b, &t);
+            g1_->hp_add(&g1_b, &beta_g1_);
+        }
+        HostPoint g2_b = res[2];
+        g2_->hp_add(&g2_b, &b2_0_);
+        t = delta_g2_;
+        g2_->hp_mul(&t, sc4);
+        g2_->hp_add(&g2_b, &t);
+        g2_->hp_add(&g2_b, &beta_g2_);
+        HostPoint g_c = g_a;
+        g1_->hp_mul(&g_c, sc4);
+        t = g1_b;
+        g1_->hp_mul(&t, rc4);
+        g1_->hp_add(&g_c, &t);
+        t = delta_g1_;
+        g1_->hp_mul(&t, rs4);
+        g1_->hp_neg(&t);
+        g1_->hp_add(&g_c, &t);
+        g1_->hp_add(&g_c, &res[3]);
+        g1_->hp_add(&g_c, &res[4]);
+        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
+        g1_->hp_serialize(&g_a, proof_out, true);
+        g2_->hp_serialize(&g2_b, proof_out + b1, true);
+        g1_->hp_serialize(&g_c, proof_out + b1 + b2, true);
+        return MG_OK;
+    }
+};
+
+} // namespace
+
+int prover_create(int curve, const mg_pk_view *pk, Prover **out) {
+    ProverImpl *p = new ProverImpl();
+    int rc = p->init(curve, pk);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return MG_OK;
+}
+
+} // namespace mg

@@ -1,0 +1,44 @@
+// Scalar-field (Fr) device engine -- NTT, sparse matrix-vector product, QAP pointwise kernel -- and the
+// Groth16 prover that strings them together with the MSM engines.
+#pragma once
+#include "../../include/mantagpu.h"
+#include "engine.h"
+
+namespace mg {
+
+struct DevCsr {
+    u32 *row_ptr = nullptr, *col = nullptr, *val = nullptr;
+    u64 nnz = 0;
+};
+
+class FrEngine {
+  public:
+    virtual ~FrEngine() {}
+    virtual int two_adicity() const = 0;
+    // In-place radix-2 NTT of 2^log_n Montgomery elements in HBM, natural order in/out
+    // (ark-poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place semantics).
+    virtual int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) = 0;
+    // out[i] = sum_k val[k] * z[col[k]] over row i, i < m
+    virtual int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s) = 0;
+    // a[i] = (a[i]*b[i] - c[i]) * (g^D - 1)^-1
+    virtual int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) = 0;
+    // host-side Fr helpers (Montgomery in/out unless noted)
+    virtual void fr_mul(const u64 a[4], const u64 b[4], u64 out[4]) const = 0;
+    virtual void fr_to_canonical(const u64 a[4], u64 out[4]) const = 0;
+};
+typedef FrEngine NttEngine;
+FrEngine *make_fr_engine_bn254();
+FrEngine *make_fr_engine_bls381();
+FrEngine *get_ntt_engine(int curve);
+
+class Prover {
+  public:
+    virtual ~Prover() {}
+    virtual int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) = 0;
+    virtual int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) = 0;
+    virtual int witness_map_host(const uint64_t *z, uint64_t *h_out) = 0;
+    virtual u64 domain_size() const = 0;
+};
+int prover_create(int curve, const mg_pk_view *pk, Prover **out);
+
+} // namespace mg

@@ -1,0 +1,89 @@
+// Common host runtime of the MI355X Groth16 hot path: error reporting, grow-only device buffers,
+// the per-engine MSM workspace pool and the (curve, group) engine registry.
+#include "engine.h"
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace mg {
+
+static thread_local std::string g_last_error;
+
+void set_last_hip_error(hipError_t e, const char *expr, const char *file, int line) {
+    char buf[512];
+    std::snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, expr);
+    g_last_error = buf;
+}
+const char *last_error_string() { return g_last_error.c_str(); }
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return MG_OK;
+    if (p) {
+        hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256; // slack so that near-equal sizes do not thrash
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_last_hip_error(e, "hipMalloc(DevBuf)", __FILE__, __LINE__);
+        return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
+    }
+    cap = want;
+    return MG_OK;
+}
+void DevBuf::release() {
+    if (p) hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+MsmWorkspace::~MsmWorkspace() {
+    DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
+                     &ppts[0], &ppts[1], &redA,     &redS,    &redP,     &misc};
+    for (DevBuf *b : all) b->release();
+    if (h_stage) hipHostFree(h_stage);
+    if (done) hipEventDestroy(done);
+    if (stream) hipStreamDestroy(stream);
+}
+
+MsmWorkspace *GroupEngine::ws_acquire() {
+    {
+        std::lock_guard<std::mutex> g(ws_mu_);
+        if (!ws_free_.empty()) {
+            MsmWorkspace *w = ws_free_.back();
+            ws_free_.pop_back();
+            return w;
+        }
+    }
+    MsmWorkspace *w = new MsmWorkspace();
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+void GroupEngine::ws_release(MsmWorkspace *w) {
+    if (!w) return;
+    std::lock_guard<std::mutex> g(ws_mu_);
+    ws_free_.push_back(w);
+}
+
+GroupEngine *get_engine(int curve, int group) {
+    static std::mutex mu;
+    static GroupEngine *tab[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    if (curve < 0 || curve > 1 || group < 1 || group > 2) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    GroupEngine *&e = tab[curve][group - 1];
+    if (!e) {
+        if (curve == 0)
+            e = group == 1 ? make_engine_bn254_g1() : make_engine_bn254_g2();
+        else
+            e = group == 1 ? make_engine_bls381_g1() : make_engine_bls381_g2();
+    }
+    return e;
+}
+
+} // namespace mg

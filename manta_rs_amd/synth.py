@@ -1,0 +1,264 @@
+"""Synthetic, shape-exact R1CS circuits and witnesses for the Groth16 hot path.
+
+The reference builds its circuits with `Transfer::known_constraints`
+(manta-accounting/src/transfer/mod.rs:667-673) and hands the prover an `R1CS<F>` carrying the
+sparse matrices A, B, C plus the full assignment z = instance || witness
+(manta-crypto/src/arkworks/constraint/mod.rs:94-135,199-217). No witness can be captured offline
+(no Rust toolchain), so benches and tests use deterministic synthetic circuits with
+the exact (D, V, P) of the real manta-pay shapes:
+
+    ToPrivate        D = 2^14, V =  8 253, P = 13
+    ToPublic         D = 2^15, V = 27 945, P = 19
+    PrivateTransfer  D = 2^16, V = 35 175, P = 27
+
+Rows are a satisfiable mix of multiplication gates, boolean gates (b*(1-b)=0, giving the 0/1-heavy
+witness real circuits have) and linear gates. Pure Python big-int arithmetic + numpy packing; no
+dependency on the oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+import numpy as np
+
+BN254 = 0
+BLS12_381 = 1
+
+FR_MODULUS = {
+    BN254: 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001,
+    BLS12_381: 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+}
+FQ_MODULUS = {
+    BN254: 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47,
+    BLS12_381: 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab,
+}
+FR_BITS = {BN254: 254, BLS12_381: 255}
+FQ_LIMBS = {BN254: 4, BLS12_381: 6}
+
+SHAPES = {
+    "to_private": (1 << 14, 8253, 13),
+    "to_public": (1 << 15, 27945, 19),
+    "private_transfer": (1 << 16, 35175, 27),
+}
+
+
+class XorShift:
+    """xoshiro256** -- the deterministic generator SURVEY.md section 8(d) names for synthetic inputs."""
+
+    def __init__(self, seed: int):
+        # splitmix64 seeding
+        s = []
+        x = seed & 0xFFFFFFFFFFFFFFFF
+        for _ in range(4):
+            x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            z = x
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+            s.append(z ^ (z >> 31))
+        self.s = s
+
+    def next(self) -> int:
+        s = self.s
+        M = 0xFFFFFFFFFFFFFFFF
+        r = (s[1] * 5) & M
+        r = (((r << 7) | (r >> 57)) & M) * 9 & M
+        t = (s[1] << 17) & M
+        s[2] ^= s[0]
+        s[3] ^= s[1]
+        s[1] ^= s[2]
+        s[0] ^= s[3]
+        s[2] ^= t
+        s[3] = ((s[3] << 45) | (s[3] >> 19)) & M
+        return r
+
+    def below(self, n: int) -> int:
+        return self.next() % n
+
+    def field(self, p: int) -> int:
+        v = 0
+        for _ in range((p.bit_length() + 63) // 64 + 1):
+            v = (v << 64) | self.next()
+        return v % p
+
+
+# ------------------------------------------------------------------ int <-> limb packing
+def ints_to_limbs(vals, nlimbs: int) -> np.ndarray:
+    """list of python ints -> (len, nlimbs) uint64 little-endian limbs."""
+    nb = 8 * nlimbs
+    buf = b"".join(int(v).to_bytes(nb, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(len(vals), nlimbs).copy()
+
+
+def limbs_to_ints(arr: np.ndarray):
+    arr = np.ascontiguousarray(arr, dtype=np.uint64)
+    n = arr.shape[-1]
+    flat = arr.reshape(-1, n)
+    raw = flat.tobytes()
+    nb = 8 * n
+    return [int.from_bytes(raw[i * nb:(i + 1) * nb], "little") for i in range(flat.shape[0])]
+
+
+def to_mont(vals, p: int, nlimbs: int) -> np.ndarray:
+    R = (1 << (64 * nlimbs)) % p
+    return ints_to_limbs([(v * R) % p for v in vals], nlimbs)
+
+
+def from_mont(arr: np.ndarray, p: int):
+    n = arr.shape[-1]
+    Rinv = pow(1 << (64 * n), -1, p)
+    return [(v * Rinv) % p for v in limbs_to_ints(arr)]
+
+
+@dataclasses.dataclass
+class CSR:
+    row_ptr: np.ndarray  # uint32 [m+1]
+    col: np.ndarray      # uint32 [nnz]
+    val: np.ndarray      # uint64 [nnz, 4] Montgomery Fr
+
+
+@dataclasses.dataclass
+class Circuit:
+    curve: int
+    m: int          # constraints
+    P: int          # instance variables incl. the constant 1
+    V: int          # all variables
+    D: int          # FFT domain = next_pow2(m + P)
+    A: CSR
+    B: CSR
+    C: CSR
+    z_int: list     # full assignment as python ints (canonical)
+    z: np.ndarray   # uint64 [V, 4] Montgomery
+
+
+def _pack_csr(rows, p, coeff_cache):
+    row_ptr = np.zeros(len(rows) + 1, dtype=np.uint32)
+    cols = []
+    vals = []
+    k = 0
+    for i, r in enumerate(rows):
+        for (c, v) in r:
+            cols.append(c)
+            vals.append(v % p)
+            k += 1
+        row_ptr[i + 1] = k
+    # montgomery-pack distinct coefficients once
+    R = (1 << 256) % p
+    uniq = {}
+    idx = np.empty(len(vals), dtype=np.int64)
+    for j, v in enumerate(vals):
+        if v not in uniq:
+            uniq[v] = len(uniq)
+        idx[j] = uniq[v]
+    table = ints_to_limbs([(v * R) % p for v in uniq.keys()], 4) if uniq else np.zeros((0, 4), dtype=np.uint64)
+    val = table[idx] if len(vals) else np.zeros((0, 4), dtype=np.uint64)
+    return CSR(row_ptr, np.asarray(cols, dtype=np.uint32), np.ascontiguousarray(val))
+
+
+def make_circuit(curve: int, m: int, V: int, P: int, seed: int = 0x4D414E5441_0001) -> Circuit:
+    """Satisfiable synthetic R1CS with m rows, V variables, P instance variables (z_0 = 1)."""
+    assert V > P >= 1 and m >= 1
+    p = FR_MODULUS[curve]
+    rng = XorShift(seed)
+    z = [0] * V
+    z[0] = 1
+    for j in range(1, P):
+        z[j] = rng.field(p)
+    A, B, C = [], [], []
+    nw = V - P
+    coeffs = [rng.field(p) for _ in range(8)]
+
+    def coef():
+        return 1 if rng.below(4) else coeffs[rng.below(8)]
+
+    bools = []
+    for k in range(min(nw, m)):
+        v = P + k
+        kind = rng.below(100)
+        if v <= 1 or kind < 45:  # boolean witness
+            z[v] = rng.below(2) if rng.below(5) else 0
+            A.append([(v, 1)])
+            B.append([(0, 1), (v, p - 1)])
+            C.append([])
+            bools.append(v)
+        elif kind < 85:  # multiplication gate
+            l, r = rng.below(v), rng.below(v)
+            ca, cb = coef(), coef()
+            z[v] = (ca * z[l] % p) * (cb * z[r] % p) % p
+            A.append([(l, ca)])
+            B.append([(r, cb)])
+            C.append([(v, 1)])
+        else:  # linear gate
+            l, r = rng.below(v), rng.below(v)
+            c = coef()
+            z[v] = (z[l] + c * z[r]) % p
+            A.append([(l, 1), (r, c)] if l != r else [(l, (1 + c) % p)])
+            B.append([(0, 1)])
+            C.append([(v, 1)])
+    for k in range(nw, m):  # extra rows over existing variables
+        if bools and rng.below(2):
+            b = bools[rng.below(len(bools))]
+            A.append([(b, 1)])
+            B.append([(b, 1)])
+            C.append([(b, 1)])
+        else:
+            l, r = rng.below(V), rng.below(V)
+            c = coef()
+            row = [(l, 1), (r, c)] if l != r else [(l, (1 + c) % p)]
+            A.append(row)
+            B.append([(0, 1)])
+            C.append(list(row))
+    # variables without a defining row (nw > m): free random values
+    for k in range(m, nw):
+        z[P + k] = rng.field(p)
+    D = 1
+    while D < m + P:
+        D <<= 1
+    cache = {}
+    return Circuit(curve, m, P, V, D, _pack_csr(A, p, cache), _pack_csr(B, p, cache), _pack_csr(C, p, cache), z,
+                   to_mont(z, p, 4))
+
+
+def make_shape(curve: int, name: str, seed: int = 0x4D414E5441_0001) -> Circuit:
+    D, V, P = SHAPES[name]
+    return make_circuit(curve, D - P, V, P, seed)
+
+
+def check_satisfied(c: Circuit) -> bool:
+    p = FR_MODULUS[c.curve]
+    Rinv = pow(1 << 256, -1, p)
+
+    def rows(M):
+        vals = [v * Rinv % p for v in limbs_to_ints(M.val)] if len(M.col) else []
+        out = []
+        for i in range(c.m):
+            s = 0
+            for k in range(M.row_ptr[i], M.row_ptr[i + 1]):
+                s += vals[k] * c.z_int[M.col[k]]
+            out.append(s % p)
+        return out
+
+    a, b, cc = rows(c.A), rows(c.B), rows(c.C)
+    return all((x * y - w) % p == 0 for x, y, w in zip(a, b, cc))
+
+
+def msm_scalars(curve: int, n: int, dist: str, seed: int = 0x4D414E5441_0003) -> np.ndarray:
+    """Canonical (non-Montgomery) scalars, uint64 [n,4]. dist: 'U' uniform, 'W' witness-like
+    (40% 0, 25% 1, 10% < 2^64, 25% uniform) -- SURVEY.md section 8(d) config 2."""
+    p = FR_MODULUS[curve]
+    rs = np.random.RandomState(seed & 0x7FFFFFFF)
+    raw = rs.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64)
+    raw ^= rs.randint(0, 1 << 63, size=(n, 4), dtype=np.int64).astype(np.uint64) << np.uint64(1)
+    # clear top bits so that every value < 2^(bits-1) < p  (uniform enough for a throughput test;
+    # exact values are irrelevant, parity is checked on whatever was generated)
+    raw[:, 3] &= np.uint64((1 << (FR_BITS[curve] - 1 - 192)) - 1)
+    if dist == "U":
+        return raw
+    assert dist == "W"
+    sel = rs.randint(0, 100, size=n)
+    out = raw.copy()
+    out[sel < 40] = 0
+    one = (sel >= 40) & (sel < 65)
+    out[one] = 0
+    out[one, 0] = 1
+    small = (sel >= 65) & (sel < 75)
+    out[small, 1:] = 0
+    return out

@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """The HIP product library, initialised on device 0. Fails loudly (no CPU fallback)."""
+    from manta_rs_amd import api
+    assert api.device_count() >= 1, "no ROCm device visible"
+    api.init(0)
+    return api
