@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X Groth16 hot path.
+
+Metric (BASELINE.json): "G1 MSM Mscalar/s at 2^20" on configs[1] = "2^20 BLS12-381 G1 variable-base
+MSM, synthetic scalars/bases, 1 MI355X". A step = one full MSM (digits -> sort -> bucket accumulate ->
+merge -> bucket reduce -> host fold to one affine point) over n = 2^20 scalars that are already
+resident in HBM, against bases registered (resident, with their 2^(c w) multiples) before timing.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+N > 1 (weak scaling): the global MSM has N * 2^20 terms, sharded by contiguous base/scalar range, one
+process per GPU; every step ends with an RCCL all_gather of the N partial points (96 B each, xGMI) and
+the local N-term sum -- SURVEY.md section 8(e). value = N * 2^20 * K / t with t the max over ranks.
+
+One JSON line on rank 0. `roofline` is for the dominant kernel (bucket accumulate), timed live with HIP
+events on its own stream; `cpu_baseline` is the arkworks-algorithm CPU restatement (oracle/, 1 thread
+like the reference) on a bounded prefix of the same inputs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+LOG_N = 20
+CURVE = 1  # BLS12-381
+WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
+ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+
+BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+          0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    import torch
+    import torch.distributed as dist
+    from manta_rs_amd import api, synth
+
+    torch.cuda.set_device(local_rank)
+    api.init(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = 1 << LOG_N
+    p = synth.FR_MODULUS[CURVE]
+    q = synth.FQ_MODULUS[CURVE]
+    G = synth.to_mont(list(BLS_G1), q, 6).reshape(-1)
+
+    # ---- synthetic inputs (untimed). Bases: arithmetic progression P_i = [s0 + i*s1]G over the GLOBAL
+    # index range, built on the GPU by the library's fixed-base batch multiply; rank r owns [r*n, (r+1)*n).
+    s0, s1 = 0x243F6A8885A308D313198A2E03707344, 0x9E3779B97F4A7C15F39CC0605CEDC835
+    base_idx = np.arange(rank * n, (rank + 1) * n, dtype=object)
+    ks = [(s0 + int(i) * s1) % p for i in base_idx]
+    d_ks = api.DeviceBuffer.from_numpy(synth.ints_to_limbs(ks, 4))
+    d_pts = api.fixed_base_mul(CURVE, 1, G, d_ks, n)
+    bases = api.Bases(CURVE, 1, (d_pts.ptr, n), precompute_window_bits=WINDOW_BITS, on_device=True)
+    scalars = synth.msm_scalars(CURVE, n, "U", seed=0x4D414E54 + rank)  # uniform: the h-query MSM's case
+    d_sc = api.DeviceBuffer.from_numpy(scalars)
+    api.synchronize()
+
+    def gather_sum(local_pt):
+        if world == 1:
+            return local_pt
+        t = torch.from_numpy(local_pt.view(np.int64)).cuda()
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)  # RCCL over xGMI: 96 B per rank
+        pts = torch.stack(outs).cpu().numpy().view(np.uint64)
+        return api.points_sum(CURVE, 1, pts)
+
+    def barrier():
+        api.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def run(steps):
+        """two MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i
+        (bucket reduce, host fold, partial-point exchange) overlaps the accumulate kernel of step i+1."""
+        res = None
+        pending = []
+        for _ in range(steps):
+            pending.append(api.VariableBaseMSM.launch(bases, d_sc, n))
+            if len(pending) == 2:
+                res = gather_sum(pending.pop(0).finish())
+        while pending:
+            res = gather_sum(pending.pop(0).finish())
+        return res
+
+    # ---- correctness gate before any timing counts: closed form sum_i k_i (s0 + i s1) mod r, one scalar mult
+    result = run(1)
+    sc_int = synth.limbs_to_ints(scalars)
+    part = sum(k * b for k, b in zip(sc_int, ks)) % p
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+        part = sum(parts) % p
+    d_one = api.DeviceBuffer.from_numpy(synth.ints_to_limbs([part], 4))
+    expect = api.fixed_base_mul(CURVE, 1, G, d_one, 1).to_numpy()
+    assert (result == expect).all(), "MSM result does not match the closed-form expectation"
+
+    run(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- roofline leg (rank 0, outside the timed region): dominant kernel timed with HIP events on its stream
+    roofline = cpu = None
+    if rank == 0:
+        api.set_kernel_timing(True)
+        acc_ms = []
+        for _ in range(5):
+            api.VariableBaseMSM.launch(bases, d_sc, n).finish()
+            acc_ms.append(api.last_accumulate_ms())
+        api.set_kernel_timing(False)
+        k_ms = float(np.mean(acc_ms))
+        achieved = n * ALGO_BYTES_PER_SCALAR / (k_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "accumulate_chunks<Fp<Bls381Fq>>", "achieved": round(achieved, 2),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                    "traffic": traffic, "kernel_ms": round(k_ms, 4),
+                    "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SCALAR,
+                    "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); see DESIGN.md for the int-MAD bound"}
+        if not args.no_cpu_baseline and world == 1:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O  # the checker, here only as the timed CPU baseline
+            ns = 1 << 17
+            host_pts = d_pts.to_numpy(shape=(n, 12))[:ns].copy()
+            tcpu, out = O.time_msm(CURVE, 1, host_pts, scalars[:ns])
+            cpu = {"value": round(ns / tcpu / 1e6, 5), "unit": "Mscalar/s", "cores": 1, "kind": "port",
+                   "sample": f"first 2^17 bases/scalars of the same workload, arkworks-0.3 Pippenger restatement, "
+                             f"{tcpu:.1f} s on 1 thread (the reference ships arkworks without `parallel`)"}
+
+    if rank == 0:
+        total = world * n * args.steps
+        line = {
+            "metric": "G1 MSM Mscalar/s at 2^20", "value": round(total / dt / 1e6, 3), "unit": "Mscalar/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)", "data": "synthetic",
+            "config": {"workload": "2^20 BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM",
+                       "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS,
+                       "precomputed_base_multiples": True, "bases_hbm_bytes": bases.device_bytes(),
+                       "sharding": "contiguous base/scalar ranges, all_gather of partial points" if world > 1 else "none"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -57,6 +57,11 @@ int mg_free(void *dptr);
 int mg_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
 int mg_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
 int mg_device_synchronize(void);
+/* Measurement hook (bench.py roofline leg): when on, each MSM brackets its dominant kernel (bucket
+ * accumulate) with HIP events on the stream it is launched on; mg_last_accumulate_ms() returns the
+ * duration of the calling thread's most recently finished MSM. Off by default. */
+int mg_set_kernel_timing(int on);
+float mg_last_accumulate_ms(void);
 
 /* ---- variable-base MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars)
  *      (ark-ec 0.3.0 msm/variable_base.rs; called 5x per proof from ark-groth16 create_proof, reached

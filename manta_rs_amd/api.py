@@ -42,6 +42,7 @@ def _load():
     lib.mg_last_error.restype = ctypes.c_char_p
     lib.mg_bases_device_bytes.restype = ctypes.c_size_t
     lib.mg_ctx_domain_size.restype = ctypes.c_uint64
+    lib.mg_last_accumulate_ms.restype = ctypes.c_float
     return lib
 
 
@@ -51,7 +52,7 @@ _sz = ctypes.c_size_t
 
 EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
-    "mg_memcpy_d2h", "mg_device_synchronize", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
+    "mg_memcpy_d2h", "mg_device_synchronize", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_point_serialize", "mg_ntt",
     "mg_ntt_device", "mg_ctx_create", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
@@ -79,6 +80,14 @@ def device_count():
     c = ctypes.c_int(0)
     _chk(LIB.mg_device_count(ctypes.byref(c)), "mg_device_count")
     return c.value
+
+
+def set_kernel_timing(on):
+    _chk(LIB.mg_set_kernel_timing(int(bool(on))), "mg_set_kernel_timing")
+
+
+def last_accumulate_ms():
+    return float(LIB.mg_last_accumulate_ms())
 
 
 def synchronize():

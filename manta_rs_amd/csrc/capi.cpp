@@ -70,6 +70,12 @@ MG_API int mg_device_synchronize(void) {
     return MG_SUCCESS;
 }
 
+MG_API int mg_set_kernel_timing(int on) {
+    set_kernel_timing(on != 0);
+    return MG_SUCCESS;
+}
+MG_API float mg_last_accumulate_ms(void) { return last_accumulate_ms(); }
+
 // ---------------------------------------------------------------------------------------------- MSM
 MG_API int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine, size_t n, int on_device,
                            int precompute_window_bits, mg_bases **out) {

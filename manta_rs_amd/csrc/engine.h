@@ -24,6 +24,12 @@ enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_HIP = 2, MG_ERR_OOM = 3, MG_ERR_DOMAIN 
         }                                                                                                         \
     } while (0)
 void set_last_hip_error(hipError_t e, const char *expr, const char *file, int line);
+// When on, every MSM brackets its accumulate kernel with HIP events on the launch stream (bench.py's
+// roofline leg); off by default.
+void set_kernel_timing(bool on);
+bool kernel_timing();
+void set_last_accumulate_ms(float ms);
+float last_accumulate_ms();
 const char *last_error_string();
 
 // grow-only device buffer
@@ -61,6 +67,9 @@ struct MsmWorkspace {
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
+    bool timed = false;
+    float accumulate_ms = 0.f;
     // host-side description of what was staged (filled by msm_launch, consumed by msm_finish)
     MsmPlan plan;
     u32 T1 = 0, nP = 0;

@@ -27,6 +27,9 @@ typedef uint64_t u64;
 #ifndef MG_MUL_ATTR
 #define MG_MUL_ATTR __device__ __noinline__
 #endif
+#ifndef MG_FP2_ATTR
+#define MG_FP2_ATTR __device__ __forceinline__
+#endif
 
 struct Acc96 {
     u64 lo;
@@ -54,6 +57,7 @@ MG_DEV void acc_shr32(Acc96 &c) {
 // C supplies: static constexpr int N; static constexpr u32 P[N], R[N] (one), R2[N], INV;
 template <class C> struct Fp {
     static constexpr int N = C::N;
+    static constexpr bool EXT = false;
     u32 v[N];
 
     static MG_DEV Fp zero() {
@@ -217,6 +221,7 @@ template <class C> struct Fp {
 template <class C> struct Fp2 {
     typedef Fp<C> B;
     static constexpr int N = 2 * C::N;
+    static constexpr bool EXT = true;
     B c0, c1;
     static MG_DEV Fp2 zero() { return Fp2{B::zero(), B::zero()}; }
     static MG_DEV Fp2 one() { return Fp2{B::one(), B::zero()}; }
@@ -226,12 +231,12 @@ template <class C> struct Fp2 {
     static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return Fp2{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
     static MG_DEV Fp2 neg(const Fp2 &a) { return Fp2{B::neg(a.c0), B::neg(a.c1)}; }
     static MG_DEV Fp2 dbl(const Fp2 &a) { return add(a, a); }
-    static MG_DEV Fp2 mul(const Fp2 &a, const Fp2 &b) { // Karatsuba, 3 base mults
+    static MG_FP2_ATTR Fp2 mul(const Fp2 &a, const Fp2 &b) { // Karatsuba, 3 base mults
         B v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
         B s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
         return Fp2{B::sub(v0, v1), B::sub(B::sub(s, v0), v1)};
     }
-    static MG_DEV Fp2 sqr(const Fp2 &a) { // (a0+a1)(a0-a1), 2 a0 a1
+    static MG_FP2_ATTR Fp2 sqr(const Fp2 &a) { // (a0+a1)(a0-a1), 2 a0 a1
         B t = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
         B u = B::mul(a.c0, a.c1);
         return Fp2{t, B::dbl(u)};

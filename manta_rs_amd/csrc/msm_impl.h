@@ -479,9 +479,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                              ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s)))
             return rc;
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
+        ws->timed = kernel_timing();
+        if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                            ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, ws->buckets.as<u32>(),
                            ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T);
+        if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * T;
         int src = 0;
         for (;;) {
@@ -548,6 +551,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (!ws || !ws->pending) return MG_ERR_STATE;
         MG_HIP(hipEventSynchronize(ws->done));
         ws->pending = 0;
+        if (ws->timed) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ws->t0, ws->t1) == hipSuccess) set_last_accumulate_ms(ms);
+        }
         const MsmPlan &pl = ws->plan;
         const u32 segs = (u32)pl.Wb, T1 = ws->T1, nP = ws->nP;
         const u32 *st = (const u32 *)ws->h_stage;

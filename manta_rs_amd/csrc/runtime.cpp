@@ -16,6 +16,13 @@ void set_last_hip_error(hipError_t e, const char *expr, const char *file, int li
 }
 const char *last_error_string() { return g_last_error.c_str(); }
 
+static bool g_kernel_timing = false;
+static thread_local float g_last_acc_ms = 0.f;
+void set_kernel_timing(bool on) { g_kernel_timing = on; }
+bool kernel_timing() { return g_kernel_timing; }
+void set_last_accumulate_ms(float ms) { g_last_acc_ms = ms; }
+float last_accumulate_ms() { return g_last_acc_ms; }
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return MG_OK;
     if (p) {
@@ -45,6 +52,8 @@ MsmWorkspace::~MsmWorkspace() {
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (done) hipEventDestroy(done);
+    if (t0) hipEventDestroy(t0);
+    if (t1) hipEventDestroy(t1);
     if (stream) hipStreamDestroy(stream);
 }
 
@@ -59,7 +68,8 @@ MsmWorkspace *GroupEngine::ws_acquire() {
     }
     MsmWorkspace *w = new MsmWorkspace();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&w->t0) != hipSuccess || hipEventCreate(&w->t1) != hipSuccess) {
         delete w;
         return nullptr;
     }

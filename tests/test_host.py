@@ -1,0 +1,106 @@
+"""CPU tests (no GPU) of the host side: the C-ABI library loads and exports every symbol the header
+declares, host-only entry points work, synthetic circuits have the real manta-pay shapes, and the
+multi-GPU partial-point reduction is exercised with world_size-2 gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from manta_rs_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from manta_rs_amd import api
+    hdr = open(os.path.join(ROOT, "include", "mantagpu.h")).read()
+    declared = set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(api.LIB, name), f"{name} declared in mantagpu.h but not exported"
+    assert declared == set(api.EXPORTS)
+
+
+def test_no_gpu_is_an_error_not_a_fallback():
+    from manta_rs_amd import api
+    try:
+        n = api.device_count()
+    except api.MantaGpuError:
+        n = 0
+    if n == 0:
+        with pytest.raises(api.MantaGpuError):
+            api.Bases(0, 1, np.ones((4, 8), dtype=np.uint64))
+        with pytest.raises(api.MantaGpuError):
+            api.Radix2EvaluationDomain(0, 8).fft(np.zeros((8, 4), dtype=np.uint64))
+
+
+def test_host_point_sum_and_serialize_match_oracle():
+    """mg_points_sum / mg_point_serialize are host-only code paths of the product (the multi-GPU partial
+    point reduction and the proof encoder)."""
+    from manta_rs_amd import api
+    import helpers as H
+    for curve, group in ((0, 1), (1, 1), (0, 2), (1, 2)):
+        pts = H.random_points(curve, group, 9, seed=curve * 10 + group)
+        pts[4] = 0
+        assert (api.points_sum(curve, group, pts) == O.g_sum(curve, group, pts)).all()
+        both = np.stack([pts[0], O.g_mul(curve, group, pts[0], synth.ints_to_limbs([synth.FR_MODULUS[curve] - 1], 4)[0])])
+        assert not api.points_sum(curve, group, both).any()  # P + (-P) = infinity
+        assert (api.points_sum(curve, group, np.stack([pts[1], pts[1]])) ==
+                O.g_mul(curve, group, pts[1], synth.ints_to_limbs([2], 4)[0])).all()
+        for p in (pts[0], pts[4]):
+            for comp in (True, False):
+                assert api.point_serialize(curve, group, p, comp) == O.serialize(curve, group, p, comp)
+
+
+@pytest.mark.parametrize("name", ["to_private", "to_public", "private_transfer"])
+def test_synthetic_shapes_match_manta_pay(name):
+    D, V, P = synth.SHAPES[name]
+    # shape arithmetic only: pk bytes = 624 + 320 V + 64 D for MPC keys
+    sizes = {"to_private": 3690160, "to_public": 11040176, "private_transfer": 15450928}
+    assert 624 + 320 * V + 64 * D == sizes[name]
+
+
+def test_small_synthetic_circuit_is_satisfied_and_deterministic():
+    a = synth.make_circuit(0, 500, 300, 13, seed=1)
+    b = synth.make_circuit(0, 500, 300, 13, seed=1)
+    assert synth.check_satisfied(a)
+    assert (a.z == b.z).all() and (a.A.val == b.A.val).all()
+    assert a.D == 1024
+    zeros_ones = sum(1 for v in a.z_int if v in (0, 1))
+    assert zeros_ones > 0.3 * a.V  # boolean-heavy like real witnesses
+
+
+def test_msm_range_sharding_with_gloo_world2(tmp_path):
+    """N > 1 path of bench.py on CPU: each rank owns a contiguous range, partial points are all_gathered
+    (gloo here, RCCL on the GPUs) and summed with the product's host reduction."""
+    script = tmp_path / "w.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_lib as O, helpers as H
+from manta_rs_amd import api, synth
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+n = 64
+pts = H.random_points(1, 1, n * world, seed=3)
+sc = synth.msm_scalars(1, n * world, "W", seed=4)
+part = O.msm(1, 1, pts[rank * n:(rank + 1) * n], sc[rank * n:(rank + 1) * n])   # stand-in for the GPU MSM
+t = torch.from_numpy(part.view(np.int64))
+outs = [torch.empty_like(t) for _ in range(world)]
+dist.all_gather(outs, t)
+total = api.points_sum(1, 1, torch.stack(outs).numpy().view(np.uint64))
+assert (total == O.msm(1, 1, pts, sc)).all()
+dist.barrier()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
