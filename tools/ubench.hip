@@ -48,7 +48,7 @@ int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     const double clk = p.clockRate * 1e3; // Hz
     printf("device %s CUs %d clock %.0f MHz\n", p.name, p.multiProcessorCount, clk / 1e6);
-    const int blocks = p.multiProcessorCount * 8, threads = 256;
+    int blocks = p.multiProcessorCount * 8; const int threads = 256;
     u32 *out; hipMalloc(&out, (size_t)blocks * threads * 12 * 4 * 2);
     u32 *in; hipMalloc(&in, 1024 * 12 * 4);
     std::vector<u32> h(1024 * 12); for (size_t i = 0; i < h.size(); ++i) h[i] = (u32)(i * 2654435761u) >> 3; hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
@@ -60,7 +60,7 @@ int main() {
         CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
         }
     };
-    for (int bpc = 8; bpc >= 1; bpc /= 2) { const int blocks = p.multiProcessorCount * bpc; printf("--- %d waves per SIMD\n", bpc); for (int mode = 0; mode < 15; ++mode) {
+    for (int bpc = 8; bpc >= 1; bpc /= 2) { blocks = p.multiProcessorCount * bpc; printf("--- %d waves per SIMD\n", bpc); for (int mode = 0; mode < 15; ++mode) {
         const int iters = 3000;
         run(mode, 2); hipDeviceSynchronize();
         hipEventRecord(e0); run(mode, iters); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -69,6 +69,7 @@ int main() {
         const double rate = winstr / (ms * 1e-3);
         printf("%-34s %8.3f ms  %8.2f G wave-instr/s  -> %.2f cycles/wave-instr/SIMD\n", names[mode], ms, rate / 1e9, (p.multiProcessorCount * 4.0 * clk) / rate);
     } }
+    blocks = p.multiProcessorCount * 8;
     auto fp = [&](const char *name, auto kern, int nlimbs, int iters) {
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, in, 2); hipDeviceSynchronize();
         hipEventRecord(e0); hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, out, in, iters); hipEventRecord(e1); hipEventSynchronize(e1);
