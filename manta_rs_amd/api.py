@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmantagpu.so")
+LIB_PATH = os.environ.get("MANTA_LIB") or os.path.join(_HERE, "lib", "libmantagpu.so")  # MANTA_LIB: A/B builds only
 
 BN254, BLS12_381 = 0, 1
 FQ_LIMBS = {BN254: 4, BLS12_381: 6}

@@ -196,10 +196,21 @@ def proof_bytes(curve):
     return 2 * point_bytes(curve, 1, True) + point_bytes(curve, 2, True)
 
 
+def _pk_struct(pk):
+    if hasattr(pk, "struct"):
+        return pk.struct()
+    keep = [np.ascontiguousarray(getattr(pk, f), dtype=np.uint64) for f in (
+        "alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1", "a_query", "b_g1_query",
+        "b_g2_query", "h_query", "l_query")]
+    st = PKStruct(pk.V, pk.P, pk.D, pk.h_len, *[_p(a) for a in keep])
+    st._keep = keep
+    return st
+
+
 def groth16_prove(c, pk, r_mont, s_mont, msm_algo=1, z=None):
     out = ctypes.create_string_buffer(proof_bytes(c.curve))
     A, B, C = csr_struct(c.A), csr_struct(c.B), csr_struct(c.C)
-    pks = pk.struct()
+    pks = _pk_struct(pk)
     zz = c.z if z is None else np.ascontiguousarray(z, dtype=np.uint64)
     rc = LIB.mo_groth16_prove(c.curve, ctypes.byref(pks), ctypes.byref(A), ctypes.byref(B), ctypes.byref(C),
                               ctypes.c_size_t(c.m), _p(zz), _p(np.ascontiguousarray(r_mont, dtype=np.uint64)),
@@ -209,7 +220,7 @@ def groth16_prove(c, pk, r_mont, s_mont, msm_algo=1, z=None):
 
 
 def groth16_verify(curve, pk, inputs_mont, proof):
-    pks = pk.struct()
+    pks = _pk_struct(pk)
     inputs = np.ascontiguousarray(inputs_mont, dtype=np.uint64)
     return LIB.mo_groth16_verify(curve, ctypes.byref(pks), _p(inputs), bytes(proof))
 

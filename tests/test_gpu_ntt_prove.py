@@ -49,3 +49,33 @@ def test_prove_matches_oracle_and_verifies(gpu, curve, m, V, P):
     z_bad[c.P + 1] = rs[0]
     bad = gpu.Groth16.prove_with_randomness(ctx, z_bad, rs[0], rs[1])
     assert bad == O.groth16_prove(c, pk, rs[0], rs[1], z=z_bad)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_gpu_keygen_matches_oracle_setup(gpu, curve):
+    """manta_rs_amd.keygen (host scalars + GPU fixed-base batch multiply) reproduces the oracle's toy setup
+    point-for-point, for G1 and G2 queries incl. infinity entries."""
+    from manta_rs_amd import keygen
+    c = synth.make_circuit(curve, 300, 200, 7, seed=77)
+    tox = H.toxic(curve, seed=21)
+    want = O.groth16_setup(c, tox)
+    got = keygen.generate(c, synth.from_mont(tox, synth.FR_MODULUS[curve]))
+    for f in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1", "a_query",
+              "b_g1_query", "b_g2_query", "h_query", "l_query"):
+        assert (getattr(got, f) == getattr(want, f)).all(), f
+    assert any(not row.any() for row in got.b_g1_query)  # infinity entries present
+
+
+def test_prove_real_shape_to_private(gpu):
+    """Shape-exact ToPrivate circuit (D=2^14, V=8253, P=13): proof bytes equal the oracle's and the
+    proof verifies."""
+    from manta_rs_amd import keygen
+    c = synth.make_shape(0, "to_private")
+    assert (c.D, c.V, c.P) == (1 << 14, 8253, 13)
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=5), synth.FR_MODULUS[0]))
+    ctx = gpu.ProvingContext(0, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(0, 2, seed=123)
+    proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    assert proof == O.groth16_prove(c, pk, rs[0], rs[1])
+    assert O.groth16_verify(0, pk, c.z[1:c.P], proof) == 1

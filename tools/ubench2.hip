@@ -10,6 +10,8 @@ typedef uint32_t u32; typedef uint64_t u64;
 #define I128 I32 I32 I32 I32
 #define I512 I128 I128 I128 I128
 #define I2048 I512 I512 I512 I512
+#define I8192 I2048 I2048 I2048 I2048
+#define I16384 I8192 I8192
 template <int BODY> __global__ __launch_bounds__(256) void k(u32 *out, int total) {
     u32 a = threadIdx.x * 2654435761u + 12345, b = blockIdx.x * 40503u + 977;
     u64 c0 = a, c1 = b, c2 = a ^ b, c3 = a + b;
@@ -20,6 +22,8 @@ template <int BODY> __global__ __launch_bounds__(256) void k(u32 *out, int total
         if (BODY == 128) asm volatile(I128 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
         if (BODY == 512) asm volatile(I512 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
         if (BODY == 2048) asm volatile(I2048 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
+        if (BODY == 8192) asm volatile(I8192 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
+        if (BODY == 16384) asm volatile(I16384 : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b) : "vcc");
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (u32)(c0 ^ c1 ^ c2 ^ c3);
 }
@@ -31,7 +35,7 @@ int main() {
     const int total = 1 << 20;
     for (int bpc = 1; bpc <= 8; bpc *= 2) {
         const int blocks = p.multiProcessorCount * bpc;
-        for (int body : {8, 32, 128, 512, 2048}) {
+        for (int body : {512, 2048, 8192, 16384}) {
             auto launch = [&]() {
                 switch (body) {
                 case 8: hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, out, total); break;
@@ -39,6 +43,8 @@ int main() {
                 case 128: hipLaunchKernelGGL(k<128>, dim3(blocks), dim3(256), 0, 0, out, total); break;
                 case 512: hipLaunchKernelGGL(k<512>, dim3(blocks), dim3(256), 0, 0, out, total); break;
                 case 2048: hipLaunchKernelGGL(k<2048>, dim3(blocks), dim3(256), 0, 0, out, total); break;
+                case 8192: hipLaunchKernelGGL(k<8192>, dim3(blocks), dim3(256), 0, 0, out, total); break;
+                case 16384: hipLaunchKernelGGL(k<16384>, dim3(blocks), dim3(256), 0, 0, out, total); break;
                 }
             };
             launch(); hipDeviceSynchronize();
