@@ -11,6 +11,11 @@
 //
 // Memory formats: affine = x || y (Montgomery limbs), infinity = all zero (b != 0 so (0,0) is never
 // on the curve); XYZZ = X || Y || ZZ || ZZZ, infinity <=> ZZ == 0.
+//
+// The same formulas serve canonical fields (Fp, Fp2) and the lazily-reduced FpR (fpr_dev.h). For FpR
+// the coordinates obey the invariants  X < 8p, Y < 4p, ZZ, ZZZ < 2p, affine x, y < 2p  (every product
+// is < 2p); each sub<M>/sub2<M> adds M*p with M >= the subtrahend's bound, each is_zero_mod<B> is told
+// the bound B of its operand. The largest product of operand bounds is 100 (P^2 in madd) <= 128.
 #pragma once
 #include "fp_dev.h"
 
@@ -25,7 +30,7 @@ namespace mg {
 
 template <class F> struct Affine {
     F x, y;
-    MG_DEV bool is_inf() const { return x.is_zero() & y.is_zero(); }
+    MG_DEV bool is_inf() const { return x.is_zero_exact() & y.is_zero_exact(); }
     static MG_DEV Affine load(const u32 *p) { return Affine{F::load(p), F::load(p + F::N)}; }
     MG_DEV void store(u32 *p) const {
         x.store(p);
@@ -37,7 +42,7 @@ template <class F> struct Affine {
 template <class F> struct XYZZ {
     F x, y, zz, zzz;
     static constexpr int WORDS = 4 * F::N;
-    MG_DEV bool is_inf() const { return zz.is_zero(); }
+    MG_DEV bool is_inf() const { return zz.is_zero_exact(); }
     static MG_DEV XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
     static MG_DEV XYZZ from_affine(const Affine<F> &a) {
         if (a.is_inf()) return inf();
@@ -51,6 +56,14 @@ template <class F> struct XYZZ {
         y.store(p + F::N);
         zz.store(p + 2 * F::N);
         zzz.store(p + 3 * F::N);
+    }
+    // arkworks-format store (canonical 32-bit Montgomery limbs) for the few points staged to the host
+    MG_DEV void store_std(u32 *p) const {
+        typedef typename F::Std S;
+        x.to_std().store(p);
+        y.to_std().store(p + S::N);
+        zz.to_std().store(p + 2 * S::N);
+        zzz.to_std().store(p + 3 * S::N);
     }
     static MG_DEV XYZZ shfl(const XYZZ &a, int src) {
         return XYZZ{F::shfl(a.x, src), F::shfl(a.y, src), F::shfl(a.zz, src), F::shfl(a.zzz, src)};
@@ -66,14 +79,14 @@ template <class F> struct XYZZ {
         else return dbl_affine_body(p);
     }
     static MG_DEV XYZZ dbl_affine_body(const Affine<F> &p) {
-        F U = F::dbl(p.y);
+        F U = F::dbl(p.y);                                     // < 4p
         F V = F::sqr(U);
         F W = F::mul(U, V);
         F S = F::mul(p.x, V);
         F X2 = F::sqr(p.x);
-        F M = F::add(F::dbl(X2), X2);
-        F X3 = F::sub(F::sqr(M), F::dbl(S));
-        F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        F M = F::add(F::dbl(X2), X2);                          // < 6p
+        F X3 = F::template sub2<4>(F::sqr(M), F::zero(), S);   // M^2 - 2S        < 6p
+        F Y3 = F::template sub<2>(F::mul(M, F::template sub<8>(S, X3)), F::mul(W, p.y)); // < 4p
         return XYZZ{X3, Y3, V, W};
     }
     // dbl-2008-s-1
@@ -84,14 +97,14 @@ template <class F> struct XYZZ {
     }
     static MG_DEV XYZZ dbl_body(const XYZZ &p) {
         if (p.is_inf()) return p;
-        F U = F::dbl(p.y);
+        F U = F::dbl(p.y);                                     // < 8p
         F V = F::sqr(U);
         F W = F::mul(U, V);
         F S = F::mul(p.x, V);
         F X2 = F::sqr(p.x);
-        F M = F::add(F::dbl(X2), X2);
-        F X3 = F::sub(F::sqr(M), F::dbl(S));
-        F Y3 = F::sub(F::mul(M, F::sub(S, X3)), F::mul(W, p.y));
+        F M = F::add(F::dbl(X2), X2);                          // < 6p
+        F X3 = F::template sub2<4>(F::sqr(M), F::zero(), S);   // < 6p
+        F Y3 = F::template sub<2>(F::mul(M, F::template sub<8>(S, X3)), F::mul(W, p.y)); // < 4p
         return XYZZ{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
     }
     // acc += (neg ? -q : q), q affine -- madd-2008-s with exact exceptional cases
@@ -103,7 +116,7 @@ template <class F> struct XYZZ {
     MG_DEV void madd_body(const Affine<F> &q_in, bool neg) {
         if (q_in.is_inf()) return;
         Affine<F> q = q_in;
-        if (neg) q.y = F::neg(q.y);
+        if (neg) q.y = F::template neg<2>(q.y);                // <= 2p
         if (is_inf()) {
             x = q.x;
             y = q.y;
@@ -113,10 +126,10 @@ template <class F> struct XYZZ {
         }
         F U2 = F::mul(q.x, zz);
         F S2 = F::mul(q.y, zzz);
-        F P = F::sub(U2, x);
-        F R = F::sub(S2, y);
-        if (P.is_zero()) {
-            if (R.is_zero())
+        F P = F::template sub<8>(U2, x);                       // < 10p
+        F R = F::template sub<4>(S2, y);                       // < 6p
+        if (P.template is_zero_mod<10>()) {
+            if (R.template is_zero_mod<6>())
                 *this = dbl_affine(q);
             else
                 *this = inf();
@@ -125,8 +138,8 @@ template <class F> struct XYZZ {
         F PP = F::sqr(P);
         F PPP = F::mul(P, PP);
         F Q = F::mul(x, PP);
-        F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(y, PPP));
+        F X3 = F::template sub2<6>(F::sqr(R), PPP, Q);         // R^2 - PPP - 2Q   < 8p
+        F Y3 = F::template sub<2>(F::mul(R, F::template sub<8>(Q, X3)), F::mul(y, PPP)); // < 4p
         x = X3;
         y = Y3;
         zz = F::mul(zz, PP);
@@ -148,10 +161,10 @@ template <class F> struct XYZZ {
         F U2 = F::mul(o.x, zz);
         F S1 = F::mul(y, o.zzz);
         F S2 = F::mul(o.y, zzz);
-        F P = F::sub(U2, U1);
-        F R = F::sub(S2, S1);
-        if (P.is_zero()) {
-            if (R.is_zero())
+        F P = F::template sub<2>(U2, U1);                      // < 4p
+        F R = F::template sub<2>(S2, S1);                      // < 4p
+        if (P.template is_zero_mod<4>()) {
+            if (R.template is_zero_mod<4>())
                 *this = dbl(*this);
             else
                 *this = inf();
@@ -160,8 +173,8 @@ template <class F> struct XYZZ {
         F PP = F::sqr(P);
         F PPP = F::mul(P, PP);
         F Q = F::mul(U1, PP);
-        F X3 = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
-        F Y3 = F::sub(F::mul(R, F::sub(Q, X3)), F::mul(S1, PPP));
+        F X3 = F::template sub2<6>(F::sqr(R), PPP, Q);         // < 8p
+        F Y3 = F::template sub<2>(F::mul(R, F::template sub<8>(Q, X3)), F::mul(S1, PPP)); // < 4p
         x = X3;
         y = Y3;
         zz = F::mul(F::mul(zz, o.zz), PP);

@@ -135,6 +135,17 @@ template <class C> struct Fp {
         return a.is_zero() ? z : sub(z, a);
     }
     static MG_DEV Fp dbl(const Fp &a) { return add(a, a); }
+    // Interface shared with the lazily-reduced FpR (fpr_dev.h): the multiple-of-p / bound template
+    // arguments are meaningless for canonical values and ignored here.
+    static constexpr bool LAZY = false;
+    template <int M> static MG_DEV Fp sub(const Fp &a, const Fp &b) { return sub(a, b); }
+    template <int M> static MG_DEV Fp sub2(const Fp &a, const Fp &b, const Fp &c) { return sub(sub(a, b), dbl(c)); }
+    template <int M> static MG_DEV Fp neg(const Fp &a) { return neg(a); }
+    template <int B> MG_DEV bool is_zero_mod() const { return is_zero(); }
+    MG_DEV bool is_zero_exact() const { return is_zero(); }
+    typedef Fp Std;
+    static MG_DEV Fp from_std(const Fp &s) { return s; }
+    MG_DEV Fp to_std() const { return *this; }
 
     // Montgomery product a*b*R^-1 mod P, product scanning with interleaved reduction.
     static MG_MUL_ATTR Fp mul(const Fp a, const Fp b) {
@@ -231,6 +242,15 @@ template <class C> struct Fp2 {
     static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return Fp2{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
     static MG_DEV Fp2 neg(const Fp2 &a) { return Fp2{B::neg(a.c0), B::neg(a.c1)}; }
     static MG_DEV Fp2 dbl(const Fp2 &a) { return add(a, a); }
+    static constexpr bool LAZY = false;
+    template <int M> static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return sub(a, b); }
+    template <int M> static MG_DEV Fp2 sub2(const Fp2 &a, const Fp2 &b, const Fp2 &c) { return sub(sub(a, b), dbl(c)); }
+    template <int M> static MG_DEV Fp2 neg(const Fp2 &a) { return neg(a); }
+    template <int B> MG_DEV bool is_zero_mod() const { return is_zero(); }
+    MG_DEV bool is_zero_exact() const { return is_zero(); }
+    typedef Fp2 Std;
+    static MG_DEV Fp2 from_std(const Fp2 &s) { return s; }
+    MG_DEV Fp2 to_std() const { return *this; }
     static MG_FP2_ATTR Fp2 mul(const Fp2 &a, const Fp2 &b) { // Karatsuba, 3 base mults
         B v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
         B s = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));

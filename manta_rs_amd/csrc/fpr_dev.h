@@ -1,0 +1,256 @@
+// Reduced-radix ("carry-free") prime-field arithmetic for gfx950 -- the internal representation of
+// the G1 MSM kernels.
+//
+// Why: CDNA4 has no multiply-with-carry-in. With saturated 32-bit limbs every 32x32 product costs one
+// v_mad_u64_u32 (4.2 cycles/wave) PLUS one v_addc_co_u32 (4.3 cycles, serialised through VCC) -- half of
+// Fp::mul's cycles are carries (measured: tools/ubench3.hip, profiles/r01_ubench3_reduced_radix_mul.txt).
+// With K limbs of LB < 32 bits a whole column of 2K products fits a 64-bit accumulator, so a product is
+// exactly one v_mad_u64_u32 and a column costs one shift + mask: 1.55x faster at the accumulate kernel's
+// occupancy, although it needs (K/N)^2 ~ 1.3x more multiplies.
+//
+//   BLS12-381 Fq: K = 14 limbs x 28 bits (R' = 2^392);  BN254 Fq: K = 9 x 29 bits (R' = 2^261).
+//
+// Values are kept LAZILY reduced: limbs are always normalised (< 2^LB), the integer value may be any
+// representative below a small multiple of p (bounds are tracked per call site in ec_dev.h). Because
+// R' >= 2^7 p, an "almost Montgomery" product of inputs a < Ba*p, b < Bb*p is < 2p whenever
+// Ba*Bb <= 128 (BN254) / 2048 (BLS12-381), with no final subtraction. Subtractions add a multiple M*p
+// chosen from the subtrahend's bound. Exact tests (is_zero_mod) compare against the multiples of p.
+//
+// Memory format: K u32 words per element. Conversion to/from the arkworks format (32-bit limbs,
+// R = 2^(32N)) happens once, when bases are registered and when the few result points are staged.
+#pragma once
+#include "fp_dev.h"
+
+namespace mg {
+
+template <class C> struct FpR {
+    static constexpr int K = C::RR_K, LB = C::RR_LB;
+    static constexpr int N = K; // words per element in memory
+    static constexpr bool EXT = false;
+    static constexpr bool LAZY = true;
+    static constexpr u32 MASK = (1u << LB) - 1;
+    typedef Fp<C> Std;
+    u32 v[K];
+
+    static MG_DEV FpR zero() {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = 0;
+        return r;
+    }
+    static MG_DEV FpR one() {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = C::RR_ONE[i];
+        return r;
+    }
+    MG_DEV bool is_zero_exact() const { // the all-zero representative (used as the infinity marker)
+        u32 x = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) x |= v[i];
+        return x == 0;
+    }
+    // value == 0 (mod p), given value < B*p : value is one of 0, p, ..., (B-1)p
+    template <int B> MG_DEV bool is_zero_mod() const {
+        static_assert(B - 1 <= C::RR_MAXM, "multiple table too short");
+        bool hit = false;
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            if (v[0] == C::RR_MULT[k][0]) { // cheap pre-filter on the low limb; the full compare is rare
+                u32 d = 0;
+#pragma unroll
+                for (int i = 1; i < K; ++i) d |= v[i] ^ C::RR_MULT[k][i];
+                hit |= (d == 0);
+            }
+        }
+        return hit;
+    }
+
+    // ---- linear operations: limb-wise in signed 32-bit, then one carry-normalisation pass
+    static MG_DEV FpR normalize(const int (&t)[K]) {
+        FpR r;
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            const int s = t[i] + c;
+            c = s >> LB; // arithmetic shift: borrows propagate as -1
+            r.v[i] = (u32)s & MASK;
+        }
+        r.v[K - 1] = (u32)(t[K - 1] + c); // value >= 0 and < 2^(LB*K): top limb needs no mask
+        return r;
+    }
+    static MG_DEV FpR add(const FpR &a, const FpR &b) {
+        int t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = (int)(a.v[i] + b.v[i]);
+        return normalize(t);
+    }
+    static MG_DEV FpR dbl(const FpR &a) { return add(a, a); }
+    // a + M*p - b   (requires b < M*p)
+    template <int M> static MG_DEV FpR sub(const FpR &a, const FpR &b) {
+        static_assert(M <= C::RR_MAXM, "multiple table too short");
+        int t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = (int)a.v[i] + (int)C::RR_MULT[M][i] - (int)b.v[i];
+        return normalize(t);
+    }
+    // a + M*p - b - 2c   (requires b + 2c < M*p)
+    template <int M> static MG_DEV FpR sub2(const FpR &a, const FpR &b, const FpR &c) {
+        static_assert(M <= C::RR_MAXM, "multiple table too short");
+        int t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = (int)a.v[i] + (int)C::RR_MULT[M][i] - (int)b.v[i] - 2 * (int)c.v[i];
+        return normalize(t);
+    }
+    template <int M> static MG_DEV FpR neg(const FpR &a) { return sub<M>(zero(), a); }
+
+    // ---- almost-Montgomery product: a*b*R'^-1 mod p, result < 2p (see header for the input bounds)
+    static MG_DEV FpR mul(const FpR &a, const FpR &b) {
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                acc += (u64)a.v[i] * b.v[k - i];
+                acc += (u64)m[i] * C::RR_P[k - i];
+            }
+            acc += (u64)a.v[k] * b.v[0];
+            m[k] = ((u32)acc * C::RR_INV) & MASK;
+            acc += (u64)m[k] * C::RR_P[0];
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int k = K; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = k - K + 1; i < K; ++i) {
+                acc += (u64)a.v[i] * b.v[k - i];
+                acc += (u64)m[i] * C::RR_P[k - i];
+            }
+            t.v[k - K] = (u32)acc & MASK;
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    // square: cross products once, against the doubled operand
+    static MG_DEV FpR sqr(const FpR &a) {
+        u64 acc = 0;
+        u32 m[K], a2[K];
+        FpR t;
+#pragma unroll
+        for (int i = 0; i < K; ++i) a2[i] = a.v[i] << 1;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = k - i;
+                if (j < 0 || j >= K) continue;
+                if (i < j) acc += (u64)a2[i] * a.v[j];
+                if (i == j) acc += (u64)a.v[i] * a.v[i];
+                if (k < K) {
+                    if (i < k) acc += (u64)m[i] * C::RR_P[k - i];
+                } else {
+                    acc += (u64)m[i] * C::RR_P[k - i];
+                }
+            }
+            if (k < K) {
+                m[k] = ((u32)acc * C::RR_INV) & MASK;
+                acc += (u64)m[k] * C::RR_P[0];
+            } else {
+                t.v[k - K] = (u32)acc & MASK;
+            }
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    static __device__ __noinline__ FpR inv(const FpR &a) { // a^(p-2); slow, one-off use only
+        FpR acc = one();
+        for (int i = 32 * C::N - 1; i >= 0; --i) {
+            acc = sqr(acc);
+            u32 w = 0;
+#pragma unroll
+            for (int j = 0; j < C::N; ++j)
+                if (j == (i >> 5)) w = C::PM2[j];
+            if ((w >> (i & 31)) & 1) acc = mul(acc, a);
+        }
+        return acc;
+    }
+
+    // ---- conversions to / from the arkworks (32-bit limb, R = 2^(32N)) Montgomery form
+    static MG_DEV FpR from_std(const Std &s) {
+        Std c;
+#pragma unroll
+        for (int i = 0; i < C::N; ++i) c.v[i] = C::RR_TO[i];
+        const Std t = Std::mul(s, c); // a*R * R' * R^-1 = a*R' mod p, canonical
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int bit = i * LB, w = bit >> 5, o = bit & 31;
+            u64 x = w < C::N ? t.v[w] : 0;
+            if (w + 1 < C::N) x |= (u64)t.v[w + 1] << 32;
+            r.v[i] = (u32)(x >> o) & MASK;
+        }
+        return r;
+    }
+    MG_DEV Std to_std() const {
+        FpR c;
+#pragma unroll
+        for (int i = 0; i < K; ++i) c.v[i] = C::RR_FROM[i];
+        FpR y = mul(*this, c); // a*R' * R * R'^-1 = a*R mod p, in [0, 2p)
+        // one conditional subtraction of p
+        int t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = (int)y.v[i] - (int)C::RR_P[i];
+        int cy = 0;
+        u32 d[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int s = t[i] + cy;
+            cy = s >> LB;
+            d[i] = (u32)s & MASK;
+        }
+        const bool ge = cy == 0; // no final borrow: y >= p
+#pragma unroll
+        for (int i = 0; i < K; ++i) y.v[i] = ge ? d[i] : y.v[i];
+        Std r;
+#pragma unroll
+        for (int w = 0; w < C::N; ++w) { // gather 32-bit words from the LB-bit limbs
+            u64 x = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int lo = i * LB - w * 32; // position of limb i relative to word w
+                if (lo > -LB && lo < 32) x |= lo >= 0 ? ((u64)y.v[i] << lo) : ((u64)y.v[i] >> (-lo));
+            }
+            r.v[w] = (u32)x;
+        }
+        return r;
+    }
+
+    static MG_DEV FpR load(const u32 *p) {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = p[i];
+        return r;
+    }
+    MG_DEV void store(u32 *p) const {
+#pragma unroll
+        for (int i = 0; i < K; ++i) p[i] = v[i];
+    }
+    static MG_DEV FpR select(bool c, const FpR &a, const FpR &b) {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = c ? a.v[i] : b.v[i];
+        return r;
+    }
+    static MG_DEV FpR shfl(const FpR &a, int src_lane) {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = __shfl(a.v[i], src_lane, 64);
+        return r;
+    }
+};
+
+} // namespace mg

@@ -23,11 +23,13 @@
 #pragma once
 #include "ec_dev.h"
 #include "engine.h"
+#include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace mg {
 
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void merge_partials(const u32 *__restrict__ pk
 template <class F>
 __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                    u32 item_off, u32 n_items, u32 tiles_per_seg, u32 n_waves,
-                                                   u32 *__restrict__ outA, u32 *__restrict__ outS) {
+                                                   u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= n_waves) return;
@@ -232,14 +234,43 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
         const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
         if (lane + d < 64) acc.add(o);
     }
-    if (lane == 0) acc.store(outA + (size_t)wave * XYZZ<F>::WORDS);
+    constexpr int SW = XYZZ<typename F::Std>::WORDS; // arkworks-format words per point (host staging)
+    if (lane == 0) {
+        if (std_out)
+            acc.store_std(outA + (size_t)wave * SW);
+        else
+            acc.store(outA + (size_t)wave * XYZZ<F>::WORDS);
+    }
     if (outS) {
         for (int d = 32; d >= 1; d >>= 1) { // tree sum of the suffix sums
             const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
             if (lane < d) acc.add(o);
         }
-        if (lane == 0) acc.store(outS + (size_t)wave * XYZZ<F>::WORDS);
+        if (lane == 0) {
+            if (std_out)
+                acc.store_std(outS + (size_t)wave * SW);
+            else
+                acc.store(outS + (size_t)wave * XYZZ<F>::WORDS);
+        }
     }
+}
+
+// arkworks-format affine bases -> internal representation (identity copy when the two coincide)
+template <class F>
+__global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef typename F::Std S;
+    const Affine<S> a = Affine<S>::load(in + i * Affine<S>::WORDS);
+    Affine<F> r;
+    if (a.is_inf()) {
+        r.x = F::zero();
+        r.y = F::zero();
+    } else {
+        r.x = F::from_std(a.x);
+        r.y = F::from_std(a.y);
+    }
+    r.store(out + i * Affine<F>::WORDS);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -261,6 +292,9 @@ template <class F> struct FieldInv; // Fermat inversion on the device (slow, one
 template <class C> struct FieldInv<Fp<C>> {
     static __device__ Fp<C> inv(const Fp<C> &a) { return Fp<C>::inv(a); }
 };
+template <class C> struct FieldInv<FpR<C>> {
+    static __device__ FpR<C> inv(const FpR<C> &a) { return FpR<C>::inv(a); }
+};
 template <class C> struct FieldInv<Fp2<C>> {
     static __device__ Fp2<C> inv(const Fp2<C> &a) {
         typedef Fp<C> B;
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
     for (int k = 0; k < KB && b0 + k < n; ++k) {
         const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
         F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
-        F d = zz.is_zero() ? F::one() : F::mul(zz, zzz);
+        F d = zz.is_zero_exact() ? F::one() : F::mul(zz, zzz);
         run.store(aff + (b0 + k) * Affine<F>::WORDS); // prefix before k
         run = F::mul(run, d);
     }
@@ -290,7 +324,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
         const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
         u32 *dst = aff + (b0 + k) * Affine<F>::WORDS;
         F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
-        if (zz.is_zero()) {
+        if (zz.is_zero_exact()) {
             F::zero().store(dst);
             F::zero().store(dst + F::N);
             continue;
@@ -340,11 +374,17 @@ __global__ __launch_bounds__(256) void sum_affine_kernel(const u32 *__restrict__
 // --------------------------------------------------------------------------------------------
 template <class Curve, int GROUP> struct GT;
 template <class Curve> struct GT<Curve, 1> {
-    typedef Fp<typename Curve::Fq> F;
+#ifdef MG_G1_SATURATED
+    typedef Fp<typename Curve::Fq> F; // 32-bit saturated limbs everywhere (A/B reference build)
+#else
+    typedef FpR<typename Curve::Fq> F; // internal: reduced radix, lazily reduced
+#endif
+    typedef Fp<typename Curve::Fq> FIO; // arkworks memory format at the ABI
     typedef host::HFp<typename Curve::Fq> HF;
 };
 template <class Curve> struct GT<Curve, 2> {
     typedef Fp2<typename Curve::Fq> F;
+    typedef Fp2<typename Curve::Fq> FIO;
     typedef host::HFp2<typename Curve::Fq> HF;
 };
 
@@ -353,16 +393,19 @@ static inline u32 cdiv(size_t a, size_t b) { return (u32)((a + b - 1) / b); }
 template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public GroupEngine {
   public:
     typedef typename GT<Curve, GROUP>::F F;
+    typedef typename GT<Curve, GROUP>::FIO FIO;
     typedef typename GT<Curve, GROUP>::HF HF;
     typedef host::HPoint<HF> HP;
     typedef typename Curve::Fr FrC;
-    static constexpr int AW = Affine<F>::WORDS, XW = XYZZ<F>::WORDS;
+    static constexpr int AW = Affine<F>::WORDS, XW = XYZZ<F>::WORDS;           // internal formats
+    static constexpr int AW_IO = Affine<FIO>::WORDS, XW_IO = XYZZ<FIO>::WORDS; // arkworks formats (ABI, staging)
+    static constexpr bool SAME = std::is_same<F, FIO>::value;
     static_assert(sizeof(HP) <= sizeof(HostPoint), "HostPoint too small");
 
     int curve() const override { return CURVE_ID; }
     int group() const override { return GROUP; }
-    int affine_words() const override { return AW; }
-    int xyzz_words() const override { return XW; }
+    int affine_words() const override { return AW_IO; }
+    int xyzz_words() const override { return XW_IO; }
     int scalar_bits() const override { return FrC::BITS; }
     int point_bytes(bool compressed) const override { return compressed ? HF::BYTES : 2 * HF::BYTES; }
 
@@ -398,10 +441,26 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             set_last_hip_error(e, "hipMalloc(bases)", __FILE__, __LINE__);
             return MG_ERR_OOM;
         }
-        e = hipMemcpy(bs->d_pts, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+        if (SAME) {
+            e = hipMemcpy(bs->d_pts, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+        } else { // convert arkworks limbs -> internal representation on the device
+            u32 *stage = nullptr;
+            const u32 *src = pts;
+            e = hipSuccess;
+            if (!src_on_device) {
+                e = hipMalloc((void **)&stage, n * AW_IO * 4);
+                if (e == hipSuccess) e = hipMemcpy(stage, pts, n * AW_IO * 4, hipMemcpyHostToDevice);
+                src = stage;
+            }
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, bs->d_pts);
+                e = hipDeviceSynchronize();
+            }
+            if (stage) hipFree(stage);
+        }
         if (e != hipSuccess) {
             bases_destroy(bs);
-            set_last_hip_error(e, "hipMemcpy(bases)", __FILE__, __LINE__);
+            set_last_hip_error(e, "upload/convert bases", __FILE__, __LINE__);
             return MG_ERR_HIP;
         }
         if (W > 1) {
@@ -520,31 +579,32 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // ---- bucket reduce
         const u32 segs = (u32)pl.Wb;
         const u32 T0 = cdiv(pl.B, 64);
-        if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)))
+        constexpr int XWM = XW > XW_IO ? XW : XW_IO;
+        if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
             return rc;
         hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                           pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>());
+                           pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), T0 == 1 ? 1 : 0);
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
         if (T0 == 1) {
             // window sum = S0[seg]
             stage_pts = segs;
-            if ((rc = stage_reserve(ws, stage_pts * XW * 4))) return rc;
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else {
             T1 = cdiv(T0 - 1, 64); // level 1 over A0[1..T0-1]
             nP = cdiv(T0, 64);     // plain sums of S0[0..T0-1]
-            if ((rc = ws->misc.reserve((size_t)segs * (2 * T1 + nP) * XW * 4))) return rc;
+            if ((rc = ws->misc.reserve((size_t)segs * (2 * T1 + nP) * XW_IO * 4))) return rc;
             u32 *A1 = ws->misc.as<u32>();
-            u32 *S1 = A1 + (size_t)segs * T1 * XW;
-            u32 *P0 = S1 + (size_t)segs * T1 * XW;
+            u32 *S1 = A1 + (size_t)segs * T1 * XW_IO;
+            u32 *P0 = S1 + (size_t)segs * T1 * XW_IO;
             hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T1, 4)), dim3(256), 0, s,
-                               ws->redA.as<u32>(), T0, 1u, T0 - 1, T1, segs * T1, A1, S1);
+                               ws->redA.as<u32>(), T0, 1u, T0 - 1, T1, segs * T1, A1, S1, 1);
             hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * nP, 4)), dim3(256), 0, s,
-                               ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr);
+                               ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr, 1);
             stage_pts = (size_t)segs * (2 * T1 + nP);
-            if ((rc = stage_reserve(ws, stage_pts * XW * 4))) return rc;
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW * 4, hipMemcpyDeviceToHost, s));
+            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
         MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());
@@ -582,23 +642,23 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         for (int w = (int)segs - 1; w >= 0; --w) {
             HP win;
             if (T1 == 0) {
-                win = HP::from_xyzz_words(st + (size_t)w * XW);
+                win = HP::from_xyzz_words(st + (size_t)w * XW_IO);
             } else {
-                const u32 *A1 = st + ((size_t)w * T1) * XW;
-                const u32 *S1 = st + ((size_t)segs * T1 + (size_t)w * T1) * XW;
-                const u32 *P0 = st + ((size_t)segs * 2 * T1 + (size_t)w * nP) * XW;
+                const u32 *A1 = st + ((size_t)w * T1) * XW_IO;
+                const u32 *S1 = st + ((size_t)segs * T1 + (size_t)w * T1) * XW_IO;
+                const u32 *P0 = st + ((size_t)segs * 2 * T1 + (size_t)w * nP) * XW_IO;
                 // X = sum_{t>=1} t*A0[t] = sum_u ( S1[u] + 64*u*A1[u] )
                 HP sumS = HP::inf(), run = HP::inf(), uA = HP::inf();
                 for (int u = (int)T1 - 1; u >= 0; --u) {
-                    sumS = HP::add(sumS, HP::from_xyzz_words(S1 + (size_t)u * XW));
+                    sumS = HP::add(sumS, HP::from_xyzz_words(S1 + (size_t)u * XW_IO));
                     if (u >= 1) {
-                        run = HP::add(run, HP::from_xyzz_words(A1 + (size_t)u * XW));
+                        run = HP::add(run, HP::from_xyzz_words(A1 + (size_t)u * XW_IO));
                         uA = HP::add(uA, run); // sum_u u*A1[u]
                     }
                 }
                 HP X = HP::add(sumS, HP::mul_pow2(uA, 6));
                 HP sumP = HP::inf();
-                for (u32 u = 0; u < nP; ++u) sumP = HP::add(sumP, HP::from_xyzz_words(P0 + (size_t)u * XW));
+                for (u32 u = 0; u < nP; ++u) sumP = HP::add(sumP, HP::from_xyzz_words(P0 + (size_t)u * XW_IO));
                 win = HP::add(sumP, HP::mul_pow2(X, 6));
             }
             if (w != (int)segs - 1) total = HP::mul_pow2(total, (unsigned)pl.c);
@@ -612,17 +672,17 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     int fixed_base_mul(const u32 *base_affine_host, const u32 *d_scalars, size_t n, u32 *d_out_affine,
                        hipStream_t s) override {
         u32 *d_base = nullptr, *tmp = nullptr;
-        MG_HIP(hipMalloc((void **)&d_base, AW * 4));
-        hipError_t e = hipMalloc((void **)&tmp, n * XW * 4);
+        MG_HIP(hipMalloc((void **)&d_base, AW_IO * 4));
+        hipError_t e = hipMalloc((void **)&tmp, n * XW_IO * 4);
         if (e != hipSuccess) {
             hipFree(d_base);
             set_last_hip_error(e, "hipMalloc(fixed_base tmp)", __FILE__, __LINE__);
             return MG_ERR_OOM;
         }
-        hipMemcpyAsync(d_base, base_affine_host, AW * 4, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL((fixed_base_mul_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
+        hipMemcpyAsync(d_base, base_affine_host, AW_IO * 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL((fixed_base_mul_kernel<FIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
         constexpr int KB = 16;
-        hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, s, tmp, n,
+        hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, s, tmp, n,
                            d_out_affine);
         e = hipStreamSynchronize(s);
         hipFree(d_base);
@@ -637,9 +697,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     int sum_affine(const u32 *d_pts, size_t n, HostPoint *out) override {
         const u32 T = n < 4096 ? (u32)(n ? n : 1) : 4096;
         u32 *tmp = nullptr;
-        MG_HIP(hipMalloc((void **)&tmp, (size_t)T * XW * 4));
-        hipLaunchKernelGGL((sum_affine_kernel<F>), dim3(cdiv(T, 256)), dim3(256), 0, 0, d_pts, n, T, tmp);
-        std::vector<u32> h((size_t)T * XW);
+        MG_HIP(hipMalloc((void **)&tmp, (size_t)T * XW_IO * 4));
+        hipLaunchKernelGGL((sum_affine_kernel<FIO>), dim3(cdiv(T, 256)), dim3(256), 0, 0, d_pts, n, T, tmp);
+        std::vector<u32> h((size_t)T * XW_IO);
         hipError_t e = hipMemcpy(h.data(), tmp, h.size() * 4, hipMemcpyDeviceToHost);
         hipFree(tmp);
         if (e != hipSuccess) {
@@ -647,7 +707,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             return MG_ERR_HIP;
         }
         HP acc = HP::inf();
-        for (u32 t = 0; t < T; ++t) acc = HP::add(acc, HP::from_xyzz_words(h.data() + (size_t)t * XW));
+        for (u32 t = 0; t < T; ++t) acc = HP::add(acc, HP::from_xyzz_words(h.data() + (size_t)t * XW_IO));
         hp(out) = acc;
         return MG_OK;
     }
