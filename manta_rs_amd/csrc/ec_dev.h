@@ -1,5 +1,6 @@
 // Device-side short-Weierstrass (a = 0) group arithmetic for gfx950, generic over the coordinate
-// field F (Fp<Fq> for G1, Fp2<Fq> for G2).
+// field F: canonical Fp<Fq>/Fp2<Fq> (32-bit saturated limbs) or the lazily-reduced FpR<Fq>/Fp2R<Fq>
+// (fpr_dev.h) the MSM kernels use.
 //
 // Replaces (on the GPU) ark-ec ^0.3.0 `short_weierstrass_jacobian` add/double/mixed-add used inside
 // VariableBaseMSM (reference call site
@@ -12,21 +13,68 @@
 // Memory formats: affine = x || y (Montgomery limbs), infinity = all zero (b != 0 so (0,0) is never
 // on the curve); XYZZ = X || Y || ZZ || ZZZ, infinity <=> ZZ == 0.
 //
-// The same formulas serve canonical fields (Fp, Fp2) and the lazily-reduced FpR (fpr_dev.h). For FpR
-// the coordinates obey the invariants  X < 8p, Y < 4p, ZZ, ZZZ < 2p, affine x, y < 2p  (every product
-// is < 2p); each sub<M>/sub2<M> adds M*p with M >= the subtrahend's bound, each is_zero_mod<B> is told
-// the bound B of its operand. The largest product of operand bounds is 100 (P^2 in madd) <= 128.
+// Lazy reduction is made safe at COMPILE TIME: every intermediate is a Bv<F, B> ("value < B*p"); the
+// operators below propagate B, static_assert that each product's operand bounds fit the field's
+// Montgomery headroom (F::LIM), that every subtraction adds a large enough multiple of p and that every
+// zero test knows how many multiples of p to compare with; b_fit<T>() inserts a cheap reduction only
+// where a bound would otherwise exceed T. Stored coordinates obey the invariants X < F::BX p,
+// Y < F::BY p, ZZ, ZZZ < F::BM p, affine x, y < F::BM p. For canonical fields all of it folds to nothing.
 #pragma once
 #include "fp_dev.h"
 
 namespace mg {
 
 // Over Fp2 (G2) the group operations are real functions (like Fp::mul): an XYZZ point over
-// Fp2/BLS12-381 is 96 VGPRs, and with everything inlined hipcc (ROCm 7.2) runs out of registers and --
+// Fp2/BLS12-381 is ~100 VGPRs, and with everything inlined hipcc (ROCm 7.2) runs out of registers and --
 // observed on gfx950, tools/ectest2.hip -- miscompiles the generic add inside the scan kernels. As
 // calls, operands travel through scratch (<2 % of the ~40 field multiplications an add costs). Over Fp
 // (G1) they stay inline: measured 25 % faster on the BLS12-381 accumulate kernel.
 #define MG_EC_CALL __device__ __noinline__
+
+// ---- compile-time bound tracking -----------------------------------------------------------------
+template <class F, int B> struct Bv {
+    F v;
+};
+template <int B, class F> MG_DEV Bv<F, B> bv(const F &f) { return Bv<F, B>{f}; }
+template <class F, int A, int B> MG_DEV Bv<F, F::BM> operator*(const Bv<F, A> &a, const Bv<F, B> &b) {
+    static_assert((long)A * B * F::MULK <= F::LIM, "product of operand bounds exceeds the Montgomery headroom");
+    return Bv<F, F::BM>{F::mul(a.v, b.v)};
+}
+template <class F, int A> MG_DEV Bv<F, F::BM> b_sqr(const Bv<F, A> &a) {
+    static_assert((long)A * A * F::MULK <= F::LIM, "square of operand bound exceeds the Montgomery headroom");
+    return Bv<F, F::BM>{F::sqr(a.v)};
+}
+template <class F, int A, int B> MG_DEV Bv<F, A + B> operator+(const Bv<F, A> &a, const Bv<F, B> &b) {
+    return Bv<F, A + B>{F::add(a.v, b.v)};
+}
+template <class F, int A> MG_DEV Bv<F, 2 * A> b_dbl(const Bv<F, A> &a) { return Bv<F, 2 * A>{F::dbl(a.v)}; }
+template <class F, int A, int B> MG_DEV Bv<F, A + B> operator-(const Bv<F, A> &a, const Bv<F, B> &b) {
+    static_assert(B <= F::MAXM, "no multiple of p large enough for this subtrahend");
+    return Bv<F, A + B>{F::template sub<B>(a.v, b.v)}; // a + B*p - b
+}
+// a - b - 2c
+template <class F, int A, int B, int C>
+MG_DEV Bv<F, A + B + 2 * C> b_sub2(const Bv<F, A> &a, const Bv<F, B> &b, const Bv<F, C> &c) {
+    static_assert(B + 2 * C <= F::MAXM, "no multiple of p large enough for this subtrahend");
+    return Bv<F, A + B + 2 * C>{F::template sub2<B + 2 * C>(a.v, b.v, c.v)};
+}
+template <class F, int A> MG_DEV Bv<F, A> b_neg(const Bv<F, A> &a) {
+    static_assert(A <= F::MAXM, "no multiple of p large enough");
+    return Bv<F, A>{F::template neg<A>(a.v)};
+}
+template <class F, int A> MG_DEV bool b_is_zero(const Bv<F, A> &a) {
+    static_assert(A - 1 <= F::MAXM, "multiple table too short for this zero test");
+    return a.v.template is_zero_mod<A>();
+}
+// make the value fit bound T, reducing only if it has to
+template <int T, class F, int A> MG_DEV Bv<F, T> b_fit(const Bv<F, A> &a) {
+    if constexpr (A <= T) {
+        return Bv<F, T>{a.v};
+    } else {
+        static_assert(F::BRED <= T, "reduction cannot reach the requested bound");
+        return Bv<F, T>{F::template reduce<A>(a.v)};
+    }
+}
 
 template <class F> struct Affine {
     F x, y;
@@ -42,6 +90,7 @@ template <class F> struct Affine {
 template <class F> struct XYZZ {
     F x, y, zz, zzz;
     static constexpr int WORDS = 4 * F::N;
+    static constexpr int BX = F::BX, BY = F::BY, BM = F::BM;
     MG_DEV bool is_inf() const { return zz.is_zero_exact(); }
     static MG_DEV XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
     static MG_DEV XYZZ from_affine(const Affine<F> &a) {
@@ -72,24 +121,32 @@ template <class F> struct XYZZ {
         return XYZZ{F::select(c, a.x, b.x), F::select(c, a.y, b.y), F::select(c, a.zz, b.zz), F::select(c, a.zzz, b.zzz)};
     }
 
-    // 2*(affine) -- mdbl-2008-s-1
+    // shared body of dbl / dbl_affine -- dbl-2008-s-1 / mdbl-2008-s-1: X3, Y3 and the factors V, W
+    template <int AX, int AY>
+    static MG_DEV void dbl_core(const Bv<F, AX> &px, const Bv<F, AY> &py, F &X3o, F &Y3o, F &Vo, F &Wo) {
+        auto U = b_fit<8>(b_dbl(py));
+        auto V = b_sqr(U);
+        auto W = U * V;
+        auto S = px * V;
+        auto X2 = b_sqr(px);
+        auto M = b_fit<6>(b_dbl(X2) + X2);                         // 3 x^2
+        auto X3 = b_fit<BX>(b_sub2(b_sqr(M), bv<0>(F::zero()), S)); // M^2 - 2S
+        auto Y3 = b_fit<BY>(M * b_fit<12>(S - X3) - W * py);
+        X3o = X3.v;
+        Y3o = Y3.v;
+        Vo = V.v;
+        Wo = W.v;
+    }
     static MG_EC_CALL XYZZ dbl_affine_call(const Affine<F> &p) { return dbl_affine_body(p); }
     static MG_DEV XYZZ dbl_affine(const Affine<F> &p) {
         if constexpr (F::EXT) return dbl_affine_call(p);
         else return dbl_affine_body(p);
     }
     static MG_DEV XYZZ dbl_affine_body(const Affine<F> &p) {
-        F U = F::dbl(p.y);                                     // < 4p
-        F V = F::sqr(U);
-        F W = F::mul(U, V);
-        F S = F::mul(p.x, V);
-        F X2 = F::sqr(p.x);
-        F M = F::add(F::dbl(X2), X2);                          // < 6p
-        F X3 = F::template sub2<4>(F::sqr(M), F::zero(), S);   // M^2 - 2S        < 6p
-        F Y3 = F::template sub<2>(F::mul(M, F::template sub<8>(S, X3)), F::mul(W, p.y)); // < 4p
-        return XYZZ{X3, Y3, V, W};
+        XYZZ r;
+        dbl_core(bv<BM>(p.x), bv<BM>(p.y), r.x, r.y, r.zz, r.zzz);
+        return r;
     }
-    // dbl-2008-s-1
     static MG_EC_CALL XYZZ dbl_call(const XYZZ &p) { return dbl_body(p); }
     static MG_DEV XYZZ dbl(const XYZZ &p) {
         if constexpr (F::EXT) return dbl_call(p);
@@ -97,15 +154,12 @@ template <class F> struct XYZZ {
     }
     static MG_DEV XYZZ dbl_body(const XYZZ &p) {
         if (p.is_inf()) return p;
-        F U = F::dbl(p.y);                                     // < 8p
-        F V = F::sqr(U);
-        F W = F::mul(U, V);
-        F S = F::mul(p.x, V);
-        F X2 = F::sqr(p.x);
-        F M = F::add(F::dbl(X2), X2);                          // < 6p
-        F X3 = F::template sub2<4>(F::sqr(M), F::zero(), S);   // < 6p
-        F Y3 = F::template sub<2>(F::mul(M, F::template sub<8>(S, X3)), F::mul(W, p.y)); // < 4p
-        return XYZZ{X3, Y3, F::mul(V, p.zz), F::mul(W, p.zzz)};
+        XYZZ r;
+        F V, W;
+        dbl_core(bv<BX>(p.x), bv<BY>(p.y), r.x, r.y, V, W);
+        r.zz = (bv<BM>(V) * bv<BM>(p.zz)).v;
+        r.zzz = (bv<BM>(W) * bv<BM>(p.zzz)).v;
+        return r;
     }
     // acc += (neg ? -q : q), q affine -- madd-2008-s with exact exceptional cases
     MG_EC_CALL void madd_call(const Affine<F> &q, bool neg) { madd_body(q, neg); }
@@ -113,10 +167,10 @@ template <class F> struct XYZZ {
         if constexpr (F::EXT) madd_call(q, neg);
         else madd_body(q, neg);
     }
-    MG_DEV void madd_body(const Affine<F> &q_in, bool neg) {
+    MG_DEV void madd_body(const Affine<F> &q_in, bool negate) {
         if (q_in.is_inf()) return;
         Affine<F> q = q_in;
-        if (neg) q.y = F::template neg<2>(q.y);                // <= 2p
+        if (negate) q.y = b_neg(bv<BM>(q.y)).v;
         if (is_inf()) {
             x = q.x;
             y = q.y;
@@ -124,26 +178,30 @@ template <class F> struct XYZZ {
             zzz = F::one();
             return;
         }
-        F U2 = F::mul(q.x, zz);
-        F S2 = F::mul(q.y, zzz);
-        F P = F::template sub<8>(U2, x);                       // < 10p
-        F R = F::template sub<4>(S2, y);                       // < 6p
-        if (P.template is_zero_mod<10>()) {
-            if (R.template is_zero_mod<6>())
+        const auto X1 = bv<BX>(x);
+        const auto Y1 = bv<BY>(y);
+        const auto ZZ1 = bv<BM>(zz);
+        const auto ZZZ1 = bv<BM>(zzz);
+        auto U2 = bv<BM>(q.x) * ZZ1;
+        auto S2 = bv<BM>(q.y) * ZZZ1;
+        auto P = U2 - X1;
+        auto R = S2 - Y1;
+        if (b_is_zero(P)) {
+            if (b_is_zero(R))
                 *this = dbl_affine(q);
             else
                 *this = inf();
             return;
         }
-        F PP = F::sqr(P);
-        F PPP = F::mul(P, PP);
-        F Q = F::mul(x, PP);
-        F X3 = F::template sub2<6>(F::sqr(R), PPP, Q);         // R^2 - PPP - 2Q   < 8p
-        F Y3 = F::template sub<2>(F::mul(R, F::template sub<8>(Q, X3)), F::mul(y, PPP)); // < 4p
-        x = X3;
-        y = Y3;
-        zz = F::mul(zz, PP);
-        zzz = F::mul(zzz, PPP);
+        auto PP = b_sqr(P);
+        auto PPP = P * PP;
+        auto Q = X1 * PP;
+        auto X3 = b_fit<BX>(b_sub2(b_sqr(R), PPP, Q)); // R^2 - PPP - 2Q
+        auto Y3 = b_fit<BY>(R * b_fit<12>(Q - X3) - Y1 * PPP);
+        x = X3.v;
+        y = Y3.v;
+        zz = (ZZ1 * PP).v;
+        zzz = (ZZZ1 * PPP).v;
     }
     // acc += o -- add-2008-s with exact exceptional cases
     MG_EC_CALL void add_call(const XYZZ &o) { add_body(o); }
@@ -157,28 +215,28 @@ template <class F> struct XYZZ {
             *this = o;
             return;
         }
-        F U1 = F::mul(x, o.zz);
-        F U2 = F::mul(o.x, zz);
-        F S1 = F::mul(y, o.zzz);
-        F S2 = F::mul(o.y, zzz);
-        F P = F::template sub<2>(U2, U1);                      // < 4p
-        F R = F::template sub<2>(S2, S1);                      // < 4p
-        if (P.template is_zero_mod<4>()) {
-            if (R.template is_zero_mod<4>())
+        auto U1 = bv<BX>(x) * bv<BM>(o.zz);
+        auto U2 = bv<BX>(o.x) * bv<BM>(zz);
+        auto S1 = bv<BY>(y) * bv<BM>(o.zzz);
+        auto S2 = bv<BY>(o.y) * bv<BM>(zzz);
+        auto P = U2 - U1;
+        auto R = S2 - S1;
+        if (b_is_zero(P)) {
+            if (b_is_zero(R))
                 *this = dbl(*this);
             else
                 *this = inf();
             return;
         }
-        F PP = F::sqr(P);
-        F PPP = F::mul(P, PP);
-        F Q = F::mul(U1, PP);
-        F X3 = F::template sub2<6>(F::sqr(R), PPP, Q);         // < 8p
-        F Y3 = F::template sub<2>(F::mul(R, F::template sub<8>(Q, X3)), F::mul(S1, PPP)); // < 4p
-        x = X3;
-        y = Y3;
-        zz = F::mul(F::mul(zz, o.zz), PP);
-        zzz = F::mul(F::mul(zzz, o.zzz), PPP);
+        auto PP = b_sqr(P);
+        auto PPP = P * PP;
+        auto Q = U1 * PP;
+        auto X3 = b_fit<BX>(b_sub2(b_sqr(R), PPP, Q));
+        auto Y3 = b_fit<BY>(R * b_fit<12>(Q - X3) - S1 * PPP);
+        x = X3.v;
+        y = Y3.v;
+        zz = ((bv<BM>(zz) * bv<BM>(o.zz)) * PP).v;
+        zzz = ((bv<BM>(zzz) * bv<BM>(o.zzz)) * PPP).v;
     }
 };
 

@@ -138,6 +138,8 @@ template <class C> struct Fp {
     // Interface shared with the lazily-reduced FpR (fpr_dev.h): the multiple-of-p / bound template
     // arguments are meaningless for canonical values and ignored here.
     static constexpr bool LAZY = false;
+    static constexpr int BM = 1, LIM = 1 << 30, MULK = 1, MAXM = 1 << 30, BX = 1, BY = 1, BRED = 1;
+    template <int A> static MG_DEV Fp reduce(const Fp &a) { return a; }
     template <int M> static MG_DEV Fp sub(const Fp &a, const Fp &b) { return sub(a, b); }
     template <int M> static MG_DEV Fp sub2(const Fp &a, const Fp &b, const Fp &c) { return sub(sub(a, b), dbl(c)); }
     template <int M> static MG_DEV Fp neg(const Fp &a) { return neg(a); }
@@ -243,6 +245,8 @@ template <class C> struct Fp2 {
     static MG_DEV Fp2 neg(const Fp2 &a) { return Fp2{B::neg(a.c0), B::neg(a.c1)}; }
     static MG_DEV Fp2 dbl(const Fp2 &a) { return add(a, a); }
     static constexpr bool LAZY = false;
+    static constexpr int BM = 1, LIM = 1 << 30, MULK = 1, MAXM = 1 << 30, BX = 1, BY = 1, BRED = 1;
+    template <int A> static MG_DEV Fp2 reduce(const Fp2 &a) { return a; }
     template <int M> static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return sub(a, b); }
     template <int M> static MG_DEV Fp2 sub2(const Fp2 &a, const Fp2 &b, const Fp2 &c) { return sub(sub(a, b), dbl(c)); }
     template <int M> static MG_DEV Fp2 neg(const Fp2 &a) { return neg(a); }

@@ -29,6 +29,13 @@ template <class C> struct FpR {
     static constexpr bool EXT = false;
     static constexpr bool LAZY = true;
     static constexpr u32 MASK = (1u << LB) - 1;
+    // bound bookkeeping consumed by ec_dev.h's Bv<> wrapper (values are "< B*p")
+    static constexpr int BM = 2;            // a product is < 2p ...
+    static constexpr int LIM = C::RR_LIM;   // ... whenever the operand bounds multiply to <= LIM
+    static constexpr int MULK = 1;
+    static constexpr int MAXM = C::RR_MAXM; // largest tabulated multiple of p
+    static constexpr int BX = 8, BY = 4;    // invariants of stored XYZZ X and Y coordinates
+    static constexpr int BRED = 2;          // reduce<>() output bound
     typedef Fp<C> Std;
     u32 v[K];
 
@@ -103,6 +110,22 @@ template <class C> struct FpR {
         return normalize(t);
     }
     template <int M> static MG_DEV FpR neg(const FpR &a) { return sub<M>(zero(), a); }
+    // value < A*p (A <= 16)  ->  same residue, < 2p: subtract floor-estimate(value / p) * p, the
+    // quotient estimated from the top limb (never too large, at most one too small)
+    template <int A> static MG_DEV FpR reduce(const FpR &a) {
+        static_assert(A <= 16, "reduce: bound too large for the top-limb quotient estimate");
+        const u32 q = (u32)(((u64)a.v[K - 1] * C::RR_RECIP) >> 32);
+        FpR r;
+        long long c = 0;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            const long long s = (long long)a.v[i] - (long long)((u64)q * C::RR_P[i]) + c;
+            c = s >> LB;
+            r.v[i] = (u32)s & MASK;
+        }
+        r.v[K - 1] = (u32)((long long)a.v[K - 1] - (long long)((u64)q * C::RR_P[K - 1]) + c);
+        return r;
+    }
 
     // ---- almost-Montgomery product: a*b*R'^-1 mod p, result < 2p (see header for the input bounds)
     static MG_DEV FpR mul(const FpR &a, const FpR &b) {
@@ -251,6 +274,59 @@ template <class C> struct FpR {
         for (int i = 0; i < K; ++i) r.v[i] = __shfl(a.v[i], src_lane, 64);
         return r;
     }
+};
+
+// Fp2 = FpR[u]/(u^2+1), components lazily reduced. Products are schoolbook (4 base products): the sum
+// a0+a1 a Karatsuba product needs would double the operand bounds and overrun BN254's 7 bits of
+// Montgomery headroom. Component bounds: product < 4p (c0 = a0 b0 + 2p - a1 b1, c1 = a0 b1 + a1 b0).
+template <class C> struct Fp2R {
+    typedef FpR<C> B;
+    static constexpr int N = 2 * B::N;
+    static constexpr bool EXT = true;
+    static constexpr bool LAZY = true;
+    static constexpr int BM = 4, LIM = B::LIM, MULK = 1, MAXM = B::MAXM, BX = 4, BY = 4, BRED = 2;
+    typedef Fp2<C> Std;
+    B c0, c1;
+    static MG_DEV Fp2R zero() { return Fp2R{B::zero(), B::zero()}; }
+    static MG_DEV Fp2R one() { return Fp2R{B::one(), B::zero()}; }
+    MG_DEV bool is_zero_exact() const { return c0.is_zero_exact() & c1.is_zero_exact(); }
+    template <int A> MG_DEV bool is_zero_mod() const { return c0.template is_zero_mod<A>() && c1.template is_zero_mod<A>(); }
+    static MG_DEV Fp2R add(const Fp2R &a, const Fp2R &b) { return Fp2R{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    static MG_DEV Fp2R dbl(const Fp2R &a) { return add(a, a); }
+    template <int M> static MG_DEV Fp2R sub(const Fp2R &a, const Fp2R &b) {
+        return Fp2R{B::template sub<M>(a.c0, b.c0), B::template sub<M>(a.c1, b.c1)};
+    }
+    template <int M> static MG_DEV Fp2R sub2(const Fp2R &a, const Fp2R &b, const Fp2R &c) {
+        return Fp2R{B::template sub2<M>(a.c0, b.c0, c.c0), B::template sub2<M>(a.c1, b.c1, c.c1)};
+    }
+    template <int M> static MG_DEV Fp2R neg(const Fp2R &a) { return Fp2R{B::template neg<M>(a.c0), B::template neg<M>(a.c1)}; }
+    template <int A> static MG_DEV Fp2R reduce(const Fp2R &a) {
+        return Fp2R{B::template reduce<A>(a.c0), B::template reduce<A>(a.c1)};
+    }
+    static MG_DEV Fp2R mul(const Fp2R &a, const Fp2R &b) {
+        const B v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
+        const B x = B::mul(a.c0, b.c1), y = B::mul(a.c1, b.c0);
+        return Fp2R{B::template sub<2>(v0, v1), B::add(x, y)};
+    }
+    static MG_DEV Fp2R sqr(const Fp2R &a) {
+        const B v0 = B::sqr(a.c0), v1 = B::sqr(a.c1), x = B::mul(a.c0, a.c1);
+        return Fp2R{B::template sub<2>(v0, v1), B::dbl(x)};
+    }
+    static __device__ __noinline__ Fp2R inv(const Fp2R &a) { // one-off use only
+        const B n = B::inv(B::add(B::sqr(a.c0), B::sqr(a.c1)));
+        return Fp2R{B::mul(a.c0, n), B::template neg<2>(B::mul(a.c1, n))};
+    }
+    static MG_DEV Fp2R from_std(const Std &s) { return Fp2R{B::from_std(s.c0), B::from_std(s.c1)}; }
+    MG_DEV Std to_std() const { return Std{c0.to_std(), c1.to_std()}; }
+    static MG_DEV Fp2R load(const u32 *p) { return Fp2R{B::load(p), B::load(p + B::N)}; }
+    MG_DEV void store(u32 *p) const {
+        c0.store(p);
+        c1.store(p + B::N);
+    }
+    static MG_DEV Fp2R select(bool c, const Fp2R &a, const Fp2R &b) {
+        return Fp2R{B::select(c, a.c0, b.c0), B::select(c, a.c1, b.c1)};
+    }
+    static MG_DEV Fp2R shfl(const Fp2R &a, int src_lane) { return Fp2R{B::shfl(a.c0, src_lane), B::shfl(a.c1, src_lane)}; }
 };
 
 } // namespace mg

@@ -295,6 +295,9 @@ template <class C> struct FieldInv<Fp<C>> {
 template <class C> struct FieldInv<FpR<C>> {
     static __device__ FpR<C> inv(const FpR<C> &a) { return FpR<C>::inv(a); }
 };
+template <class C> struct FieldInv<Fp2R<C>> {
+    static __device__ Fp2R<C> inv(const Fp2R<C> &a) { return Fp2R<C>::inv(a); }
+};
 template <class C> struct FieldInv<Fp2<C>> {
     static __device__ Fp2<C> inv(const Fp2<C> &a) {
         typedef Fp<C> B;
@@ -383,7 +386,11 @@ template <class Curve> struct GT<Curve, 1> {
     typedef host::HFp<typename Curve::Fq> HF;
 };
 template <class Curve> struct GT<Curve, 2> {
-    typedef Fp2<typename Curve::Fq> F;
+    // G2 uses the lazily-reduced Fp2R only where an XYZZ point still fits the register file: BN254
+    // (4 x 2 x 9 = 72 words). Over BLS12-381 (112 words) the Fp2R kernels need 256 VGPRs + 1.4 KB of
+    // scratch per lane and -- observed on MI355X, ROCm 7.2 -- do not terminate; they stay on the saturated
+    // Fp2 path (group operations as calls), which passes every parity test.
+    typedef typename std::conditional<(Curve::Fq::RR_K <= 9), Fp2R<typename Curve::Fq>, Fp2<typename Curve::Fq>>::type F;
     typedef Fp2<typename Curve::Fq> FIO;
     typedef host::HFp2<typename Curve::Fq> HF;
 };
