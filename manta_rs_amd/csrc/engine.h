@@ -109,6 +109,12 @@ class GroupEngine {
     virtual void hp_add(HostPoint *acc, const HostPoint *o) const = 0;
     virtual void hp_neg(HostPoint *p) const = 0;
     virtual void hp_mul(HostPoint *p, const u64 *k4) const = 0; // p = [k]p, k canonical 4x u64
+    // out = [k1]p + [k2]q (shared doubling chain)
+    virtual void hp_mul2(const HostPoint *p, const u64 *k1, const HostPoint *q, const u64 *k2, HostPoint *out) const = 0;
+    // fixed-base table for a point that is multiplied in every proof (opaque; freed with hp_table_free)
+    virtual void *hp_table_create(const HostPoint *base) const = 0;
+    virtual void hp_table_mul(const void *table, const u64 *k4, HostPoint *out) const = 0;
+    virtual void hp_table_free(void *table) const = 0;
     virtual void hp_to_affine(const HostPoint *p, u32 *affine_words) const = 0;
     virtual void hp_serialize(const HostPoint *p, unsigned char *out, bool compressed) const = 0;
     virtual int point_bytes(bool compressed) const = 0;

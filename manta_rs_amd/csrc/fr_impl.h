@@ -81,6 +81,92 @@ __global__ __launch_bounds__(256) void scale_const_kernel(u32 *__restrict__ data
     F::mul(F::load(data + (size_t)i * 8), F::load(k)).store(data + (size_t)i * 8);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-fused NTT pass: `ns` consecutive butterfly stages (global stages s0 .. s0+ns-1) of up to three
+// vectors (blockIdx.y) in one launch. A workgroup owns the 2^ns elements that differ only in index bits
+// [s0-1, s0-1+ns), for 2^cb adjacent values of the low bits (so that every global access is a run of
+// 2^cb * 32 contiguous bytes); the tile lives in LDS as limb-major SoA (conflict-free ds_read_b32) and
+// is read from / written to HBM exactly once per pass -- 64 B per element per pass instead of per stage.
+//   DIT (DIF = false): stages ascending, input bit-reversed -> output natural (Cooley-Tukey)
+//   DIF (DIF = true) : stages descending, input natural -> output bit-reversed (Gentleman-Sande)
+// `post` (optional) multiplies element i by post[i] on the way out (n^-1 and coset powers, tabulated in
+// the order the pass leaves the data in), so scaling never costs a pass of its own.
+template <class FrC, bool DIF>
+__global__ __launch_bounds__(256) void ntt_pass_kernel(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
+                                                       const u32 *__restrict__ tw, unsigned lg, unsigned s0,
+                                                       unsigned ns, unsigned cb, const u32 *__restrict__ post) {
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    typedef Fp<FrC> F;
+    u32 *__restrict__ data = blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2);
+    const u32 E = 1u << ns, TOT = E << cb, CM = (1u << cb) - 1;
+    const u32 lo_bits = s0 - 1;
+    const u32 nlo = (1u << lo_bits) >> cb; // groups of 2^cb low-index values
+    const u32 lo_base = (blockIdx.x % nlo) << cb, hi = blockIdx.x / nlo;
+    const size_t base = ((size_t)hi << (lo_bits + ns)) + lo_base;
+    for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
+        const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
+        const uint4 *p = reinterpret_cast<const uint4 *>(data + gi * 8);
+        const uint4 x = p[0], y = p[1];
+        sm[0 * TOT + t] = x.x, sm[1 * TOT + t] = x.y, sm[2 * TOT + t] = x.z, sm[3 * TOT + t] = x.w;
+        sm[4 * TOT + t] = y.x, sm[5 * TOT + t] = y.y, sm[6 * TOT + t] = y.z, sm[7 * TOT + t] = y.w;
+    }
+    __syncthreads();
+    for (unsigned st = 0; st < ns; ++st) {
+        const unsigned tl = DIF ? ns - st : st + 1; // local stage 1..ns
+        const unsigned s = s0 + tl - 1;             // global stage
+        const u32 half = 1u << (tl - 1);
+        for (u32 k = threadIdx.x; k < TOT / 2; k += blockDim.x) {
+            const u32 c = k & CM, kk = k >> cb;
+            const u32 jl = kk & (half - 1), g = kk >> (tl - 1);
+            const u32 i0 = ((((g << tl) | jl)) << cb) + c, i1 = i0 + (half << cb);
+            F a, b;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) a.v[l] = sm[l * TOT + i0], b.v[l] = sm[l * TOT + i1];
+            F w;
+            const bool has_w = s > 1;
+            if (has_w) {
+                const size_t j = ((size_t)jl << lo_bits) | (lo_base + c);
+                w = F::load(tw + (j << (lg - s)) * 8);
+            }
+            F x, y;
+            if (DIF) {
+                x = F::add(a, b);
+                y = F::sub(a, b);
+                if (has_w) y = F::mul(y, w);
+            } else {
+                if (has_w) b = F::mul(b, w);
+                x = F::add(a, b);
+                y = F::sub(a, b);
+            }
+#pragma unroll
+            for (int l = 0; l < 8; ++l) sm[l * TOT + i0] = x.v[l], sm[l * TOT + i1] = y.v[l];
+        }
+        __syncthreads();
+    }
+    for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
+        const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
+        F v;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) v.v[l] = sm[l * TOT + t];
+        if (post) v = F::mul(v, F::load(post + gi * 8));
+        uint4 *p = reinterpret_cast<uint4 *>(data + gi * 8);
+        p[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        p[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+    }
+}
+
+// out[p] = in[bitrev(p)]
+template <class FrC>
+__global__ __launch_bounds__(256) void permute_bitrev_kernel(u32 *__restrict__ out, const u32 *__restrict__ in, unsigned lg) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << lg)) return;
+    const u32 j = lg ? (__brev(i) >> (32 - lg)) : 0;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + (size_t)j * 8);
+    uint4 *q = reinterpret_cast<uint4 *>(out + (size_t)i * 8);
+    q[0] = p[0];
+    q[1] = p[1];
+}
+
 // CSR row dot products: one lane per row (rows of the manta-pay circuits hold <= a handful of terms)
 template <class FrC>
 __global__ __launch_bounds__(256) void spmv_kernel(const u32 *__restrict__ row_ptr, const u32 *__restrict__ col,
@@ -119,6 +205,8 @@ template <class FrC> class FrEngineT : public FrEngine {
         u32 *coset_fwd = nullptr;                 // g^i
         u32 *coset_inv = nullptr;                 // n^-1 * g^-i
         u32 *consts = nullptr;                    // [0] n^-1, [1] (g^n - 1)^-1
+        u32 *t1_br = nullptr;                     // n^-1 * g^bitrev(p)   (between ifft and coset fft)
+        u32 *t2_br = nullptr;                     // n^-1 * g^-bitrev(p)  (after the final coset ifft)
     };
     int two_adicity() const override { return FrC::TWO_ADICITY; }
 
@@ -186,6 +274,19 @@ template <class FrC> class FrEngineT : public FrEngine {
         n_inv.store_words(hc);
         zinv.store_words(hc + 8);
         MG_HIP(hipMemcpy(d.consts, hc, 64, hipMemcpyHostToDevice));
+        // bit-reversed scale tables of the permutation-free witness-map pipeline
+        MG_HIP(hipMalloc((void **)&d.t1_br, n * 32));
+        MG_HIP(hipMalloc((void **)&d.t2_br, n * 32));
+        {
+            u32 *tmp = nullptr;
+            MG_HIP(hipMalloc((void **)&tmp, n * 32));
+            hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, 0, tmp, d_sq + 2 * 33 * 8, (u32)n, bits + 1,
+                               (const u32 *)(d_sq + 4 * 33 * 8)); // n^-1 * g^i
+            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.t1_br, tmp, log_n);
+            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.t2_br, d.coset_inv, log_n);
+            MG_HIP(hipDeviceSynchronize());
+            hipFree(tmp);
+        }
         MG_HIP(hipDeviceSynchronize());
         hipFree(d_sq);
         auto ins = domains_.emplace(log_n, d);
@@ -193,25 +294,65 @@ template <class FrC> class FrEngineT : public FrEngine {
         return MG_OK;
     }
 
+    // all stages of one transform over up to 3 vectors as LDS-fused passes of <= 10 stages
+    template <bool DIF>
+    static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw, unsigned lg, const u32 *post, hipStream_t s) {
+        if (lg == 0) return;
+        const unsigned npass = (lg + 9) / 10;
+        unsigned done = 0;
+        for (unsigned p = 0; p < npass; ++p) {
+            const unsigned ns = (lg - done + (npass - p) - 1) / (npass - p); // balanced split
+            // DIT walks the stages upwards, DIF downwards
+            const unsigned s0 = DIF ? (lg - done - ns + 1) : (done + 1);
+            const unsigned lo_bits = s0 - 1;
+            unsigned cb = ns >= 11 ? 0 : 11 - ns; // tile <= 2048 elements = 64 KB of LDS
+            if (cb > lo_bits) cb = lo_bits;
+            if (cb > 3) cb = 3;
+            const u32 blocks = (u32)(((size_t)1 << lg) >> (ns + cb));
+            const size_t lds = ((size_t)32 << (ns + cb));
+            const bool last = p + 1 == npass;
+            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec), dim3(256), lds, s, d0, d1, d2, tw, lg, s0,
+                               ns, cb, last ? post : (const u32 *)nullptr);
+            done += ns;
+        }
+    }
+
     int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) override {
         Domain *d;
         int rc = get_domain(log_n, &d);
         if (rc) return rc;
         const u32 n = 1u << log_n;
-        const u32 gn = (n + 255) / 256, gh = (n / 2 + 255) / 256;
+        const u32 gn = (n + 255) / 256;
         if (!inverse && coset) hipLaunchKernelGGL((scale_table_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->coset_fwd, n);
         if (log_n > 0) {
             hipLaunchKernelGGL((bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, log_n);
-            const u32 *tw = inverse ? d->tw_inv : d->tw_fwd;
-            for (unsigned st = 1; st <= log_n; ++st)
-                hipLaunchKernelGGL((ntt_stage_kernel<FrC>), dim3(gh ? gh : 1), dim3(256), 0, s, d_data, tw, log_n, st);
+            const u32 *post = inverse ? (coset ? d->coset_inv : nullptr) : nullptr;
+            run_passes<false>(d_data, d_data, d_data, 1, inverse ? d->tw_inv : d->tw_fwd, log_n, post, s);
+            if (inverse && !coset) hipLaunchKernelGGL((scale_const_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->consts, n);
+        } else if (inverse && coset) {
+            hipLaunchKernelGGL((scale_table_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->coset_inv, n);
         }
-        if (inverse) {
-            if (coset)
-                hipLaunchKernelGGL((scale_table_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->coset_inv, n);
-            else
-                hipLaunchKernelGGL((scale_const_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->consts, n);
+        MG_HIP(hipGetLastError());
+        return MG_OK;
+    }
+    // QAP quotient in place: a, b, c hold the constraint evaluations; on return a holds the coefficients
+    // of h = (A B - C)/Z in BIT-REVERSED order (the h-query bases are stored in the same order).
+    // ifft = DIF (natural -> bit-reversed) with n^-1 g^i folded into its last pass, coset fft = DIT
+    // (bit-reversed -> natural): no permutation pass, 2 x ceil(lg/10) launches per transform, a/b/c batched.
+    int qap_quotient(u32 *a, u32 *b, u32 *c, unsigned lg, hipStream_t s) override {
+        Domain *d;
+        int rc = get_domain(lg, &d);
+        if (rc) return rc;
+        const u32 n = 1u << lg;
+        if (lg == 0) { // degenerate domain: h = (a b - c) / (g - 1) scaled as the general path would
+            hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1), dim3(256), 0, s, a, b, c, d->consts + 8, n);
+            MG_HIP(hipGetLastError());
+            return MG_OK;
         }
+        run_passes<true>(a, b, c, 3, d->tw_inv, lg, d->t1_br, s);
+        run_passes<false>(a, b, c, 3, d->tw_fwd, lg, nullptr, s);
+        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, d->consts + 8, n);
+        run_passes<true>(a, a, a, 1, d->tw_inv, lg, d->t2_br, s);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }

@@ -259,6 +259,21 @@ template <class F> struct HPoint {
         }
         return acc;
     }
+    // [k1]p + [k2]q with one shared doubling chain (Shamir's trick)
+    static HPoint mul2(const HPoint &p, const u64 *k1, const HPoint &q, const u64 *k2, int nl) {
+        const HPoint pq = add(p, q);
+        HPoint acc = inf();
+        bool started = false;
+        for (int i = 64 * nl - 1; i >= 0; --i) {
+            const int b1 = (int)((k1[i >> 6] >> (i & 63)) & 1), b2 = (int)((k2[i >> 6] >> (i & 63)) & 1);
+            if (started) acc = dbl(acc);
+            if (b1 | b2) {
+                acc = add(acc, b1 && b2 ? pq : (b1 ? p : q));
+                started = true;
+            }
+        }
+        return acc;
+    }
     static HPoint mul_pow2(HPoint p, unsigned k) { // 2^k * p
         for (unsigned i = 0; i < k; ++i) p = dbl(p);
         return p;
@@ -297,6 +312,28 @@ template <class F> struct HPoint {
         } else {
             ay.write_canonical(out + xb);
         }
+    }
+};
+
+// Fixed-base multiplication table: T[w][d-1] = d * 16^w * B for 64 nibble windows. [k]B = 64 additions,
+// no doublings -- used for the blinding terms r*delta, s*delta, rs*delta of every proof.
+template <class HP> struct FixedBaseTable {
+    HP t[64][15];
+    void build(const HP &base) {
+        HP cur = base;
+        for (int w = 0; w < 64; ++w) {
+            t[w][0] = cur;
+            for (int d = 2; d <= 15; ++d) t[w][d - 1] = HP::add(t[w][d - 2], cur);
+            cur = HP::add(t[w][14], cur); // 16 * cur
+        }
+    }
+    HP mul(const u64 *k4) const {
+        HP acc = HP::inf();
+        for (int w = 0; w < 64; ++w) {
+            const unsigned d = (unsigned)((k4[w >> 4] >> ((w & 15) * 4)) & 15);
+            if (d) acc = HP::add(acc, t[w][d - 1]);
+        }
+        return acc;
     }
 };
 

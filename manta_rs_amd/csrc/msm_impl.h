@@ -423,6 +423,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     void hp_add(HostPoint *a, const HostPoint *o) const override { hp(a) = HP::add(hp(a), hp(o)); }
     void hp_neg(HostPoint *p) const override { hp(p) = hp(p).neg(); }
     void hp_mul(HostPoint *p, const u64 *k4) const override { hp(p) = HP::mul(hp(p), k4, 4); }
+    void hp_mul2(const HostPoint *p, const u64 *k1, const HostPoint *q, const u64 *k2, HostPoint *out) const override {
+        hp(out) = HP::mul2(hp(p), k1, hp(q), k2, 4);
+    }
+    void *hp_table_create(const HostPoint *base) const override {
+        auto *t = new host::FixedBaseTable<HP>();
+        t->build(hp(base));
+        return t;
+    }
+    void hp_table_mul(const void *table, const u64 *k4, HostPoint *out) const override {
+        hp(out) = static_cast<const host::FixedBaseTable<HP> *>(table)->mul(k4);
+    }
+    void hp_table_free(void *table) const override { delete static_cast<host::FixedBaseTable<HP> *>(table); }
     void hp_to_affine(const HostPoint *p, u32 *w) const override { hp(p).to_affine_words(w); }
     void hp_serialize(const HostPoint *p, unsigned char *out, bool compressed) const override {
         hp(p).serialize(out, compressed);

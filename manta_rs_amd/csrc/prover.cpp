@@ -55,16 +55,22 @@ class ProverImpl : public Prover {
     bool have_r1cs_ = false;
     BaseSet *a_bs_ = nullptr, *b1_bs_ = nullptr, *b2_bs_ = nullptr, *h_bs_ = nullptr, *l_bs_ = nullptr;
     HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
+    HostPoint a0_alpha_, b10_beta_, b20_beta_; // constant terms of g_a, g1_b, g2_b folded once
+    void *delta1_tab_ = nullptr, *delta2_tab_ = nullptr; // fixed-base tables for r*delta, s*delta, rs*delta
     DevCsr A_, B_, C_;
+    std::vector<u32> h_query_host_; // kept until the domain size is known (set_r1cs), then re-laid
     std::mutex mu_;
     std::vector<ProveWs *> ws_free_;
 
     ~ProverImpl() override {
+        // (h_bs_ is created by set_r1cs)
         if (a_bs_) g1_->bases_destroy(a_bs_);
         if (b1_bs_) g1_->bases_destroy(b1_bs_);
         if (h_bs_) g1_->bases_destroy(h_bs_);
         if (l_bs_) g1_->bases_destroy(l_bs_);
         if (b2_bs_) g2_->bases_destroy(b2_bs_);
+        if (delta1_tab_) g1_->hp_table_free(delta1_tab_);
+        if (delta2_tab_) g2_->hp_table_free(delta2_tab_);
         free_csr(A_);
         free_csr(B_);
         free_csr(C_);
@@ -110,13 +116,23 @@ class ProverImpl : public Prover {
         g1_->hp_from_affine(&a0_, (const u32 *)pk->a_query);
         g1_->hp_from_affine(&b1_0_, (const u32 *)pk->b_g1_query);
         g2_->hp_from_affine(&b2_0_, (const u32 *)pk->b_g2_query);
+        a0_alpha_ = a0_;
+        g1_->hp_add(&a0_alpha_, &alpha_g1_);
+        b10_beta_ = b1_0_;
+        g1_->hp_add(&b10_beta_, &beta_g1_);
+        b20_beta_ = b2_0_;
+        g2_->hp_add(&b20_beta_, &beta_g2_);
+        delta1_tab_ = g1_->hp_table_create(&delta_g1_);
+        delta2_tab_ = g2_->hp_table_create(&delta_g2_);
         int rc;
         const int c_z = pre_c_for(V_ - 1);
         if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, c_z, &a_bs_))) return rc;
         if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, c_z, &b1_bs_))) return rc;
         if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, c_z, &b2_bs_))) return rc;
         if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, pre_c_for(V_ - P_), &l_bs_))) return rc;
-        if ((rc = g1_->bases_create((const u32 *)pk->h_query, h_len_, false, pre_c_for(h_len_), &h_bs_))) return rc;
+        // h_query is stored in the bit-reversed order the witness map leaves h in; that order depends on
+        // the domain size, known once the R1CS arrives (set_r1cs)
+        h_query_host_.assign((const u32 *)pk->h_query, (const u32 *)pk->h_query + (size_t)h_len_ * w1);
         return MG_OK;
     }
 
@@ -147,6 +163,18 @@ class ProverImpl : public Prover {
         int rc;
         if ((rc = upload_csr(a, m, V_, A_)) || (rc = upload_csr(b, m, V_, B_)) || (rc = upload_csr(c, m, V_, C_)))
             return rc;
+        if (!h_bs_ || lg != log_d_) { // (re)build the h-query base set for this domain
+            const size_t D = (size_t)1 << lg, w1 = (size_t)g1_->affine_words();
+            std::vector<u32> perm(D * w1, 0u); // entries beyond len(h_query) stay infinity: h[D-1] = 0 anyway
+            for (size_t p = 0; p < D; ++p) {
+                size_t src = 0;
+                for (unsigned b = 0; b < lg; ++b) src |= ((p >> b) & 1) << (lg - 1 - b);
+                if (src < h_len_) std::memcpy(&perm[p * w1], &h_query_host_[src * w1], w1 * 4);
+            }
+            if (h_bs_) g1_->bases_destroy(h_bs_);
+            h_bs_ = nullptr;
+            if ((rc = g1_->bases_create(perm.data(), D, false, pre_c_for(D), &h_bs_))) return rc;
+        }
         m_ = m;
         log_d_ = lg;
         have_r1cs_ = true;
@@ -195,11 +223,8 @@ class ProverImpl : public Prover {
             return rc;
         // input-consistency rows: a[m + j] = z_j for j < P (mpc.rs:299-312)
         MG_HIP(hipMemcpyAsync(a + (size_t)m_ * 8, zz, P_ * 32, hipMemcpyDeviceToDevice, s));
-        if ((rc = fr_->transform(a, log_d_, true, false, s)) || (rc = fr_->transform(b, log_d_, true, false, s)) ||
-            (rc = fr_->transform(a, log_d_, false, true, s)) || (rc = fr_->transform(b, log_d_, false, true, s)) ||
-            (rc = fr_->transform(c, log_d_, true, false, s)) || (rc = fr_->transform(c, log_d_, false, true, s)) ||
-            (rc = fr_->qap_pointwise(a, b, c, log_d_, s)) || (rc = fr_->transform(a, log_d_, true, true, s)))
-            return rc;
+        // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
+        if ((rc = fr_->qap_quotient(a, b, c, log_d_, s))) return rc;
         MG_HIP(hipEventRecord(w->h_ready, s));
         return MG_OK;
     }
@@ -210,11 +235,19 @@ class ProverImpl : public Prover {
         if (!w) return MG_ERR_HIP;
         int rc = launch_witness_map(w, z);
         if (!rc) {
-            hipError_t e = hipMemcpyAsync(h_out, w->a.p, ((size_t)1 << log_d_) * 32, hipMemcpyDeviceToHost, w->stream);
+            const size_t D = (size_t)1 << log_d_;
+            std::vector<uint64_t> tmp(D * 4);
+            hipError_t e = hipMemcpyAsync(tmp.data(), w->a.p, D * 32, hipMemcpyDeviceToHost, w->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
             if (e != hipSuccess) {
                 set_last_hip_error(e, "witness_map_host", __FILE__, __LINE__);
                 rc = MG_ERR_HIP;
+            } else { // the device keeps h bit-reversed; the API returns natural order like witness_map
+                for (size_t p = 0; p < D; ++p) {
+                    size_t src = 0;
+                    for (unsigned b = 0; b < log_d_; ++b) src |= ((p >> b) & 1) << (log_d_ - 1 - b);
+                    std::memcpy(h_out + src * 4, &tmp[p * 4], 32);
+                }
             }
         } else {
             hipStreamSynchronize(w->stream);
@@ -258,8 +291,23 @@ class ProverImpl : public Prover {
         }
         if (!rc) {
             hipStreamWaitEvent(mw[4]->stream, w->h_ready, 0);
-            const size_t hl = h_len_ < D ? h_len_ : D; // multi_scalar_mul zips to the shorter
-            rc = g1_->msm_launch(h_bs_, w->a.as<u32>(), hl, true, 0, mw[4]);
+            // h and the h-query bases are both in bit-reversed order; bases beyond len(h_query) are infinity
+            // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
+            rc = g1_->msm_launch(h_bs_, w->a.as<u32>(), D, true, 0, mw[4]);
+        }
+        // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
+        // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2 are fixed-base (64 table additions each)
+        u64 rc4[4], sc4[4], rs_m[4], rs4[4];
+        HostPoint t_rd, t_sd, t_rsd, t_sd2;
+        if (!rc) {
+            fr_->fr_to_canonical(r, rc4);
+            fr_->fr_to_canonical(s, sc4);
+            fr_->fr_mul(r, s, rs_m);
+            fr_->fr_to_canonical(rs_m, rs4);
+            g1_->hp_table_mul(delta1_tab_, rc4, &t_rd);
+            g1_->hp_table_mul(delta1_tab_, sc4, &t_sd);
+            g1_->hp_table_mul(delta1_tab_, rs4, &t_rsd);
+            g2_->hp_table_mul(delta2_tab_, sc4, &t_sd2);
         }
         HostPoint res[5];
         for (int i = 0; i < 5; ++i) {
@@ -277,42 +325,23 @@ class ProverImpl : public Prover {
         if (rc) return rc;
 
         // ---- serial assembly on the host
-        u64 rc4[4], sc4[4], rs_m[4], rs4[4];
-        fr_->fr_to_canonical(r, rc4);
-        fr_->fr_to_canonical(s, sc4);
-        fr_->fr_mul(r, s, rs_m);
-        fr_->fr_to_canonical(rs_m, rs4);
-        HostPoint g_a = res[0], t;
-        g1_->hp_add(&g_a, &a0_);
-        t = delta_g1_;
-        g1_->hp_mul(&t, rc4);
-        g1_->hp_add(&g_a, &t);
-        g1_->hp_add(&g_a, &alpha_g1_);
+        HostPoint g_a = res[0];
+        g1_->hp_add(&g_a, &a0_alpha_);
+        g1_->hp_add(&g_a, &t_rd);
         HostPoint g1_b;
         g1_->hp_set_inf(&g1_b);
         if (!r_zero) {
             g1_b = res[1];
-            g1_->hp_add(&g1_b, &b1_0_);
-            t = delta_g1_;
-            g1_->hp_mul(&t, sc4);
-            g1_->hp_add(&g1_b, &t);
-            g1_->hp_add(&g1_b, &beta_g1_);
+            g1_->hp_add(&g1_b, &b10_beta_);
+            g1_->hp_add(&g1_b, &t_sd);
         }
         HostPoint g2_b = res[2];
-        g2_->hp_add(&g2_b, &b2_0_);
-        t = delta_g2_;
-        g2_->hp_mul(&t, sc4);
-        g2_->hp_add(&g2_b, &t);
-        g2_->hp_add(&g2_b, &beta_g2_);
-        HostPoint g_c = g_a;
-        g1_->hp_mul(&g_c, sc4);
-        t = g1_b;
-        g1_->hp_mul(&t, rc4);
-        g1_->hp_add(&g_c, &t);
-        t = delta_g1_;
-        g1_->hp_mul(&t, rs4);
-        g1_->hp_neg(&t);
-        g1_->hp_add(&g_c, &t);
+        g2_->hp_add(&g2_b, &b20_beta_);
+        g2_->hp_add(&g2_b, &t_sd2);
+        HostPoint g_c;
+        g1_->hp_mul2(&g_a, sc4, &g1_b, rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
+        g1_->hp_neg(&t_rsd);
+        g1_->hp_add(&g_c, &t_rsd);
         g1_->hp_add(&g_c, &res[3]);
         g1_->hp_add(&g_c, &res[4]);
         const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);

@@ -20,6 +20,9 @@ class FrEngine {
     virtual int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) = 0;
     // out[i] = sum_k val[k] * z[col[k]] over row i, i < m
     virtual int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s) = 0;
+    // a, b, c = constraint evaluations over the domain -> a = coefficients of h = (AB - C)/Z in
+    // bit-reversed order (ifft, coset fft x3, pointwise, coset ifft; fused, permutation-free)
+    virtual int qap_quotient(u32 *d_a, u32 *d_b, u32 *d_c, unsigned log_n, hipStream_t s) = 0;
     // a[i] = (a[i]*b[i] - c[i]) * (g^D - 1)^-1
     virtual int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) = 0;
     // host-side Fr helpers (Montgomery in/out unless noted)
