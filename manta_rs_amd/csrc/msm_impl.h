@@ -230,7 +230,13 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
     const u32 idx = tile * 64 + lane;
     XYZZ<F> acc = XYZZ<F>::inf();
     if (idx < n_items) acc = XYZZ<F>::load(in + ((size_t)seg * seg_stride + item_off + idx) * XYZZ<F>::WORDS);
-    for (int d = 1; d < 64; d <<= 1) { // suffix scan
+    int top = 1; // lanes actually populated in this tile, rounded up to a power of two
+    {
+        const u32 left = n_items - tile * 64;
+        const int lim = left < 64 ? (int)left : 64;
+        while (top < lim) top <<= 1;
+    }
+    for (int d = 1; d < top; d <<= 1) { // suffix scan
         const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
         if (lane + d < 64) acc.add(o);
     }
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
             acc.store(outA + (size_t)wave * XYZZ<F>::WORDS);
     }
     if (outS) {
-        for (int d = 32; d >= 1; d >>= 1) { // tree sum of the suffix sums
+        for (int d = top >> 1; d >= 1; d >>= 1) { // tree sum of the suffix sums
             const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
             if (lane < d) acc.add(o);
         }
@@ -253,6 +259,38 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
                 acc.store(outS + (size_t)wave * XYZZ<F>::WORDS);
         }
     }
+}
+
+// Second (last) reduce level for 2 <= T0 <= 64 tiles per window, ONE launch, two wavefronts per window on
+// different SIMDs: wave 0 turns the tile totals A_t into X = sum_{t>=1} t*A_t (suffix scan + tree sum, only
+// ceil(log2 T0) steps each), wave 1 sums the S_t. The host gets (X, sumS): window sum = sumS + 64*X.
+// Together with the level-0 tile_reduce that is 12 + 2*log2(T0) dependent additions (20 for B = 1024)
+// instead of 36 over three launches -- on a latency-bound tail the depth is what matters.
+template <class F>
+__global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
+                                                     u32 *__restrict__ out_std) {
+    constexpr int XW = XYZZ<F>::WORDS;
+    constexpr int SW = XYZZ<typename F::Std>::WORDS;
+    const u32 seg = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int top = 1;
+    while (top < (int)T0) top <<= 1;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (wave == 0) { // X = sum_{t>=1} t*A_t  =  sum_{j>=1} (sum_{t>=j} A_t)
+        if (lane >= 1 && lane < (int)T0) acc = XYZZ<F>::load(A0 + ((size_t)seg * T0 + lane) * XW);
+        for (int d = 1; d < top; d <<= 1) {
+            const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+            if (lane + d < 64) acc.add(o);
+        }
+        if (lane == 0) acc = XYZZ<F>::inf(); // lane 0's suffix (the total) carries weight 0
+    } else {
+        if (lane < (int)T0) acc = XYZZ<F>::load(S0 + ((size_t)seg * T0 + lane) * XW);
+    }
+    for (int d = top >> 1; d >= 1; d >>= 1) {
+        const XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+        if (lane < d) acc.add(o);
+    }
+    if (lane == 0) acc.store_std(out_std + ((size_t)seg * 2 + wave) * SW);
 }
 
 // arkworks-format affine bases -> internal representation (identity copy when the two coincide)
@@ -598,19 +636,33 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // ---- bucket reduce
         const u32 segs = (u32)pl.Wb;
         const u32 T0 = cdiv(pl.B, 64);
-        constexpr int XWM = XW > XW_IO ? XW : XW_IO;
-        if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
-            return rc;
-        hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                           pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), T0 == 1 ? 1 : 0);
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
-        if (T0 == 1) {
-            // window sum = S0[seg]
+        constexpr int XWM = XW > XW_IO ? XW : XW_IO;
+        if (T0 == 1) { // a single tile per window: its S is the window sum
+            if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                               pl.B, 0u, pl.B, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             stage_pts = segs;
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+        } else if (T0 <= 64) { // two launches: tiles, then (X, sumS) per window
+            if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
+                (rc = ws->misc.reserve((size_t)segs * 2 * XW_IO * 4)))
+                return rc;
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                               pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
+            hipLaunchKernelGGL((reduce_level1<F>), dim3(segs), dim3(128), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(), T0,
+                               ws->misc.as<u32>());
+            stage_pts = (size_t)segs * 2;
+            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            T1 = 0xffffffffu; // marks the (X, sumS) layout for msm_finish
         } else {
+            if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
+                return rc;
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                               pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
             T1 = cdiv(T0 - 1, 64); // level 1 over A0[1..T0-1]
             nP = cdiv(T0, 64);     // plain sums of S0[0..T0-1]
             if ((rc = ws->misc.reserve((size_t)segs * (2 * T1 + nP) * XW_IO * 4))) return rc;
@@ -660,7 +712,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         HP total = HP::inf();
         for (int w = (int)segs - 1; w >= 0; --w) {
             HP win;
-            if (T1 == 0) {
+            if (T1 == 0xffffffffu) { // fused reduce: (X, sumS) per window, window = sumS + 64 X
+                const HP X = HP::from_xyzz_words(st + ((size_t)w * 2 + 0) * XW_IO);
+                const HP sumS = HP::from_xyzz_words(st + ((size_t)w * 2 + 1) * XW_IO);
+                win = HP::add(sumS, HP::mul_pow2(X, 6));
+            } else if (T1 == 0) { // one tile per window: the staged point is the window sum
                 win = HP::from_xyzz_words(st + (size_t)w * XW_IO);
             } else {
                 const u32 *A1 = st + ((size_t)w * T1) * XW_IO;
