@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 LOG_N = 20
 CURVE = 1  # BLS12-381
 WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
+DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
 ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -62,10 +63,15 @@ def main():
     import torch.distributed as dist
     from manta_rs_amd import api, synth
 
-    torch.cuda.set_device(local_rank)
-    api.init(local_rank)
+    dev = _device_index(local_rank)
+    backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")  # "gloo": single-GPU functional check of the N>1 path
+    torch.cuda.set_device(dev)
+    api.init(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n = 1 << LOG_N
     p = synth.FR_MODULUS[CURVE]
@@ -87,7 +93,9 @@ def main():
     def gather_sum(local_pt):
         if world == 1:
             return local_pt
-        t = torch.from_numpy(local_pt.view(np.int64)).cuda()
+        t = torch.from_numpy(local_pt.view(np.int64))
+        if backend == "nccl":
+            t = t.cuda()
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)  # RCCL over xGMI: 96 B per rank
         pts = torch.stack(outs).cpu().numpy().view(np.uint64)
@@ -101,13 +109,13 @@ def main():
             torch.cuda.synchronize()
 
     def run(steps):
-        """two MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i
+        """DEPTH MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i
         (bucket reduce, host fold, partial-point exchange) overlaps the accumulate kernel of step i+1."""
         res = None
         pending = []
         for _ in range(steps):
             pending.append(api.VariableBaseMSM.launch(bases, d_sc, n))
-            if len(pending) == 2:
+            if len(pending) == DEPTH:
                 res = gather_sum(pending.pop(0).finish())
         while pending:
             res = gather_sum(pending.pop(0).finish())
@@ -132,7 +140,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -154,7 +162,7 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": "accumulate_chunks<Fp<Bls381Fq>>", "achieved": round(achieved, 2),
+        roofline = {"bound": "hbm", "kernel": "accumulate_chunks<FpR<Bls381Fq>>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                     "traffic": traffic, "kernel_ms": round(k_ms, 4),
                     "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SCALAR,
@@ -187,6 +195,12 @@ def main():
         dist.destroy_process_group()
 
 
+def _device_index(local_rank):
+    """LOCAL_RANK, unless MANTA_BENCH_DEVICE pins every rank to one device (functional test of the
+    multi-process path on a 1-GPU box)."""
+    return int(os.environ.get("MANTA_BENCH_DEVICE", local_rank))
+
+
 def prove_main(args):
     """Whole proofs of a shape-exact synthetic manta-pay circuit (BN254, the curve manta-pay uses).
     A step = one `Groth16::prove` call: H2D of z, witness map (3 SpMV, 7 NTT), 5 MSMs, host assembly, 128 proof
@@ -200,10 +214,15 @@ def prove_main(args):
     import torch
     import torch.distributed as dist
     from manta_rs_amd import api, synth, keygen
-    torch.cuda.set_device(local_rank)
-    api.init(local_rank)
+    dev = _device_index(local_rank)
+    backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev)
+    api.init(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     curve = synth.BN254
     p = synth.FR_MODULUS[curve]
     t0 = time.perf_counter()
@@ -257,7 +276,7 @@ def prove_main(args):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert proofs[0] == first

@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ sca
 template <class F>
 __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
-                                                         u32 *__restrict__ buckets, u32 *__restrict__ pkeys,
-                                                         u32 *__restrict__ ppts, u32 T) {
+                                                         u32 astride, u32 *__restrict__ buckets,
+                                                         u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const size_t begin = (size_t)t * L;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
 #ifdef MG_ACC_PREFETCH
     // software pipeline: the gather of entry j+1 is in flight while entry j is being added
     u32 v_next = vals[begin];
-    Affine<F> p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * Affine<F>::WORDS);
+    Affine<F> p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * astride);
 #endif
     for (size_t j = begin; j < end; ++j) {
         const u32 k = keys[j];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
         const Affine<F> p = p_next;
         if (j + 1 < end) {
             v_next = vals[j + 1];
-            p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * Affine<F>::WORDS);
+            p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * astride);
         }
 #endif
         if (k != cur) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
         }
 #ifndef MG_ACC_PREFETCH
         const u32 v = vals[j];
-        const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * Affine<F>::WORDS);
+        const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * astride);
 #endif
         acc.madd(p, (v >> 31) != 0);
     }
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0,
 
 // arkworks-format affine bases -> internal representation (identity copy when the two coincide)
 template <class F>
-__global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out) {
+__global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out,
+                                                         u32 astride) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     typedef typename F::Std S;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__
         r.x = F::from_std(a.x);
         r.y = F::from_std(a.y);
     }
-    r.store(out + i * Affine<F>::WORDS);
+    r.store(out + i * astride);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -316,11 +317,11 @@ __global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__
 // batched conversion to affine with Montgomery's trick (one Fermat inversion per KB points).
 // --------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void precompute_chain(const u32 *__restrict__ base, u32 n, int c, int W,
+__global__ __launch_bounds__(256) void precompute_chain(const u32 *__restrict__ base, u32 astride, u32 n, int c, int W,
                                                         u32 *__restrict__ xyzz_out /* (W-1)*n */) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    XYZZ<F> p = XYZZ<F>::from_affine(Affine<F>::load(base + (size_t)i * Affine<F>::WORDS));
+    XYZZ<F> p = XYZZ<F>::from_affine(Affine<F>::load(base + (size_t)i * astride));
     for (int w = 1; w < W; ++w) {
         for (int k = 0; k < c; ++k) p = XYZZ<F>::dbl(p);
         p.store(xyzz_out + ((size_t)(w - 1) * n + i) * XYZZ<F>::WORDS);
@@ -345,7 +346,7 @@ template <class C> struct FieldInv<Fp2<C>> {
 };
 template <class F, int KB>
 __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restrict__ xyzz, size_t n,
-                                                            u32 *__restrict__ aff) {
+                                                            u32 *__restrict__ aff, u32 astride) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = t * KB;
     if (b0 >= n) return;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
         const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
         F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
         F d = zz.is_zero_exact() ? F::one() : F::mul(zz, zzz);
-        run.store(aff + (b0 + k) * Affine<F>::WORDS); // prefix before k
+        run.store(aff + (b0 + k) * astride); // prefix before k
         run = F::mul(run, d);
     }
     F inv = FieldInv<F>::inv(run);
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
     if (b0 + KB > n) last = (int)(n - b0) - 1;
     for (int k = last; k >= 0; --k) {
         const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
-        u32 *dst = aff + (b0 + k) * Affine<F>::WORDS;
+        u32 *dst = aff + (b0 + k) * astride;
         F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
         if (zz.is_zero_exact()) {
             F::zero().store(dst);
@@ -445,6 +446,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     static constexpr int AW = Affine<F>::WORDS, XW = XYZZ<F>::WORDS;           // internal formats
     static constexpr int AW_IO = Affine<FIO>::WORDS, XW_IO = XYZZ<FIO>::WORDS; // arkworks formats (ABI, staging)
     static constexpr bool SAME = std::is_same<F, FIO>::value;
+    // stride of one point in a BaseSet: the internal affine record padded to a multiple of 32 B (BLS12-381
+    // G1: 28 -> 32 words = one 128 B line per gathered point instead of a record straddling two)
+    static constexpr int AWS = SAME ? AW : (AW + 7) / 8 * 8;
     static_assert(sizeof(HP) <= sizeof(HostPoint), "HostPoint too small");
 
     int curve() const override { return CURVE_ID; }
@@ -491,7 +495,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             bs->pre_c = pre_c;
             bs->pre_W = W;
         }
-        bs->bytes = (size_t)W * n * AW * 4;
+        bs->bytes = (size_t)W * n * AWS * 4;
         hipError_t e = hipMalloc((void **)&bs->d_pts, bs->bytes);
         if (e != hipSuccess) {
             delete bs;
@@ -510,7 +514,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 src = stage;
             }
             if (e == hipSuccess) {
-                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, bs->d_pts);
+                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, bs->d_pts, (u32)AWS);
                 e = hipDeviceSynchronize();
             }
             if (stage) hipFree(stage);
@@ -529,11 +533,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 set_last_hip_error(e, "hipMalloc(precompute tmp)", __FILE__, __LINE__);
                 return MG_ERR_OOM;
             }
-            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, bs->d_pts, (u32)n, pre_c,
-                               W, tmp);
+            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, bs->d_pts, (u32)AWS, (u32)n,
+                               pre_c, W, tmp);
             constexpr int KB = 16;
             hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(cnt, KB), 256)), dim3(256), 0, 0, tmp,
-                               cnt, bs->d_pts + n * AW);
+                               cnt, bs->d_pts + n * AWS, (u32)AWS);
             e = hipDeviceSynchronize();
             hipFree(tmp);
             if (e != hipSuccess) {
@@ -618,7 +622,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         ws->timed = kernel_timing();
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
-                           ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, ws->buckets.as<u32>(),
+                           ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                            ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * T;
@@ -758,7 +762,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipLaunchKernelGGL((fixed_base_mul_kernel<FIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
         constexpr int KB = 16;
         hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, s, tmp, n,
-                           d_out_affine);
+                           d_out_affine, (u32)AW_IO);
         e = hipStreamSynchronize(s);
         hipFree(d_base);
         hipFree(tmp);
