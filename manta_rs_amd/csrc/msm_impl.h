@@ -572,11 +572,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             p.Wb = p.W;
         }
         p.B = 1u << (p.c - 1);
-        // entries per lane: aim at >= ~128k lanes of work, 8 <= L <= 64
+        // entries per lane: one full round of lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131k) when the MSM is
+        // large, never fewer than 8 per lane; longer chunks mean fewer partials for the merge levels
+        // (measured at 2^20: L = 64 / 128 / 192 / 256 -> 295 / 312 / 316 / 301 Mscalar/s)
         const size_t M = n * (size_t)p.W;
-        size_t L = M / (128 * 1024);
+        size_t L = M / (96 * 1024);
         if (L < 8) L = 8;
-        if (L > 64) L = 64;
+        if (L > 192) L = 192;
         if (const char *e = getenv("MANTA_MSM_L")) L = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : L;
         p.L = (u32)L;
         return p;

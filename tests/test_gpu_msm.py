@@ -96,3 +96,37 @@ def test_msm_medium_closed_form(gpu, curve):
         dsc = gpu.DeviceBuffer.from_numpy(sc)
         got = gpu.VariableBaseMSM.launch(b, dsc, n).finish()
         assert (got == want).all(), pre
+
+
+@pytest.mark.parametrize("curve,pre", [(1, 16), (0, 16), (1, 0)])
+def test_msm_full_size_2_20_closed_form(gpu, curve, pre):
+    """BASELINE size (n = 2^20), property check that needs no O(n) oracle run: bases P_i = [s0 + i s1]G built
+    by the library's fixed-base batch multiply, so sum k_i P_i = [sum k_i (s0 + i s1) mod r] G. Run for uniform
+    and witness-like scalars; also linearity: MSM(k) + MSM(k') = MSM(k + k')."""
+    n = 1 << 20
+    p = synth.FR_MODULUS[curve]
+    s0, s1 = 0x1234567, 0x89abcdef1
+    kb = np.zeros((n, 4), dtype=np.uint64)
+    idx = np.arange(n, dtype=np.uint64)
+    kb[:, 0] = np.uint64(s0) + idx * np.uint64(s1)          # < 2^64 for n = 2^20: no reduction needed
+    G = O.generator(curve, 1)
+    dpts = gpu.fixed_base_mul(curve, 1, G, gpu.DeviceBuffer.from_numpy(kb), n)
+    b = gpu.Bases(curve, 1, (dpts.ptr, n), precompute_window_bits=pre, on_device=True)
+    base_k = [s0 + i * s1 for i in range(n)]
+
+    def expect(sc):
+        t = sum(k * bk for k, bk in zip(synth.limbs_to_ints(sc), base_k)) % p
+        return O.g_mul(curve, 1, G, synth.ints_to_limbs([t], 4)[0])
+
+    res = {}
+    for dist in ("U", "W"):
+        sc = synth.msm_scalars(curve, n, dist, seed=33)
+        got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(sc), n).finish()
+        assert (got == expect(sc)).all(), dist
+        res[dist] = (sc, got)
+    # linearity: scalars U + W (mod r) -- sum of the two results
+    su = synth.limbs_to_ints(res["U"][0])
+    sw = synth.limbs_to_ints(res["W"][0])
+    ssum = synth.ints_to_limbs([(a + c) % p for a, c in zip(su, sw)], 4)
+    got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(ssum), n).finish()
+    assert (got == O.g_add(curve, 1, res["U"][1], res["W"][1])).all()

@@ -79,3 +79,54 @@ def test_prove_real_shape_to_private(gpu):
     proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
     assert proof == O.groth16_prove(c, pk, rs[0], rs[1])
     assert O.groth16_verify(0, pk, c.z[1:c.P], proof) == 1
+
+
+def test_prove_real_shape_private_transfer(gpu):
+    """Shape-exact PrivateTransfer circuit (D=2^16, V=35175, P=27): bit-exact vs the oracle, pairing-verified,
+    and -- like manta-pay/src/test/transfer.rs:346-417 -- a fuzzed public input must invalidate the proof."""
+    from manta_rs_amd import keygen
+    c = synth.make_shape(0, "private_transfer")
+    assert (c.D, c.V, c.P) == (1 << 16, 35175, 27)
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=8), synth.FR_MODULUS[0]))
+    ctx = gpu.ProvingContext(0, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(0, 2, seed=321)
+    proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    assert proof == O.groth16_prove(c, pk, rs[0], rs[1])
+    assert O.groth16_verify(0, pk, c.z[1:c.P], proof) == 1
+    bad = c.z[1:c.P].copy()
+    bad[3] = rs[0]
+    assert O.groth16_verify(0, pk, bad, proof) == 0
+    # concurrent proofs on one context (the reference's signer shares a ProvingContext across threads)
+    import threading
+    outs = [None] * 8
+
+    def work(i):
+        outs[i] = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(o == proof for o in outs)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ntt_full_size_roundtrip_and_linearity(gpu, curve):
+    """2^20 (BASELINE size): ifft(fft(x)) = x, coset round trip, linearity fft(x + y) = fft(x) + fft(y); a 2^16
+    slice is also compared with the oracle directly."""
+    n = 1 << 20
+    rs = np.random.RandomState(5)
+    p = synth.FR_MODULUS[curve]
+
+    def rand():
+        a = rs.randint(0, 1 << 62, size=(n, 4), dtype=np.int64).astype(np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)  # < p
+        return a
+    x, y = rand(), rand()
+    dom = gpu.Radix2EvaluationDomain(curve, n)
+    fx = dom.fft(x)
+    assert (dom.ifft(fx) == x).all()
+    assert (dom.coset_ifft(dom.coset_fft(x)) == x).all()
+    fr = "bn254_fr" if curve == 0 else "bls381_fr"
+    assert (O.field_op(fr, "add", fx, dom.fft(y)) == dom.fft(O.field_op(fr, "add", x, y))).all()
+    m = 1 << 16
+    assert (gpu.Radix2EvaluationDomain(curve, m).coset_fft(x[:m]) == O.ntt(curve, x[:m], coset=True)).all()
