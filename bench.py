@@ -49,7 +49,7 @@ def main():
                     help="msm = BASELINE configs[1] (default, the headline line); prove = whole Groth16 proofs of a "
                          "manta-pay circuit shape (configs[0]/[3]/[4] shapes, BN254)")
     ap.add_argument("--shape", default="private_transfer", choices=["to_private", "to_public", "private_transfer"])
-    ap.add_argument("--threads", type=int, default=4, help="prove workload: host threads issuing proofs concurrently")
+    ap.add_argument("--threads", type=int, default=2, help="prove workload: host threads issuing proofs concurrently")
     args = ap.parse_args()
     if args.workload == "prove":
         return prove_main(args)

@@ -101,7 +101,8 @@ class GroupEngine {
     virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
                            MsmWorkspace *ws) = 0;
     // Waits for the stream, folds the staged partial points on the host. out = XYZZ host point.
-    virtual int msm_finish(MsmWorkspace *ws, HostPoint *out) = 0;
+    // already_synced: the caller has synchronised with the work itself (hipGraph replay of a whole proof)
+    virtual int msm_finish(MsmWorkspace *ws, HostPoint *out, bool already_synced = false) = 0;
 
     // host-point helpers (type-erased)
     virtual void hp_set_inf(HostPoint *p) const = 0;

@@ -704,11 +704,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // ---------------------------------------------------------------- finish (host fold)
-    int msm_finish(MsmWorkspace *ws, HostPoint *out) override {
+    int msm_finish(MsmWorkspace *ws, HostPoint *out, bool already_synced = false) override {
         if (!ws || !ws->pending) return MG_ERR_STATE;
-        MG_HIP(hipEventSynchronize(ws->done));
+        if (!already_synced) MG_HIP(hipEventSynchronize(ws->done));
         ws->pending = 0;
-        if (ws->timed) {
+        if (ws->timed && !already_synced) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ws->t0, ws->t1) == hipSuccess) set_last_accumulate_ms(ms);
         }

@@ -13,6 +13,7 @@
 // An unsatisfied witness is not an error (ark-groth16 only debug_asserts it): a non-verifying proof
 // comes back, exactly like the reference in release builds.
 #include "prover.h"
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -30,20 +31,40 @@ FrEngine *get_ntt_engine(int curve) {
 
 namespace {
 
-struct ProveWs { // per-call device scratch for the witness map
+// One in-flight proof: device scratch for the witness map, its five MSM workspaces (each with its own
+// stream), a pinned copy of z, and -- after two eager runs that size every buffer -- a captured hipGraph
+// of the whole GPU side of the proof (~90 launches on 6 streams become one hipGraphLaunch: the prover is
+// launch-bound at manta-pay circuit sizes, and concurrent host threads stop contending on the runtime).
+struct ProveWs {
     DevBuf z, a, b, c;
     hipStream_t stream = nullptr;
     hipEvent_t z_ready = nullptr, h_ready = nullptr;
+    MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GroupEngine *me[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *h_z = nullptr; // pinned staging of the assignment
+    size_t h_z_cap = 0;
+    hipGraphExec_t exec = nullptr;
+    int eager_runs = 0;
+    bool no_graph = false;
     ~ProveWs() {
+        if (exec) hipGraphExecDestroy(exec);
+        for (int i = 0; i < 5; ++i)
+            if (mw[i]) me[i]->ws_release(mw[i]);
         z.release();
         a.release();
         b.release();
         c.release();
+        if (h_z) hipHostFree(h_z);
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
         if (stream) hipStreamDestroy(stream);
     }
 };
+
+static bool graphs_enabled() {
+    static const bool on = std::getenv("MANTA_NO_GRAPH") == nullptr;
+    return on;
+}
 
 class ProverImpl : public Prover {
   public:
@@ -87,10 +108,13 @@ class ProverImpl : public Prover {
     // window bits for precomputed tables, by MSM length (HBM is plentiful: trade table size for fewer
     // buckets to fold and no doubling chain -- tuned on MI355X)
     static int pre_c_for(u64 n) {
-        if (n <= (1u << 10)) return 7;
-        if (n <= (1u << 13)) return 9;
-        if (n <= (1u << 16)) return 11;
-        if (n <= (1u << 18)) return 13;
+        if (const char *e = std::getenv("MANTA_PROVE_C")) // tuning override (window bits of the pk tables)
+            if (std::atoi(e) > 0) return std::atoi(e);
+        // Measured on MI355X for the PrivateTransfer shape (n = 35k / 65k): c = 6..8 -> 2.0 ms per proof,
+        // c = 9..13 -> 2.5-2.7 ms, c = 14 -> 3.0 ms. Few buckets keep the latency-bound bucket reduce short
+        // (B = 128: two tiles); the extra windows only add perfectly parallel mixed additions.
+        if (n <= (1u << 17)) return 8;
+        if (n <= (1u << 19)) return 12;
         return 16;
     }
 
@@ -197,6 +221,15 @@ class ProverImpl : public Prover {
             delete w;
             return nullptr;
         }
+        GroupEngine *me[5] = {g1_, g1_, g2_, g1_, g1_}; // a, b_g1, b_g2, l, h
+        for (int i = 0; i < 5; ++i) {
+            w->me[i] = me[i];
+            w->mw[i] = me[i]->ws_acquire();
+            if (!w->mw[i]) {
+                delete w;
+                return nullptr;
+            }
+        }
         return w;
     }
     void ws_release(ProveWs *w) {
@@ -256,44 +289,83 @@ class ProverImpl : public Prover {
         return rc;
     }
 
+    // enqueue the whole GPU side of one proof: witness map on w->stream, the five MSMs forked onto their own
+    // streams and joined back. Identical in eager mode and under stream capture.
+    int enqueue_proof(ProveWs *w, const uint64_t *z_src) {
+        const size_t D = (size_t)1 << log_d_;
+        int rc = launch_witness_map(w, z_src);
+        if (rc) return rc;
+        const u32 *dz = w->z.as<u32>();
+        const BaseSet *bs[5] = {a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_};
+        const u32 *sc[5] = {dz + 8, dz + 8, dz + 8, dz + (size_t)P_ * 8, w->a.as<u32>()};
+        const size_t cnt[5] = {(size_t)V_ - 1, (size_t)V_ - 1, (size_t)V_ - 1, (size_t)(V_ - P_), D};
+        for (int i = 0; i < 5; ++i) {
+            // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
+            // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
+            MG_HIP(hipStreamWaitEvent(w->mw[i]->stream, i == 4 ? w->h_ready : w->z_ready, 0));
+            if ((rc = w->me[i]->msm_launch(bs[i], sc[i], cnt[i], true, 0, w->mw[i]))) return rc;
+            MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0)); // join
+        }
+        return MG_OK;
+    }
+
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
         if (!have_r1cs_) return MG_ERR_STATE;
         ProveWs *w = ws_acquire();
         if (!w) return MG_ERR_HIP;
-        MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        GroupEngine *me[5] = {g1_, g1_, g2_, g1_, g1_}; // a, b_g1, b_g2, l, h
-        int rc = launch_witness_map(w, z);
-        bool r_zero = (r[0] | r[1] | r[2] | r[3]) == 0;
-        const size_t D = (size_t)1 << log_d_;
-        const u32 *dz = w->z.as<u32>();
-        if (!rc) {
-            for (int i = 0; i < 5 && !rc; ++i) {
-                if (i == 1 && r_zero) continue; // g1_b skipped iff r == 0 (App. B.1)
-                mw[i] = me[i]->ws_acquire();
-                if (!mw[i]) rc = MG_ERR_HIP;
+        const bool r_zero = (r[0] | r[1] | r[2] | r[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
+        int rc = MG_OK;
+        if (w->h_z_cap < V_ * 32) {
+            if (w->h_z) hipHostFree(w->h_z);
+            w->h_z = nullptr;
+            w->h_z_cap = 0;
+            if (hipHostMalloc(&w->h_z, V_ * 32, hipHostMallocDefault) != hipSuccess) {
+                ws_release(w);
+                return MG_ERR_OOM;
+            }
+            w->h_z_cap = V_ * 32;
+        }
+        std::memcpy(w->h_z, z, V_ * 32);
+        bool launched = false;
+        if (w->exec) {
+            hipError_t e = hipGraphLaunch(w->exec, w->stream);
+            if (e == hipSuccess) {
+                for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
+                launched = true;
+            } else {
+                hipGraphExecDestroy(w->exec);
+                w->exec = nullptr;
+                w->no_graph = true;
+            }
+        } else if (graphs_enabled() && !w->no_graph && w->eager_runs >= 2) {
+            // every buffer has its final size: capture this proof's launches and replay them from now on
+            if (hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                int crc = enqueue_proof(w, (const uint64_t *)w->h_z);
+                hipGraph_t graph = nullptr;
+                hipError_t e = hipStreamEndCapture(w->stream, &graph);
+                if (!crc && e == hipSuccess && graph &&
+                    hipGraphInstantiate(&w->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    hipGraphDestroy(graph);
+                    if (hipGraphLaunch(w->exec, w->stream) == hipSuccess) {
+                        for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
+                        launched = true;
+                    }
+                } else {
+                    if (graph) hipGraphDestroy(graph);
+                    w->exec = nullptr;
+                }
+                if (!launched) {
+                    (void)hipGetLastError();
+                    w->no_graph = true;
+                    for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
+                }
+            } else {
+                w->no_graph = true;
             }
         }
-        if (!rc) {
-            hipStreamWaitEvent(mw[0]->stream, w->z_ready, 0);
-            rc = g1_->msm_launch(a_bs_, dz + 8, V_ - 1, true, 0, mw[0]);
-        }
-        if (!rc && mw[1]) {
-            hipStreamWaitEvent(mw[1]->stream, w->z_ready, 0);
-            rc = g1_->msm_launch(b1_bs_, dz + 8, V_ - 1, true, 0, mw[1]);
-        }
-        if (!rc) {
-            hipStreamWaitEvent(mw[2]->stream, w->z_ready, 0);
-            rc = g2_->msm_launch(b2_bs_, dz + 8, V_ - 1, true, 0, mw[2]);
-        }
-        if (!rc) {
-            hipStreamWaitEvent(mw[3]->stream, w->z_ready, 0);
-            rc = g1_->msm_launch(l_bs_, dz + (size_t)P_ * 8, V_ - P_, true, 0, mw[3]);
-        }
-        if (!rc) {
-            hipStreamWaitEvent(mw[4]->stream, w->h_ready, 0);
-            // h and the h-query bases are both in bit-reversed order; bases beyond len(h_query) are infinity
-            // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-            rc = g1_->msm_launch(h_bs_, w->a.as<u32>(), D, true, 0, mw[4]);
+        if (!launched) {
+            rc = enqueue_proof(w, (const uint64_t *)w->h_z);
+            w->eager_runs++;
         }
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
         // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2 are fixed-base (64 table additions each)
@@ -310,17 +382,22 @@ class ProverImpl : public Prover {
             g2_->hp_table_mul(delta2_tab_, sc4, &t_sd2);
         }
         HostPoint res[5];
-        for (int i = 0; i < 5; ++i) {
-            if (!mw[i]) continue;
-            if (mw[i]->pending) {
-                int rc2 = me[i]->msm_finish(mw[i], &res[i]);
-                if (!rc) rc = rc2;
-            } else {
-                hipStreamSynchronize(mw[i]->stream);
+        {
+            hipError_t e = hipStreamSynchronize(w->stream); // every MSM stream has been joined into it
+            if (e != hipSuccess && !rc) {
+                set_last_hip_error(e, "prove: hipStreamSynchronize", __FILE__, __LINE__);
+                rc = MG_ERR_HIP;
             }
-            me[i]->ws_release(mw[i]);
+            for (int i = 0; i < 5; ++i) {
+                if (w->mw[i]->pending) {
+                    int rc2 = w->me[i]->msm_finish(w->mw[i], &res[i], true);
+                    if (!rc) rc = rc2;
+                } else {
+                    hipStreamSynchronize(w->mw[i]->stream);
+                    if (!rc) rc = MG_ERR_STATE;
+                }
+            }
         }
-        hipStreamSynchronize(w->stream);
         ws_release(w);
         if (rc) return rc;
 
