@@ -120,6 +120,10 @@ typedef struct {
 
 /* Uploads and re-lays the proving key once (lifetime = the Rust ProvingContext). */
 int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
+/* Same, from the key's wire format: arkworks 0.3 `ProvingKey::serialize_unchecked` bytes (uncompressed points,
+ * no curve checks) exactly as `ProvingContext::decode` reads them (manta-crypto/src/arkworks/groth16.rs:268-288)
+ * and `generate_parameters` / manta-parameters ship them (data/pay/proving/ *.lfs). */
+int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out);
 /* Once per circuit shape: the matrices of `cs.to_matrices()` (identical for every proof of a shape). */
 int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t num_constraints);
 /* One proof. z = instance || witness (V x 4 u64 Montgomery), r, s = the two blinding scalars drawn by

@@ -54,7 +54,7 @@ EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_point_serialize", "mg_ntt",
-    "mg_ntt_device", "mg_ctx_create", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_witness_map", "mg_ctx_domain_size",
+    "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
 ]
 
@@ -294,6 +294,19 @@ class ProvingContext:
         self._keep = None  # the library copied everything
         self.handle = h
         self._shape = None
+
+    @classmethod
+    def decode(cls, curve, data: bytes):
+        """Mirror of `impl Decode for ProvingContext` (groth16.rs:268-288): arkworks `deserialize_unchecked`
+        bytes of the ProvingKey -- the format of manta-parameters' proving-key files."""
+        self = cls.__new__(cls)
+        self.curve = curve
+        self._keep = None
+        self._shape = None
+        h = _vp()
+        _chk(LIB.mg_ctx_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_ctx_create_from_bytes")
+        self.handle = h
+        return self
 
     def set_r1cs(self, r1cs: R1CS):
         ms = []

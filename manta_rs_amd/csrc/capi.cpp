@@ -223,6 +223,16 @@ MG_API int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out) {
     return MG_SUCCESS;
     MG_CATCH
 }
+MG_API int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out) {
+    MG_TRY
+    if (!bytes || !out) return MG_ERROR_INVALID_ARGUMENT;
+    Prover *p = nullptr;
+    int rc = prover_create_from_bytes((int)curve, bytes, len, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
 MG_API int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t m) {
     MG_TRY
     if (!ctx || !a || !b || !c) return MG_ERROR_INVALID_ARGUMENT;

@@ -62,7 +62,7 @@ struct BaseSet {
 
 // Per-call scratch for one MSM (device + pinned host staging). Pooled per engine.
 struct MsmWorkspace {
-    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, buckets, pkeys[2], ppts[2], redA, redS, redP, misc;
+    DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, buckets, pkeys[2], ppts[2], redA, redS, misc;
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;

@@ -45,26 +45,6 @@ template <class FrC> __global__ __launch_bounds__(256) void bitrev_kernel(u32 *_
     }
 }
 
-// One DIT butterfly stage (after bit reversal). stage s: m = 2^s, butterflies (i0, i0 + m/2),
-// twiddle = tw[j * (n/m)], tw[k] = omega^k for k < n/2.
-template <class FrC>
-__global__ __launch_bounds__(256) void ntt_stage_kernel(u32 *__restrict__ data, const u32 *__restrict__ tw,
-                                                        unsigned log_n, unsigned s) {
-    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (1u << (log_n - 1))) return;
-    typedef Fp<FrC> F;
-    const u32 half = 1u << (s - 1);
-    const u32 j = k & (half - 1);
-    const u32 i0 = ((k >> (s - 1)) << s) + j, i1 = i0 + half;
-    F a = F::load(data + (size_t)i0 * 8), b = F::load(data + (size_t)i1 * 8);
-    if (s > 1) { // stage 1 twiddle is 1
-        F w = F::load(tw + ((size_t)j << (log_n - s)) * 8);
-        b = F::mul(b, w);
-    }
-    F::add(a, b).store(data + (size_t)i0 * 8);
-    F::sub(a, b).store(data + (size_t)i1 * 8);
-}
-
 template <class FrC>
 __global__ __launch_bounds__(256) void scale_table_kernel(u32 *__restrict__ data, const u32 *__restrict__ table,
                                                           u32 n) {

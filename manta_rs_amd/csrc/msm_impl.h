@@ -33,8 +33,6 @@
 
 namespace mg {
 
-static constexpr u32 KEY_INVALID_BIT = 0x80000000u; // never used as a key; INVALID = Wb*B (sorts last)
-
 // --------------------------------------------------------------------------------------------
 // K5: digits
 // --------------------------------------------------------------------------------------------

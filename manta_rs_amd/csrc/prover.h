@@ -43,5 +43,7 @@ class Prover {
     virtual u64 domain_size() const = 0;
 };
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);
+// arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
+int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out);
 
 } // namespace mg

@@ -48,7 +48,7 @@ void DevBuf::release() {
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
-                     &ppts[0], &ppts[1], &redA,     &redS,    &redP,     &misc};
+                     &ppts[0], &ppts[1], &redA,     &redS,    &misc};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (done) hipEventDestroy(done);

@@ -130,3 +130,40 @@ def test_ntt_full_size_roundtrip_and_linearity(gpu, curve):
     assert (O.field_op(fr, "add", fx, dom.fft(y)) == dom.fft(O.field_op(fr, "add", x, y))).all()
     m = 1 << 16
     assert (gpu.Radix2EvaluationDomain(curve, m).coset_fft(x[:m]) == O.ntt(curve, x[:m], coset=True)).all()
+
+
+def _pk_bytes(curve, pk):
+    """arkworks 0.3 ProvingKey::serialize_unchecked layout (SURVEY.md App. A.3 / App. C), written with the
+    oracle's uncompressed point encoder."""
+    import struct
+    ser1 = lambda p: O.serialize(curve, 1, p, compressed=False)
+    ser2 = lambda p: O.serialize(curve, 2, p, compressed=False)
+    vec = lambda pts, f: struct.pack("<Q", len(pts)) + b"".join(f(p) for p in pts)
+    return (ser1(pk.alpha_g1[0]) + ser2(pk.beta_g2[0]) + ser2(pk.gamma_g2[0]) + ser2(pk.delta_g2[0]) +
+            vec(pk.gamma_abc_g1, ser1) + ser1(pk.beta_g1[0]) + ser1(pk.delta_g1[0]) + vec(pk.a_query, ser1) +
+            vec(pk.b_g1_query, ser1) + vec(pk.b_g2_query, ser2) + vec(pk.h_query, ser1) + vec(pk.l_query, ser1))
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_proving_context_decode_wire_format(gpu, curve):
+    """ProvingContext::decode (groth16.rs:268-288): a key in arkworks' serialize_unchecked byte format, incl.
+    infinity entries, gives the same proofs as the same key passed as limb arrays; size matches App. C."""
+    c = synth.make_circuit(curve, 400, 300, 9, seed=12)
+    pk = O.groth16_setup(c, H.toxic(curve, seed=3))
+    data = _pk_bytes(curve, pk)
+    if curve == 0:
+        # 64 + 3*128 + (8 + 64 P) + 64 + 64 + (8 + 64 V)*2 + (8 + 128 V) + (8 + 64 H) + (8 + 64 (V - P)) = 624 + 320 V + 64 H
+        assert len(data) == 624 + 320 * c.V + 64 * (c.D - 1)
+    ctx = gpu.ProvingContext.decode(curve, data)
+    r1cs = gpu.R1CS.from_circuit(c)
+    ctx.set_r1cs(r1cs)
+    rs = H.rand_fr_mont(curve, 2, seed=4)
+    proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    assert proof == O.groth16_prove(c, pk, rs[0], rs[1])
+    assert O.groth16_verify(curve, pk, c.z[1:c.P], proof) == 1
+    with pytest.raises(gpu.MantaGpuError):
+        gpu.ProvingContext.decode(curve, data[:-5])          # truncated
+    bad = bytearray(data)
+    bad[31 if curve == 0 else 47] = 0x3f                    # x coordinate >= p (non-canonical)
+    with pytest.raises(gpu.MantaGpuError):
+        gpu.ProvingContext.decode(curve, bytes(bad))
