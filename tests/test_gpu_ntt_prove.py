@@ -167,3 +167,30 @@ def test_proving_context_decode_wire_format(gpu, curve):
     bad[31 if curve == 0 else 47] = 0x3f                    # x coordinate >= p (non-canonical)
     with pytest.raises(gpu.MantaGpuError):
         gpu.ProvingContext.decode(curve, bytes(bad))
+
+
+def test_error_codes_not_exceptions(gpu):
+    """The C ABI reports failures as status codes (any non-zero -> the reference's opaque `Error`): domain
+    larger than the field's two-adicity (PolynomialDegreeTooLarge), prove before the R1CS is set, bad arguments."""
+    import ctypes
+    with pytest.raises(gpu.MantaGpuError) as e:  # BN254 Fr has two-adicity 28: a 2^29 domain does not exist
+        gpu._chk(gpu.LIB.mg_ntt_device(0, ctypes.c_void_p(8), 29, 0, 0), "mg_ntt_device")
+    assert e.value.status == 4
+    c = synth.make_circuit(0, 50, 40, 3, seed=1)
+    pk = O.groth16_setup(c, H.toxic(0))
+    ctx = gpu.ProvingContext(0, pk)
+    rs = H.rand_fr_mont(0, 2, seed=1)
+    with pytest.raises(gpu.MantaGpuError) as e:
+        gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])   # no R1CS yet
+    assert e.value.status == 5
+    with pytest.raises(gpu.MantaGpuError) as e:
+        gpu.Bases(0, 3, np.ones((4, 8), dtype=np.uint64))           # no such group
+    assert e.value.status == 1
+    bad = synth.make_circuit(0, 50, 40, 3, seed=1)
+    bad.A.col = bad.A.col.copy()
+    bad.A.col[0] = 1000                                             # column index out of range
+    with pytest.raises(gpu.MantaGpuError) as e:
+        ctx.set_r1cs(gpu.R1CS.from_circuit(bad))
+    assert e.value.status == 1
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == O.groth16_prove(c, pk, rs[0], rs[1])
