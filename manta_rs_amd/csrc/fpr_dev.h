@@ -157,6 +157,9 @@ template <class C> struct FpR {
         t.v[K - 1] = (u32)acc;
         return t;
     }
+    // the same as real functions: for callers whose register budget cannot take the inlined products
+    static __device__ __noinline__ FpR mul_call(const FpR a, const FpR b) { return mul(a, b); }
+    static __device__ __noinline__ FpR sqr_call(const FpR a) { return sqr(a); }
     // square: cross products once, against the doubled operand
     static MG_DEV FpR sqr(const FpR &a) {
         u64 acc = 0;
@@ -303,13 +306,24 @@ template <class C> struct Fp2R {
     template <int A> static MG_DEV Fp2R reduce(const Fp2R &a) {
         return Fp2R{B::template reduce<A>(a.c0), B::template reduce<A>(a.c1)};
     }
+    // 14-limb products (BLS12-381) are calls here: four of them inlined per Fp2 product overflow the
+    // register file in the group operations
+    static constexpr bool CALLS = B::K > 9;
+    static MG_DEV B bmul(const B &x, const B &y) {
+        if constexpr (CALLS) return B::mul_call(x, y);
+        else return B::mul(x, y);
+    }
+    static MG_DEV B bsqr(const B &x) {
+        if constexpr (CALLS) return B::sqr_call(x);
+        else return B::sqr(x);
+    }
     static MG_DEV Fp2R mul(const Fp2R &a, const Fp2R &b) {
-        const B v0 = B::mul(a.c0, b.c0), v1 = B::mul(a.c1, b.c1);
-        const B x = B::mul(a.c0, b.c1), y = B::mul(a.c1, b.c0);
+        const B v0 = bmul(a.c0, b.c0), v1 = bmul(a.c1, b.c1);
+        const B x = bmul(a.c0, b.c1), y = bmul(a.c1, b.c0);
         return Fp2R{B::template sub<2>(v0, v1), B::add(x, y)};
     }
     static MG_DEV Fp2R sqr(const Fp2R &a) {
-        const B v0 = B::sqr(a.c0), v1 = B::sqr(a.c1), x = B::mul(a.c0, a.c1);
+        const B v0 = bsqr(a.c0), v1 = bsqr(a.c1), x = bmul(a.c0, a.c1);
         return Fp2R{B::template sub<2>(v0, v1), B::dbl(x)};
     }
     static __device__ __noinline__ Fp2R inv(const Fp2R &a) { // one-off use only

@@ -423,11 +423,15 @@ template <class Curve> struct GT<Curve, 1> {
     typedef host::HFp<typename Curve::Fq> HF;
 };
 template <class Curve> struct GT<Curve, 2> {
-    // G2 uses the lazily-reduced Fp2R only where an XYZZ point still fits the register file: BN254
-    // (4 x 2 x 9 = 72 words). Over BLS12-381 (112 words) the Fp2R kernels need 256 VGPRs + 1.4 KB of
-    // scratch per lane and -- observed on MI355X, ROCm 7.2 -- do not terminate; they stay on the saturated
-    // Fp2 path (group operations as calls), which passes every parity test.
-    typedef typename std::conditional<(Curve::Fq::RR_K <= 9), Fp2R<typename Curve::Fq>, Fp2<typename Curve::Fq>>::type F;
+    // G2 on the lazily-reduced Fp2R as well. Over BLS12-381 (an XYZZ point is 112 words) the 14-limb base
+    // products inside Fp2R are calls (fpr_dev.h `CALLS`): fully inlined, those kernels need 256 VGPRs + 1.4 KB of
+    // scratch per lane and -- observed on MI355X, ROCm 7.2 -- do not terminate. MG_G2_SATURATED keeps the
+    // canonical 32-bit Fp2 path for A/B.
+#ifdef MG_G2_SATURATED
+    typedef Fp2<typename Curve::Fq> F;
+#else
+    typedef Fp2R<typename Curve::Fq> F;
+#endif
     typedef Fp2<typename Curve::Fq> FIO;
     typedef host::HFp2<typename Curve::Fq> HF;
 };
