@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-LOG_N = 20
+LOG_N = int(os.environ.get("MANTA_BENCH_LOGN", "20"))  # 20 = the BASELINE config; smaller n only for scaling studies
 CURVE = 1  # BLS12-381
 WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
 DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
@@ -170,21 +170,21 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O  # the checker, here only as the timed CPU baseline
-            ns = 1 << 17
+            ns = min(n, 1 << 17)
             host_pts = d_pts.to_numpy(shape=(n, 12))[:ns].copy()
             tcpu, out = O.time_msm(CURVE, 1, host_pts, scalars[:ns])
             cpu = {"value": round(ns / tcpu / 1e6, 5), "unit": "Mscalar/s", "cores": 1, "kind": "port",
-                   "sample": f"first 2^17 bases/scalars of the same workload, arkworks-0.3 Pippenger restatement, "
+                   "sample": f"first {ns} bases/scalars of the same workload, arkworks-0.3 Pippenger restatement, "
                              f"{tcpu:.1f} s on 1 thread (the reference ships arkworks without `parallel`)"}
 
     if rank == 0:
         total = world * n * args.steps
         line = {
-            "metric": "G1 MSM Mscalar/s at 2^20", "value": round(total / dt / 1e6, 3), "unit": "Mscalar/s",
+            "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(total / dt / 1e6, 3), "unit": "Mscalar/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": "2^20 BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM",
+            "config": {"workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
                        "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS,
                        "precomputed_base_multiples": True, "bases_hbm_bytes": bases.device_bytes(),
                        "sharding": "contiguous base/scalar ranges, all_gather of partial points" if world > 1 else "none"},

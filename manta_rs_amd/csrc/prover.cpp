@@ -199,6 +199,9 @@ class ProverImpl : public Prover {
             h_bs_ = nullptr;
             if ((rc = g1_->bases_create(perm.data(), D, false, pre_c_for(D), &h_bs_))) return rc;
         }
+        // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them
+        for (ProveWs *w : ws_free_) delete w;
+        ws_free_.clear();
         m_ = m;
         log_d_ = lg;
         have_r1cs_ = true;

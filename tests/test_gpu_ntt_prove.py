@@ -194,3 +194,31 @@ def test_error_codes_not_exceptions(gpu):
     assert e.value.status == 1
     ctx.set_r1cs(gpu.R1CS.from_circuit(c))
     assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == O.groth16_prove(c, pk, rs[0], rs[1])
+
+
+def test_context_reused_across_shapes_and_many_proofs(gpu):
+    """One ProvingContext, the R1CS replaced by a different (larger-domain) one after the proof slots have
+    captured their hipGraphs; then a run of proofs with fresh randomness each -- all byte-identical to the oracle."""
+    curve = 0
+    c1 = synth.make_circuit(curve, 200, 300, 5, seed=41)      # D = 256
+    c2 = synth.make_circuit(curve, 900, 300, 5, seed=42)      # D = 1024, same V and P -> same key shape
+    pk1 = O.groth16_setup(c1, H.toxic(curve, seed=9))
+    ctx = gpu.ProvingContext(curve, pk1)
+    rs = H.rand_fr_mont(curve, 12, seed=77)
+    r1 = gpu.R1CS.from_circuit(c1)
+    ctx.set_r1cs(r1)
+    for i in range(4):  # eager, eager, capture, replay
+        got = gpu.Groth16.prove_with_randomness(ctx, c1.z, rs[2 * i], rs[2 * i + 1])
+        assert got == O.groth16_prove(c1, pk1, rs[2 * i], rs[2 * i + 1])
+    # a different circuit over the same variables needs its own key; reuse the context object only for the R1CS swap
+    pk2 = O.groth16_setup(c2, H.toxic(curve, seed=9))
+    ctx2 = gpu.ProvingContext(curve, pk2)
+    ctx2.set_r1cs(gpu.R1CS.from_circuit(c1))                  # wrong (smaller) circuit first ...
+    gpu.Groth16.prove_with_randomness(ctx2, c1.z, rs[0], rs[1])
+    gpu.Groth16.prove_with_randomness(ctx2, c1.z, rs[0], rs[1])
+    gpu.Groth16.prove_with_randomness(ctx2, c1.z, rs[0], rs[1])
+    ctx2.set_r1cs(gpu.R1CS.from_circuit(c2))                  # ... then the right one: slots must be rebuilt
+    for i in range(4):
+        got = gpu.Groth16.prove_with_randomness(ctx2, c2.z, rs[2 * i], rs[2 * i + 1])
+        assert got == O.groth16_prove(c2, pk2, rs[2 * i], rs[2 * i + 1])
+        assert O.groth16_verify(curve, pk2, c2.z[1:c2.P], got) == 1
