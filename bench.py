@@ -166,7 +166,13 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                     "traffic": traffic, "kernel_ms": round(k_ms, 4),
                     "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SCALAR,
-                    "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); see DESIGN.md for the int-MAD bound"}
+                    "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); int_mad gives the bound that governs",
+                    # v_mad_u64_u32 per launch: ~15.06 mixed adds per scalar (16 signed 16-bit windows, top one nearly
+                    # empty) x (8 mul x 406 + 2 sqr x 315) mads; peak = 1024 SIMDs x 64 lanes / 4.2 cycles (measured issue
+                    # rate, profiles/r01_ubench2_mad_u64_u32.txt) x 2.4 GHz
+                    "int_mad": {"mads_per_launch": int(n * 15.06 * 3878), "achieved_Tmad_s": round(n * 15.06 * 3878 / (k_ms * 1e-3) / 1e12, 2),
+                                "peak_Tmad_s": round(1024 * 64 / 4.2 * 2.4e9 / 1e12, 2),
+                                "frac": round(n * 15.06 * 3878 / (k_ms * 1e-3) / (1024 * 64 / 4.2 * 2.4e9), 3)} if LOG_N == 20 and WINDOW_BITS == 16 else None}
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O  # the checker, here only as the timed CPU baseline
@@ -183,7 +189,7 @@ def main():
             "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(total / dt / 1e6, 3), "unit": "Mscalar/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
                        "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS,
                        "precomputed_base_multiples": True, "bases_hbm_bytes": bases.device_bytes(),
@@ -299,7 +305,7 @@ def prove_main(args):
         line = {"metric": f"Groth16 proofs/sec (manta-pay {args.shape} shape)", "value": round(world * args.steps / dt, 3),
                 "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers, BN254)", "data": "synthetic",
+                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": f"Groth16 prove, shape-exact synthetic {args.shape} circuit (D={D}, V={V}, P={P}), BN254",
                            "host_threads": args.threads, "sequential_latency_ms": round(lat_ms, 3),
                            "setup_s": round(setup_s, 2)},

@@ -54,7 +54,9 @@ struct MsmPlan {
 // A static set of bases resident in HBM (a proving-key query, or a caller-registered vector).
 struct BaseSet {
     int curve = 0, group = 1;
-    size_t n = 0;
+    size_t n = 0;         // points stored (after dropping infinity entries when compacted)
+    size_t n_orig = 0;    // logical length: scalars are indexed 0 .. n_orig-1
+    u32 *d_map = nullptr; // compacted sets: stored point i belongs to scalar d_map[i]; nullptr = identity
     u32 *d_pts = nullptr; // affine AoS; with precompute: W tables of n points, table w = 2^(c w) * P
     int pre_c = 0, pre_W = 0; // 0 = no precompute
     size_t bytes = 0;
@@ -92,7 +94,11 @@ class GroupEngine {
     virtual int scalar_bits() const = 0;
 
     // bases: affine Montgomery AoS (host or device pointer). precompute_c > 0 builds 2^(c w) tables.
-    virtual int bases_create(const u32 *pts, size_t n, bool src_on_device, int precompute_c, BaseSet **out) = 0;
+    // drop_infinity (host sources only): points at infinity are removed from the stored set (proving-key
+    // queries are full of them: every variable absent from B has b_g1_query = b_g2_query = infinity) and
+    // never reach the sort or the accumulate kernel; scalars stay indexed by the original positions.
+    virtual int bases_create(const u32 *pts, size_t n, bool src_on_device, int precompute_c, BaseSet **out,
+                             bool drop_infinity = false) = 0;
     virtual void bases_destroy(BaseSet *) = 0;
 
     virtual MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override) const = 0;

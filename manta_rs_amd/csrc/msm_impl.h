@@ -45,12 +45,21 @@ MG_DEV u32 limb_at(const u32 (&s)[8], int i) { // dynamic index without scratch
 template <class FrC>
 __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
                                                      int precomp, u32 tstride, int mont, u32 invalid,
-                                                     u32 *__restrict__ keys, u32 *__restrict__ vals) {
+                                                     u32 *__restrict__ keys, u32 *__restrict__ vals,
+                                                     const u32 *__restrict__ map, u32 n_scalars) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const u32 src = map ? map[i] : i; // which scalar belongs to stored base i
+    if (src >= n_scalars) {           // the scalar vector is shorter than the base set: zip to the shorter
+        for (int w = 0; w < W; ++w) {
+            keys[(size_t)w * n + i] = invalid;
+            vals[(size_t)w * n + i] = 0;
+        }
+        return;
+    }
     u32 s[8];
     {
-        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + (size_t)i * 8);
+        const uint4 *p = reinterpret_cast<const uint4 *>(scalars + (size_t)src * 8);
         uint4 a = p[0], b = p[1];
         s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b.x, s[5] = b.y, s[6] = b.z, s[7] = b.w;
     }
@@ -485,12 +494,50 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // ---------------------------------------------------------------- bases
-    int bases_create(const u32 *pts, size_t n, bool src_on_device, int pre_c, BaseSet **out) override {
-        if (!pts || !n || !out) return MG_ERR_ARG;
+    int bases_create(const u32 *pts_in, size_t n_in, bool src_on_device, int pre_c, BaseSet **out,
+                     bool drop_infinity = false) override {
+        if (!pts_in || !n_in || !out) return MG_ERR_ARG;
+        const u32 *pts = pts_in;
+        size_t n = n_in;
+        std::vector<u32> compact, map;
+        if (drop_infinity && !src_on_device) {
+            size_t kept = 0;
+            for (size_t i = 0; i < n_in; ++i) {
+                const u32 *q = pts_in + i * AW_IO;
+                u32 x = 0;
+                for (int k = 0; k < AW_IO; ++k) x |= q[k];
+                kept += x != 0;
+            }
+            if (kept < n_in) {
+                if (kept == 0) kept = 1; // keep one infinity entry so that the set is never empty
+                compact.resize(kept * AW_IO, 0u);
+                map.resize(kept, 0u);
+                size_t o = 0;
+                for (size_t i = 0; i < n_in && o < kept; ++i) {
+                    const u32 *q = pts_in + i * AW_IO;
+                    u32 x = 0;
+                    for (int k = 0; k < AW_IO; ++k) x |= q[k];
+                    if (x != 0) {
+                        std::memcpy(&compact[o * AW_IO], q, AW_IO * 4);
+                        map[o++] = (u32)i;
+                    }
+                }
+                pts = compact.data();
+                n = kept;
+            }
+        }
         BaseSet *bs = new BaseSet();
         bs->curve = CURVE_ID;
         bs->group = GROUP;
         bs->n = n;
+        bs->n_orig = n_in;
+        if (!map.empty()) {
+            if (hipMalloc((void **)&bs->d_map, map.size() * 4) != hipSuccess ||
+                hipMemcpy(bs->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                bases_destroy(bs);
+                return MG_ERR_OOM;
+            }
+        }
         int W = 1;
         if (pre_c > 0) {
             W = (FrC::BITS + 1 + pre_c - 1) / pre_c;
@@ -553,6 +600,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
     void bases_destroy(BaseSet *bs) override {
         if (!bs) return;
+        if (bs->d_map) hipFree(bs->d_map);
         if (bs->d_pts) hipFree(bs->d_pts);
         delete bs;
     }
@@ -589,8 +637,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
                    MsmWorkspace *ws) override {
-        if (!bs || !d_scalars || !ws || n == 0 || n > bs->n) return MG_ERR_ARG;
+        if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
+        const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
+        if (bs->d_map || n > bs->n) n = bs->n; // entries = stored points; the kernel zips to the shorter side
         const MsmPlan pl = plan_for(bs, n, c_override);
         hipStream_t s = ws->stream;
         const size_t M = n * (size_t)pl.W;
@@ -616,7 +666,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalars_mont ? 1 : 0, invalid,
-                           ws->keys_in.as<u32>(), ws->vals_in.as<u32>());
+                           ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars);
         int end_bit = 1;
         while ((1u << end_bit) <= invalid) ++end_bit;
         if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),

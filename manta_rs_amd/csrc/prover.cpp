@@ -150,10 +150,10 @@ class ProverImpl : public Prover {
         delta2_tab_ = g2_->hp_table_create(&delta_g2_);
         int rc;
         const int c_z = pre_c_for(V_ - 1);
-        if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, c_z, &a_bs_))) return rc;
-        if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, c_z, &b1_bs_))) return rc;
-        if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, c_z, &b2_bs_))) return rc;
-        if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, pre_c_for(V_ - P_), &l_bs_))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, c_z, &a_bs_, true))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, c_z, &b1_bs_, true))) return rc;
+        if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, c_z, &b2_bs_, true))) return rc;
+        if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
         // h_query is stored in the bit-reversed order the witness map leaves h in; that order depends on
         // the domain size, known once the R1CS arrives (set_r1cs)
         h_query_host_.assign((const u32 *)pk->h_query, (const u32 *)pk->h_query + (size_t)h_len_ * w1);
