@@ -38,7 +38,7 @@ template <class F, int B> struct Bv {
 template <int B, class F> MG_DEV Bv<F, B> bv(const F &f) { return Bv<F, B>{f}; }
 template <class F, int A, int B> MG_DEV Bv<F, F::BM> operator*(const Bv<F, A> &a, const Bv<F, B> &b) {
     static_assert((long)A * B * F::MULK <= F::LIM, "product of operand bounds exceeds the Montgomery headroom");
-    return Bv<F, F::BM>{F::mul(a.v, b.v)};
+    return Bv<F, F::BM>{F::template mulb<A, B>(a.v, b.v)};
 }
 template <class F, int A> MG_DEV Bv<F, F::BM> b_sqr(const Bv<F, A> &a) {
     static_assert((long)A * A * F::MULK <= F::LIM, "square of operand bound exceeds the Montgomery headroom");
@@ -131,7 +131,7 @@ template <class F> struct XYZZ {
         auto X2 = b_sqr(px);
         auto M = b_fit<6>(b_dbl(X2) + X2);                         // 3 x^2
         auto X3 = b_fit<BX>(b_sub2(b_sqr(M), bv<0>(F::zero()), S)); // M^2 - 2S
-        auto Y3 = b_fit<BY>(M * b_fit<12>(S - X3) - W * py);
+        auto Y3 = b_fit<BY>(M * (S - X3) - W * py);
         X3o = X3.v;
         Y3o = Y3.v;
         Vo = V.v;
@@ -197,7 +197,7 @@ template <class F> struct XYZZ {
         auto PPP = P * PP;
         auto Q = X1 * PP;
         auto X3 = b_fit<BX>(b_sub2(b_sqr(R), PPP, Q)); // R^2 - PPP - 2Q
-        auto Y3 = b_fit<BY>(R * b_fit<12>(Q - X3) - Y1 * PPP);
+        auto Y3 = b_fit<BY>(R * (Q - X3) - Y1 * PPP);
         x = X3.v;
         y = Y3.v;
         zz = (ZZ1 * PP).v;
@@ -232,7 +232,7 @@ template <class F> struct XYZZ {
         auto PPP = P * PP;
         auto Q = U1 * PP;
         auto X3 = b_fit<BX>(b_sub2(b_sqr(R), PPP, Q));
-        auto Y3 = b_fit<BY>(R * b_fit<12>(Q - X3) - S1 * PPP);
+        auto Y3 = b_fit<BY>(R * (Q - X3) - S1 * PPP);
         x = X3.v;
         y = Y3.v;
         zz = ((bv<BM>(zz) * bv<BM>(o.zz)) * PP).v;

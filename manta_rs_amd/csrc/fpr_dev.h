@@ -127,6 +127,7 @@ template <class C> struct FpR {
         return r;
     }
 
+    template <int A, int B> static MG_DEV FpR mulb(const FpR &a, const FpR &b) { return mul(a, b); }
     // ---- almost-Montgomery product: a*b*R'^-1 mod p, result < 2p (see header for the input bounds)
     static MG_DEV FpR mul(const FpR &a, const FpR &b) {
         u64 acc = 0;
@@ -321,6 +322,19 @@ template <class C> struct Fp2R {
         const B v0 = bmul(a.c0, b.c0), v1 = bmul(a.c1, b.c1);
         const B x = bmul(a.c0, b.c1), y = bmul(a.c1, b.c0);
         return Fp2R{B::template sub<2>(v0, v1), B::add(x, y)};
+    }
+    // product of operands with component bounds A, B. Where the headroom allows the operand sums
+    // (4 A B <= R'/p) this is Karatsuba -- 3 base products + one cheap reduction of c1 back below 2p -- else
+    // the 4-product schoolbook form above. Either way the components of the result are < 4p.
+    template <int A, int Bb> static MG_DEV Fp2R mulb(const Fp2R &a, const Fp2R &b) {
+        if constexpr (4L * A * Bb <= LIM && 2 * A <= 16 && 2 * Bb <= 16) {
+            const B v0 = bmul(a.c0, b.c0), v1 = bmul(a.c1, b.c1);
+            const B s = bmul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+            const B c1 = B::template reduce<6>(B::template sub<4>(s, B::add(v0, v1))); // s + 4p - v0 - v1 < 6p
+            return Fp2R{B::template sub<2>(v0, v1), c1};
+        } else {
+            return mul(a, b);
+        }
     }
     static MG_DEV Fp2R sqr(const Fp2R &a) {
         const B v0 = bsqr(a.c0), v1 = bsqr(a.c1), x = bmul(a.c0, a.c1);
