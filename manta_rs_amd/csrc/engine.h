@@ -30,6 +30,9 @@ void set_kernel_timing(bool on);
 bool kernel_timing();
 void set_last_accumulate_ms(float ms);
 float last_accumulate_ms();
+// process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)
+hipStream_t stream_pool_get();
+void stream_pool_put(hipStream_t s);
 const char *last_error_string();
 
 // grow-only device buffer

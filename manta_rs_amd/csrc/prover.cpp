@@ -57,7 +57,7 @@ struct ProveWs {
         if (h_z) hipHostFree(h_z);
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
-        if (stream) hipStreamDestroy(stream);
+        if (stream) stream_pool_put(stream); // never destroyed: see stream_pool_get()
     }
 };
 
@@ -218,7 +218,7 @@ class ProverImpl : public Prover {
             }
         }
         ProveWs *w = new ProveWs();
-        if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+        if (!(w->stream = stream_pool_get()) ||
             hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess) {
             delete w;

@@ -46,6 +46,31 @@ void DevBuf::release() {
     cap = 0;
 }
 
+// Streams that originate a graph capture are pooled for the life of the process and never destroyed: the
+// HIP runtime this library is loaded next to (libamdhip64 of ROCm 7.0) dereferences the destroyed origin
+// stream of an EARLIER capture inside hip::Graph::UpdateStreams when a LATER exec is launched (seen as a
+// segfault in hipGraphLaunch once a ProvingContext had been dropped and another one captured its proofs).
+static std::mutex g_stream_mu;
+static std::vector<hipStream_t> g_stream_pool;
+hipStream_t stream_pool_get() {
+    {
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        if (!g_stream_pool.empty()) {
+            hipStream_t s = g_stream_pool.back();
+            g_stream_pool.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return s;
+}
+void stream_pool_put(hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    g_stream_pool.push_back(s);
+}
+
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
                      &ppts[0], &ppts[1], &redA,     &redS,    &misc};

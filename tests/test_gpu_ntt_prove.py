@@ -222,3 +222,22 @@ def test_context_reused_across_shapes_and_many_proofs(gpu):
         got = gpu.Groth16.prove_with_randomness(ctx2, c2.z, rs[2 * i], rs[2 * i + 1])
         assert got == O.groth16_prove(c2, pk2, rs[2 * i], rs[2 * i + 1])
         assert O.groth16_verify(curve, pk2, c2.z[1:c2.P], got) == 1
+
+
+def test_contexts_created_and_dropped_between_captured_proofs(gpu):
+    """Regression: a ProvingContext that has captured its proof graph is dropped, then another context captures
+    and replays its own -- the HIP runtime used to crash in hipGraphLaunch when the first context's capture
+    stream had been destroyed (proof-slot streams are pooled for the life of the process since)."""
+    import gc
+    curve = 0
+    c = synth.make_circuit(curve, 200, 300, 5, seed=51)
+    pk = O.groth16_setup(c, H.toxic(curve, seed=10))
+    rs = H.rand_fr_mont(curve, 2, seed=78)
+    want = O.groth16_prove(c, pk, rs[0], rs[1])
+    for _ in range(6):
+        ctx = gpu.ProvingContext(curve, pk)
+        ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+        for _ in range(4):  # eager, eager, capture, replay
+            assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == want
+        del ctx
+        gc.collect()
