@@ -71,6 +71,7 @@ struct MsmWorkspace {
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
+    hipStream_t run_on = nullptr; // when set, msm_launch enqueues on this stream instead of the workspace's own
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
     bool timed = false;

@@ -166,59 +166,102 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
 }
 
 // --------------------------------------------------------------------------------------------
-// K7b: wavefront segmented merge of partials
+// K7b: merge of partials. The partial array is a key-sorted sequence of (key, point) entries, two per
+// producer (head run, tail run; a producer whose whole range was one run emits (key, sum), (key, inf)).
+// Every lane first folds G consecutive entries serially -- work-efficient: one addition per entry, and none at
+// all for G = 2 on accumulate output, where the pair never shares a summable key -- which leaves it with a
+// head run (parked in its own consumed input slot) and a tail run, or one run that spans the lane. The wave then
+// runs ONE segmented scan over the tail runs (a run only crosses a lane if that lane is a single run, so
+// equality of the sorted tail keys at distance d is the segment test) and one fix-up addition for the head
+// runs. Runs that end inside the wave and do not touch its first element go to their bucket; the wave's first
+// and last runs become the next level's two entries. 64*G entries -> 2 per wave.
 // --------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void merge_partials(const u32 *__restrict__ pkeys, const u32 *__restrict__ ppts,
-                                                      u32 cnt, u32 invalid, int final_level,
-                                                      u32 *__restrict__ buckets, u32 *__restrict__ okeys,
-                                                      u32 *__restrict__ opts, u32 n_waves) {
+__global__ __launch_bounds__(256) void merge_partials(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
+                                                      u32 invalid, int final_level, u32 *__restrict__ buckets,
+                                                      u32 *__restrict__ okeys, u32 *__restrict__ opts, u32 n_waves) {
+    constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= n_waves) return;
-    const u32 e = wave * 64 + lane;
-    u32 key = invalid;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    if (e < cnt) {
-        key = pkeys[e];
-        if (key != invalid) acc = XYZZ<F>::load(ppts + (size_t)e * XYZZ<F>::WORDS);
+    const size_t b = ((size_t)wave * 64 + lane) * G;
+    u32 kh = invalid, kt = invalid; // keys of the lane's first and last run
+    bool single = true;             // the lane holds one run only (kh == kt)
+    XYZZ<F> acc = XYZZ<F>::inf();   // sum of the last run
+    if (b < cnt) {
+        const size_t end = b + G < cnt ? b + G : cnt;
+        u32 cur = pkeys[b];
+        if (cur != invalid) {
+            kh = cur;
+            acc = XYZZ<F>::load(ppts + b * XW);
+            for (size_t j = b + 1; j < end; ++j) {
+                const u32 k = pkeys[j];
+                if (k != cur) {
+                    if (single) { // park the head run in slot b (already consumed; pkeys[b] == kh)
+                        acc.store(ppts + b * XW);
+                        single = false;
+                    } else {
+                        acc.store(buckets + (size_t)cur * XW);
+                    }
+                    cur = k;
+                    acc = XYZZ<F>::inf();
+                    if (k == invalid) break;
+                    acc = XYZZ<F>::load(ppts + j * XW);
+                } else {
+                    const XYZZ<F> p = XYZZ<F>::load(ppts + j * XW);
+                    if (!p.is_inf()) acc.add(p);
+                }
+            }
+            kt = cur;
+        }
     }
-    // inclusive segmented scan (Hillis-Steele); keys are sorted so "key at distance d equal" <=> same run
+    // inclusive segmented scan over (kt, acc)
     for (int d = 1; d < 64; d <<= 1) {
-        const u32 nk = __shfl_up(key, d, 64);
-        const bool take = (lane >= d) && (nk == key) && (key != invalid);
+        const u32 nk = __shfl_up(kt, d, 64);
+        const bool take = (lane >= d) && (nk == kt) && (kt != invalid);
         if (!__any(take)) break;
         const XYZZ<F> o = XYZZ<F>::shfl(acc, lane - d < 0 ? lane : lane - d);
         if (take) acc.add(o);
     }
-    const u32 next_key = __shfl_down(key, 1, 64);
-    const bool seg_end = (lane == 63) || (next_key != key);
-    const u32 key0 = __shfl(key, 0, 64), key63 = __shfl(key, 63, 64);
-    if (!seg_end || key == invalid) {
-        // nothing to emit from this lane -- but a wave whose last run is `invalid` must still mark it
-        if (!final_level && lane == 63 && key == invalid) {
-            okeys[2 * wave + 1] = invalid;
-            if (key0 == invalid) okeys[2 * wave] = invalid;
+    const u32 prev_kt = __shfl_up(kt, 1, 64), next_kh = __shfl_down(kh, 1, 64);
+    const u32 key0 = __shfl(kh, 0, 64);
+    const bool need_in = !single && lane > 0 && prev_kt == kh; // the previous lane's last run flows into my head run
+    const bool any_in = __any(need_in);
+    XYZZ<F> prev = XYZZ<F>::inf();
+    if (any_in) prev = XYZZ<F>::shfl(acc, lane > 0 ? lane - 1 : 0);
+    // the run that ends at this lane's right edge
+    const bool cont = lane < 63 && next_kh == kt;
+    if (kt != invalid && !cont) {
+        if (final_level) {
+            acc.store(buckets + (size_t)kt * XW);
+        } else if (kt == key0) {
+            okeys[2 * wave] = kt;
+            acc.store(opts + (size_t)(2 * wave) * XW);
+            if (lane == 63) { // the whole wave is one run
+                okeys[2 * wave + 1] = kt;
+                XYZZ<F>::inf().store(opts + (size_t)(2 * wave + 1) * XW);
+            }
+        } else if (lane == 63) {
+            okeys[2 * wave + 1] = kt;
+            acc.store(opts + (size_t)(2 * wave + 1) * XW);
+        } else {
+            acc.store(buckets + (size_t)kt * XW);
         }
-        return;
     }
-    if (final_level) {
-        acc.store(buckets + (size_t)key * XYZZ<F>::WORDS);
-        return;
+    if (!final_level && lane == 63 && kt == invalid) { // all further entries are invalid too (sorted last)
+        okeys[2 * wave + 1] = invalid;
+        if (key0 == invalid) okeys[2 * wave] = invalid;
     }
-    const bool is_first = (key == key0), is_last = (key == key63);
-    if (is_first) {
-        okeys[2 * wave] = key;
-        acc.store(opts + (size_t)(2 * wave) * XYZZ<F>::WORDS);
-        if (is_last) { // whole wave is one run
-            okeys[2 * wave + 1] = key;
-            XYZZ<F>::inf().store(opts + (size_t)(2 * wave + 1) * XYZZ<F>::WORDS);
+    // the head run of a lane with several runs ends inside the lane
+    if (!single) {
+        XYZZ<F> h = XYZZ<F>::load(ppts + b * XW);
+        if (need_in) h.add(prev);
+        if (!final_level && kh == key0) {
+            okeys[2 * wave] = kh;
+            h.store(opts + (size_t)(2 * wave) * XW);
+        } else {
+            h.store(buckets + (size_t)kh * XW);
         }
-    } else if (is_last) {
-        okeys[2 * wave + 1] = key;
-        acc.store(opts + (size_t)(2 * wave + 1) * XYZZ<F>::WORDS);
-    } else {
-        acc.store(buckets + (size_t)key * XYZZ<F>::WORDS);
     }
 }
 
@@ -634,6 +677,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         return p;
     }
 
+    static u32 merge_g1() {
+        static const u32 g = [] {
+            const char *e = getenv("MANTA_MERGE_G");
+            const int v = e ? atoi(e) : 0;
+            return (u32)(v >= 1 && v <= 64 ? v : 4);
+        }();
+        return g;
+    }
+
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
                    MsmWorkspace *ws) override {
@@ -642,7 +694,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
         if (bs->d_map || n > bs->n) n = bs->n; // entries = stored points; the kernel zips to the shorter side
         const MsmPlan pl = plan_for(bs, n, c_override);
-        hipStream_t s = ws->stream;
+        hipStream_t s = ws->run_on ? ws->run_on : ws->stream;
         const size_t M = n * (size_t)pl.W;
         if (M >= (1ull << 31)) return MG_ERR_ARG;
         const u32 nb = (u32)pl.Wb * pl.B; // real buckets; key nb = INVALID
@@ -681,11 +733,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * T;
         int src = 0;
-        for (;;) {
-            const u32 waves = cdiv(cnt, 64);
+        for (int level = 0;; ++level) {
+            // entries folded serially per lane: the first level is throughput-bound (as many entries as
+            // accumulate lanes x 2), later ones are pure latency; <= 512 entries finish in one wave
+            u32 G = level == 0 ? merge_g1() : 2;
+            if (cnt <= 512) G = cnt <= 64 ? 1 : cdiv(cnt, 64);
+            const u32 waves = cdiv(cdiv(cnt, G), 64);
             const int fin = waves == 1;
             hipLaunchKernelGGL((merge_partials<F>), dim3(cdiv(waves, 4)), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
-                               ws->ppts[src].as<u32>(), cnt, invalid, fin, ws->buckets.as<u32>(),
+                               ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
                                ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves);
             if (fin) break;
             cnt = 2 * waves;

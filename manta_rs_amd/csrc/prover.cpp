@@ -37,7 +37,8 @@ namespace {
 // launch-bound at manta-pay circuit sizes, and concurrent host threads stop contending on the runtime).
 struct ProveWs {
     DevBuf z, a, b, c;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // witness map, then the h MSM; everything is joined back into it
+    hipStream_t side[2] = {nullptr, nullptr}; // [0]: the G2 MSM (the longest chain); [1]: a, b_g1, l one after another
     hipEvent_t z_ready = nullptr, h_ready = nullptr;
     MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     GroupEngine *me[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -49,7 +50,10 @@ struct ProveWs {
     ~ProveWs() {
         if (exec) hipGraphExecDestroy(exec);
         for (int i = 0; i < 5; ++i)
-            if (mw[i]) me[i]->ws_release(mw[i]);
+            if (mw[i]) {
+                mw[i]->run_on = nullptr;
+                me[i]->ws_release(mw[i]);
+            }
         z.release();
         a.release();
         b.release();
@@ -57,9 +61,19 @@ struct ProveWs {
         if (h_z) hipHostFree(h_z);
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
-        if (stream) stream_pool_put(stream); // never destroyed: see stream_pool_get()
+        stream_pool_put(stream); // never destroyed: see stream_pool_get()
+        stream_pool_put(side[0]);
+        stream_pool_put(side[1]);
     }
 };
+
+static int prove_streams() {
+    static const int n = [] {
+        const char *e = std::getenv("MANTA_PROVE_STREAMS");
+        return e && std::atoi(e) == 3 ? 3 : 6;
+    }();
+    return n;
+}
 
 static bool graphs_enabled() {
     static const bool on = std::getenv("MANTA_NO_GRAPH") == nullptr;
@@ -218,8 +232,8 @@ class ProverImpl : public Prover {
             }
         }
         ProveWs *w = new ProveWs();
-        if (!(w->stream = stream_pool_get()) ||
-            hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
+        if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
+            !(w->side[1] = stream_pool_get()) || hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess) {
             delete w;
             return nullptr;
@@ -232,6 +246,18 @@ class ProverImpl : public Prover {
                 delete w;
                 return nullptr;
             }
+        }
+        // Three streams per proof, not six: the G2 MSM is the critical path (~3x a G1 MSM), so the three
+        // z-MSMs over G1 run back to back beside it and the h MSM follows the witness map on the main stream.
+        // Fewer streams = fewer hardware queues per proof in flight (the runtime multiplexes streams onto
+        // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
+        // stream per MSM.
+        if (prove_streams() == 3) {
+            w->mw[0]->run_on = w->side[1];
+            w->mw[1]->run_on = w->side[1];
+            w->mw[2]->run_on = w->side[0];
+            w->mw[3]->run_on = w->side[1];
+            w->mw[4]->run_on = w->stream;
         }
         return w;
     }
@@ -305,9 +331,13 @@ class ProverImpl : public Prover {
         for (int i = 0; i < 5; ++i) {
             // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
             // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-            MG_HIP(hipStreamWaitEvent(w->mw[i]->stream, i == 4 ? w->h_ready : w->z_ready, 0));
+            hipStream_t ms = w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream;
+            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->z_ready, 0));
             if ((rc = w->me[i]->msm_launch(bs[i], sc[i], cnt[i], true, 0, w->mw[i]))) return rc;
-            MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0)); // join
+        }
+        for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
+            hipStream_t ms = w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream;
+            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         return MG_OK;
     }
@@ -396,7 +426,7 @@ class ProverImpl : public Prover {
                     int rc2 = w->me[i]->msm_finish(w->mw[i], &res[i], true);
                     if (!rc) rc = rc2;
                 } else {
-                    hipStreamSynchronize(w->mw[i]->stream);
+                    hipStreamSynchronize(w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream);
                     if (!rc) rc = MG_ERR_STATE;
                 }
             }
