@@ -54,7 +54,7 @@ EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_point_serialize", "mg_ntt",
-    "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_witness_map", "mg_ctx_domain_size",
+    "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
 ]
 
@@ -362,3 +362,20 @@ class Groth16:
         out = ctypes.create_string_buffer(PROOF_BYTES[context.curve])
         _chk(LIB.mg_groth16_prove(context.handle, _p(_u64(z)), _p(_u64(r)), _p(_u64(s)), out), "mg_groth16_prove")
         return out.raw
+
+    @staticmethod
+    def prove_batch(context: ProvingContext, zs, rs, ss) -> list:
+        """k proofs of the context's circuit in one pass of the GPU pipeline (`mg_groth16_prove_batch`): zs = k
+        assignments (k x V x 4 u64), rs / ss = k blinding scalars each. Returns k proofs, proof q byte-identical to
+        prove_with_randomness(context, zs[q], rs[q], ss[q])."""
+        zs = np.ascontiguousarray(zs, dtype=np.uint64)
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(-1, 4)
+        ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
+        k = rs.shape[0]
+        if ss.shape[0] != k or zs.size % k or zs.size == 0:
+            raise ValueError("prove_batch: zs, rs, ss must describe the same number of proofs")
+        n = PROOF_BYTES[context.curve]
+        out = ctypes.create_string_buffer(n * k)
+        _chk(LIB.mg_groth16_prove_batch(context.handle, ctypes.c_uint64(k), _p(zs), _p(rs), _p(ss), out),
+             "mg_groth16_prove_batch")
+        return [out.raw[i * n:(i + 1) * n] for i in range(k)]

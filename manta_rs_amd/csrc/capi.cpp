@@ -246,6 +246,13 @@ MG_API int mg_groth16_prove(const mg_ctx *ctx, const uint64_t *z, const uint64_t
     return ctx->p->prove(z, r, s, proof_out);
     MG_CATCH
 }
+MG_API int mg_groth16_prove_batch(const mg_ctx *ctx, uint64_t k, const uint64_t *z, const uint64_t *r, const uint64_t *s,
+                                  uint8_t *proofs_out) {
+    MG_TRY
+    if (!ctx || !z || !r || !s || !proofs_out || k == 0) return MG_ERROR_INVALID_ARGUMENT;
+    return ctx->p->prove_batch(k, z, r, s, proofs_out);
+    MG_CATCH
+}
 MG_API int mg_witness_map(const mg_ctx *ctx, const uint64_t *z, uint64_t *h_out) {
     MG_TRY
     if (!ctx || !z || !h_out) return MG_ERROR_INVALID_ARGUMENT;

@@ -41,7 +41,7 @@ struct DevBuf {
     size_t cap = 0;
     int reserve(size_t bytes);
     void release();
-    template <class T> T *as() { return (T *)p; }
+    template <class T> T *as() const { return (T *)p; }
 };
 
 // Pippenger plan. Signed digits of c bits, B = 2^(c-1) buckets per bucket-window.
@@ -75,10 +75,11 @@ struct MsmWorkspace {
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
     bool timed = false;
+    bool capturing = false; // msm_launch is being stream-captured: enqueue kernels and copies only, no event records
     float accumulate_ms = 0.f;
     // host-side description of what was staged (filled by msm_launch, consumed by msm_finish)
     MsmPlan plan;
-    u32 T1 = 0, nP = 0;
+    u32 T1 = 0, nP = 0, batch = 1;
     int pending = 0;
     ~MsmWorkspace();
 };
@@ -105,12 +106,15 @@ class GroupEngine {
                              bool drop_infinity = false) = 0;
     virtual void bases_destroy(BaseSet *) = 0;
 
-    virtual MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override) const = 0;
+    virtual MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override, u32 batch = 1) const = 0;
     // Enqueue the whole MSM on ws->stream: scalars are device-resident (canonical, or Montgomery if
     // scalars_mont), n <= bs->n. Result is staged to pinned memory; call msm_finish to fold it.
+    // batch > 1: `batch` independent scalar vectors (vector q starts scalar_stride_words u32 after vector
+    // q-1) against the SAME bases in one pass of the pipeline -- every (vector, window) pair is its own
+    // bucket segment, so the kernels run once over batch x the entries (a batch of proofs of one circuit).
     virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
-                           MsmWorkspace *ws) = 0;
-    // Waits for the stream, folds the staged partial points on the host. out = XYZZ host point.
+                           MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0) = 0;
+    // Waits for the stream, folds the staged partial points on the host. out = `batch` XYZZ host points.
     // already_synced: the caller has synchronised with the work itself (hipGraph replay of a whole proof)
     virtual int msm_finish(MsmWorkspace *ws, HostPoint *out, bool already_synced = false) = 0;
 

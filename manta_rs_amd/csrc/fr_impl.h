@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void ntt_pass_kernel(u32 *__restrict__ d0, u32
                                                        unsigned ns, unsigned cb, const u32 *__restrict__ post) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     typedef Fp<FrC> F;
-    u32 *__restrict__ data = blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2);
+    // blockIdx.y: which of the (up to three) vectors; blockIdx.z: which member of a batch of such vectors,
+    // stored back to back (2^lg elements apart)
+    u32 *__restrict__ data = (blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2)) + ((size_t)blockIdx.z << (lg + 3));
     const u32 E = 1u << ns, TOT = E << cb, CM = (1u << cb) - 1;
     const u32 lo_bits = s0 - 1;
     const u32 nlo = (1u << lo_bits) >> cb; // groups of 2^cb low-index values
@@ -151,9 +153,11 @@ __global__ __launch_bounds__(256) void permute_bitrev_kernel(u32 *__restrict__ o
 template <class FrC>
 __global__ __launch_bounds__(256) void spmv_kernel(const u32 *__restrict__ row_ptr, const u32 *__restrict__ col,
                                                    const u32 *__restrict__ val, const u32 *__restrict__ z,
-                                                   u32 *__restrict__ out, u32 m) {
+                                                   u32 *__restrict__ out, u32 m, size_t z_stride, size_t out_stride) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
+    z += (size_t)blockIdx.y * z_stride; // batch member
+    out += (size_t)blockIdx.y * out_stride;
     typedef Fp<FrC> F;
     F acc = F::zero();
     const F one = F::one();
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(256) void qap_pointwise_kernel(u32 *__restrict__ a,
                                                             u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    a += (size_t)blockIdx.y * n * 8, b += (size_t)blockIdx.y * n * 8, c += (size_t)blockIdx.y * n * 8; // batch member
     typedef Fp<FrC> F;
     F ab = F::mul(F::load(a + (size_t)i * 8), F::load(b + (size_t)i * 8));
     ab = F::sub(ab, F::load(c + (size_t)i * 8));
@@ -276,7 +281,8 @@ template <class FrC> class FrEngineT : public FrEngine {
 
     // all stages of one transform over up to 3 vectors as LDS-fused passes of <= 10 stages
     template <bool DIF>
-    static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw, unsigned lg, const u32 *post, hipStream_t s) {
+    static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw, unsigned lg, const u32 *post, hipStream_t s,
+                           u32 batch = 1) {
         if (lg == 0) return;
         const unsigned npass = (lg + 9) / 10;
         unsigned done = 0;
@@ -291,7 +297,7 @@ template <class FrC> class FrEngineT : public FrEngine {
             const u32 blocks = (u32)(((size_t)1 << lg) >> (ns + cb));
             const size_t lds = ((size_t)32 << (ns + cb));
             const bool last = p + 1 == npass;
-            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec), dim3(256), lds, s, d0, d1, d2, tw, lg, s0,
+            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec, batch), dim3(256), lds, s, d0, d1, d2, tw, lg, s0,
                                ns, cb, last ? post : (const u32 *)nullptr);
             done += ns;
         }
@@ -319,27 +325,28 @@ template <class FrC> class FrEngineT : public FrEngine {
     // of h = (A B - C)/Z in BIT-REVERSED order (the h-query bases are stored in the same order).
     // ifft = DIF (natural -> bit-reversed) with n^-1 g^i folded into its last pass, coset fft = DIT
     // (bit-reversed -> natural): no permutation pass, 2 x ceil(lg/10) launches per transform, a/b/c batched.
-    int qap_quotient(u32 *a, u32 *b, u32 *c, unsigned lg, hipStream_t s) override {
+    int qap_quotient(u32 *a, u32 *b, u32 *c, unsigned lg, hipStream_t s, u32 batch = 1) override {
         Domain *d;
         int rc = get_domain(lg, &d);
         if (rc) return rc;
         const u32 n = 1u << lg;
         if (lg == 0) { // degenerate domain: h = (a b - c) / (g - 1) scaled as the general path would
-            hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1), dim3(256), 0, s, a, b, c, d->consts + 8, n);
+            hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1, batch), dim3(256), 0, s, a, b, c, d->consts + 8, n);
             MG_HIP(hipGetLastError());
             return MG_OK;
         }
-        run_passes<true>(a, b, c, 3, d->tw_inv, lg, d->t1_br, s);
-        run_passes<false>(a, b, c, 3, d->tw_fwd, lg, nullptr, s);
-        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256), dim3(256), 0, s, a, b, c, d->consts + 8, n);
-        run_passes<true>(a, a, a, 1, d->tw_inv, lg, d->t2_br, s);
+        run_passes<true>(a, b, c, 3, d->tw_inv, lg, d->t1_br, s, batch);
+        run_passes<false>(a, b, c, 3, d->tw_fwd, lg, nullptr, s, batch);
+        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, b, c, d->consts + 8, n);
+        run_passes<true>(a, a, a, 1, d->tw_inv, lg, d->t2_br, s, batch);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }
-    int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s) override {
+    int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s, u32 batch = 1, size_t z_stride = 0,
+             size_t out_stride = 0) override {
         if (m == 0) return MG_OK;
-        hipLaunchKernelGGL((spmv_kernel<FrC>), dim3((u32)((m + 255) / 256)), dim3(256), 0, s, M.row_ptr, M.col, M.val,
-                           d_z, d_out, (u32)m);
+        hipLaunchKernelGGL((spmv_kernel<FrC>), dim3((u32)((m + 255) / 256), batch), dim3(256), 0, s, M.row_ptr, M.col, M.val,
+                           d_z, d_out, (u32)m, z_stride, out_stride);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }

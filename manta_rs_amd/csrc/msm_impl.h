@@ -46,9 +46,16 @@ template <class FrC>
 __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
                                                      int precomp, u32 tstride, int mont, u32 invalid,
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
-                                                     const u32 *__restrict__ map, u32 n_scalars) {
+                                                     const u32 *__restrict__ map, u32 n_scalars,
+                                                     size_t scalar_stride, u32 seg_keys) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // blockIdx.y = scalar vector of a batch: its own scalars, its own slice of the key/value arrays and its own
+    // range of bucket keys; the bases (and so the values) are shared
+    scalars += (size_t)blockIdx.y * scalar_stride;
+    keys += (size_t)blockIdx.y * W * n;
+    vals += (size_t)blockIdx.y * W * n;
+    const u32 key0 = blockIdx.y * seg_keys;
     const u32 src = map ? map[i] : i; // which scalar belongs to stored base i
     if (src >= n_scalars) {           // the scalar vector is shorter than the base set: zip to the shorter
         for (int w = 0; w < W; ++w) {
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ sca
             keys[o] = invalid;
             vals[o] = 0;
         } else {
-            keys[o] = precomp ? (d - 1) : ((u32)w * B + d - 1);
+            keys[o] = key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1));
             vals[o] = (precomp ? ((u32)w * tstride + i) : i) | (neg << 31);
         }
     }
@@ -649,7 +656,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // ---------------------------------------------------------------- plan
-    MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override) const override {
+    MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override, u32 batch = 1) const override {
         MsmPlan p;
         if (bs->pre_c > 0) {
             p.c = bs->pre_c;
@@ -668,7 +675,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // entries per lane: one full round of lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131k) when the MSM is
         // large, never fewer than 8 per lane; longer chunks mean fewer partials for the merge levels
         // (measured at 2^20: L = 64 / 128 / 192 / 256 -> 295 / 312 / 316 / 301 Mscalar/s)
-        const size_t M = n * (size_t)p.W;
+        const size_t M = n * (size_t)p.W * batch;
         size_t L = M / (96 * 1024);
         if (L < 8) L = 8;
         if (L > 192) L = 192;
@@ -688,16 +695,17 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
-                   MsmWorkspace *ws) override {
-        if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig) return MG_ERR_ARG;
+                   MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0) override {
+        if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig || batch == 0 || batch > 65535) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
         if (bs->d_map || n > bs->n) n = bs->n; // entries = stored points; the kernel zips to the shorter side
-        const MsmPlan pl = plan_for(bs, n, c_override);
+        const MsmPlan pl = plan_for(bs, n, c_override, batch);
         hipStream_t s = ws->run_on ? ws->run_on : ws->stream;
-        const size_t M = n * (size_t)pl.W;
-        if (M >= (1ull << 31)) return MG_ERR_ARG;
-        const u32 nb = (u32)pl.Wb * pl.B; // real buckets; key nb = INVALID
+        const size_t M = n * (size_t)pl.W * batch;
+        if (M >= (1ull << 31) || (size_t)batch * pl.Wb * pl.B >= (1ull << 24)) return MG_ERR_ARG;
+        const u32 seg_keys = (u32)pl.Wb * pl.B; // bucket keys per scalar vector
+        const u32 nb = batch * seg_keys;        // real buckets; key nb = INVALID
         const u32 invalid = nb;
         int rc;
         if ((rc = ws->keys_in.reserve(M * 4)) || (rc = ws->keys_out.reserve(M * 4)) ||
@@ -716,16 +724,17 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 
         // with precomputed tables the base index is w*stride + i: table w starts bs->n points after w-1
         if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
-        hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
+        hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256), batch), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalars_mont ? 1 : 0, invalid,
-                           ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars);
+                           ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
+                           scalar_stride_words, seg_keys);
         int end_bit = 1;
         while ((1u << end_bit) <= invalid) ++end_bit;
         if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
                              ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s)))
             return rc;
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
-        ws->timed = kernel_timing();
+        ws->timed = kernel_timing() && !ws->capturing;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                            ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
@@ -748,7 +757,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             src ^= 1;
         }
         // ---- bucket reduce
-        const u32 segs = (u32)pl.Wb;
+        const u32 segs = batch * (u32)pl.Wb;
         const u32 T0 = cdiv(pl.B, 64);
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
@@ -791,11 +800,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
-        MG_HIP(hipEventRecord(ws->done, s));
+        if (!ws->capturing) MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());
         ws->plan = pl;
         ws->T1 = T1;
         ws->nP = nP;
+        ws->batch = batch;
         ws->pending = 1;
         return MG_OK;
     }
@@ -821,10 +831,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if (hipEventElapsedTime(&ms, ws->t0, ws->t1) == hipSuccess) set_last_accumulate_ms(ms);
         }
         const MsmPlan &pl = ws->plan;
-        const u32 segs = (u32)pl.Wb, T1 = ws->T1, nP = ws->nP;
+        const u32 Wb = (u32)pl.Wb, segs = ws->batch * Wb, T1 = ws->T1, nP = ws->nP;
         const u32 *st = (const u32 *)ws->h_stage;
+        for (u32 q = 0; q < ws->batch; ++q) {
         HP total = HP::inf();
-        for (int w = (int)segs - 1; w >= 0; --w) {
+        for (int w = (int)((q + 1) * Wb) - 1; w >= (int)(q * Wb); --w) {
             HP win;
             if (T1 == 0xffffffffu) { // fused reduce: (X, sumS) per window, window = sumS + 64 X
                 const HP X = HP::from_xyzz_words(st + ((size_t)w * 2 + 0) * XW_IO);
@@ -850,10 +861,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 for (u32 u = 0; u < nP; ++u) sumP = HP::add(sumP, HP::from_xyzz_words(P0 + (size_t)u * XW_IO));
                 win = HP::add(sumP, HP::mul_pow2(X, 6));
             }
-            if (w != (int)segs - 1) total = HP::mul_pow2(total, (unsigned)pl.c);
+            if (w != (int)((q + 1) * Wb) - 1) total = HP::mul_pow2(total, (unsigned)pl.c);
             total = HP::add(total, win);
         }
-        hp(out) = total;
+        hp(out + q) = total;
+        }
         return MG_OK;
     }
 

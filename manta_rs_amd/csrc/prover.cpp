@@ -15,6 +15,7 @@
 #include "prover.h"
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -31,10 +32,14 @@ FrEngine *get_ntt_engine(int curve) {
 
 namespace {
 
-// One in-flight proof: device scratch for the witness map, its five MSM workspaces (each with its own
-// stream), a pinned copy of z, and -- after two eager runs that size every buffer -- a captured hipGraph
-// of the whole GPU side of the proof (~90 launches on 6 streams become one hipGraphLaunch: the prover is
-// launch-bound at manta-pay circuit sizes, and concurrent host threads stop contending on the runtime).
+// One in-flight proof (or batch of proofs): device scratch for the witness map, its five MSM workspaces (each
+// with its own stream), a pinned copy of z, and -- after two eager runs that size every buffer -- six captured
+// hipGraphs: the witness map and each MSM, every one a SINGLE-stream capture replayed on its own stream with
+// the same event fork/join as the eager path (~90 launches become 6 hipGraphLaunch + 12 event calls: the prover
+// is launch-bound at manta-pay circuit sizes, and concurrent host threads stop contending on the runtime).
+// One graph over all six streams saved another ~20 us per proof but crashed inside hipGraphLaunch
+// (hip::Graph::UpdateStreams) about once in ten processes after earlier contexts had come and gone; linear
+// single-stream graphs have no parallel branches for the runtime to re-map.
 struct ProveWs {
     DevBuf z, a, b, c;
     hipStream_t stream = nullptr;          // witness map, then the h MSM; everything is joined back into it
@@ -44,11 +49,26 @@ struct ProveWs {
     GroupEngine *me[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     void *h_z = nullptr; // pinned staging of the assignment
     size_t h_z_cap = 0;
-    hipGraphExec_t exec = nullptr;
+    hipGraphExec_t g_all = nullptr;                                         // "single" mode: the whole proof, all streams
+    hipGraphExec_t g_wm = nullptr;                                          // witness map body (main stream)
+    hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
+    bool graphs_ready = false;
+    u32 k = 1; // proofs per pass (the slot's buffers and its captured graph are sized for exactly this batch)
     int eager_runs = 0;
     bool no_graph = false;
+    void drop_graphs() {
+        if (g_all) hipGraphExecDestroy(g_all);
+        g_all = nullptr;
+        if (g_wm) hipGraphExecDestroy(g_wm);
+        g_wm = nullptr;
+        for (int i = 0; i < 5; ++i) {
+            if (g_msm[i]) hipGraphExecDestroy(g_msm[i]);
+            g_msm[i] = nullptr;
+        }
+        graphs_ready = false;
+    }
     ~ProveWs() {
-        if (exec) hipGraphExecDestroy(exec);
+        drop_graphs();
         for (int i = 0; i < 5; ++i)
             if (mw[i]) {
                 mw[i]->run_on = nullptr;
@@ -70,15 +90,27 @@ struct ProveWs {
 static int prove_streams() {
     static const int n = [] {
         const char *e = std::getenv("MANTA_PROVE_STREAMS");
-        return e && std::atoi(e) == 3 ? 3 : 6;
+        const int v = e ? std::atoi(e) : 6;
+        return v == 1 || v == 3 ? v : 6;
     }();
     return n;
 }
 
-static bool graphs_enabled() {
-    static const bool on = std::getenv("MANTA_NO_GRAPH") == nullptr;
-    return on;
+// MANTA_GRAPH = single (default): one captured graph for the whole proof (fork/join over all streams);
+//               split: six single-stream graphs (witness map + one per MSM) with eager event fork/join;
+//               off (or MANTA_NO_GRAPH): plain stream launches
+enum GraphMode { GRAPH_OFF = 0, GRAPH_SINGLE = 1, GRAPH_SPLIT = 2 };
+static GraphMode graph_mode() {
+    static const GraphMode m = [] {
+        if (std::getenv("MANTA_NO_GRAPH")) return GRAPH_OFF;
+        const char *e = std::getenv("MANTA_GRAPH");
+        if (!e) return GRAPH_SINGLE;
+        if (!std::strcmp(e, "off")) return GRAPH_OFF;
+        return std::strcmp(e, "split") ? GRAPH_SINGLE : GRAPH_SPLIT;
+    }();
+    return m;
 }
+static bool graphs_enabled() { return graph_mode() != GRAPH_OFF; }
 
 class ProverImpl : public Prover {
   public:
@@ -95,7 +127,7 @@ class ProverImpl : public Prover {
     DevCsr A_, B_, C_;
     std::vector<u32> h_query_host_; // kept until the domain size is known (set_r1cs), then re-laid
     std::mutex mu_;
-    std::vector<ProveWs *> ws_free_;
+    std::map<u32, std::vector<ProveWs *>> ws_free_; // idle proof slots, by batch size
 
     ~ProverImpl() override {
         // (h_bs_ is created by set_r1cs)
@@ -109,7 +141,8 @@ class ProverImpl : public Prover {
         free_csr(A_);
         free_csr(B_);
         free_csr(C_);
-        for (ProveWs *w : ws_free_) delete w;
+        for (auto &kv : ws_free_)
+            for (ProveWs *w : kv.second) delete w;
     }
     static void free_csr(DevCsr &M) {
         if (M.row_ptr) hipFree(M.row_ptr);
@@ -214,7 +247,8 @@ class ProverImpl : public Prover {
             if ((rc = g1_->bases_create(perm.data(), D, false, pre_c_for(D), &h_bs_))) return rc;
         }
         // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them
-        for (ProveWs *w : ws_free_) delete w;
+        for (auto &kv : ws_free_)
+            for (ProveWs *w : kv.second) delete w;
         ws_free_.clear();
         m_ = m;
         log_d_ = lg;
@@ -222,16 +256,18 @@ class ProverImpl : public Prover {
         return MG_OK;
     }
 
-    ProveWs *ws_acquire() {
+    ProveWs *ws_acquire(u32 k = 1) {
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (!ws_free_.empty()) {
-                ProveWs *w = ws_free_.back();
-                ws_free_.pop_back();
+            auto it = ws_free_.find(k);
+            if (it != ws_free_.end() && !it->second.empty()) {
+                ProveWs *w = it->second.back();
+                it->second.pop_back();
                 return w;
             }
         }
         ProveWs *w = new ProveWs();
+        w->k = k;
         if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
             !(w->side[1] = stream_pool_get()) || hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess) {
@@ -258,36 +294,62 @@ class ProverImpl : public Prover {
             w->mw[2]->run_on = w->side[0];
             w->mw[3]->run_on = w->side[1];
             w->mw[4]->run_on = w->stream;
+        } else if (prove_streams() == 1) {
+            for (int i = 0; i < 5; ++i) w->mw[i]->run_on = w->stream;
         }
         return w;
     }
     void ws_release(ProveWs *w) {
         std::lock_guard<std::mutex> g(mu_);
-        ws_free_.push_back(w);
+        ws_free_[w->k].push_back(w);
     }
 
-    // enqueue H2D(z) + witness map on w->stream; h ends up in w->a
-    int launch_witness_map(ProveWs *w, const uint64_t *z) {
-        const size_t D = (size_t)1 << log_d_;
+    // Witness map for the slot's w->k assignments (stored back to back, like the three work vectors: member q of
+    // a batch lives V resp. D elements after member q-1); h ends up in w->a.
+    int reserve_witness_map(ProveWs *w) {
+        const size_t D = (size_t)1 << log_d_, k = w->k;
         int rc;
-        if ((rc = w->z.reserve(V_ * 32)) || (rc = w->a.reserve(D * 32)) || (rc = w->b.reserve(D * 32)) ||
-            (rc = w->c.reserve(D * 32)))
+        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(k * D * 32)) || (rc = w->b.reserve(k * D * 32)) ||
+            (rc = w->c.reserve(k * D * 32)))
             return rc;
+        return MG_OK;
+    }
+    // everything after the upload of z, on w->stream (this is what the witness-map graph captures)
+    int enqueue_witness_map_body(ProveWs *w) {
+        const size_t D = (size_t)1 << log_d_, k = w->k;
+        int rc;
         hipStream_t s = w->stream;
-        MG_HIP(hipMemcpyAsync(w->z.p, z, V_ * 32, hipMemcpyHostToDevice, s));
-        MG_HIP(hipEventRecord(w->z_ready, s));
-        MG_HIP(hipMemsetAsync(w->a.p, 0, D * 32, s));
-        MG_HIP(hipMemsetAsync(w->b.p, 0, D * 32, s));
-        MG_HIP(hipMemsetAsync(w->c.p, 0, D * 32, s));
+        MG_HIP(hipMemsetAsync(w->a.p, 0, k * D * 32, s));
+        MG_HIP(hipMemsetAsync(w->b.p, 0, k * D * 32, s));
+        MG_HIP(hipMemsetAsync(w->c.p, 0, k * D * 32, s));
         u32 *a = w->a.as<u32>(), *b = w->b.as<u32>(), *c = w->c.as<u32>(), *zz = w->z.as<u32>();
-        if ((rc = fr_->spmv(A_, zz, a, m_, s)) || (rc = fr_->spmv(B_, zz, b, m_, s)) ||
-            (rc = fr_->spmv(C_, zz, c, m_, s)))
+        const size_t zs = (size_t)V_ * 8, ds = D * 8;
+        if ((rc = fr_->spmv(A_, zz, a, m_, s, (u32)k, zs, ds)) || (rc = fr_->spmv(B_, zz, b, m_, s, (u32)k, zs, ds)) ||
+            (rc = fr_->spmv(C_, zz, c, m_, s, (u32)k, zs, ds)))
             return rc;
         // input-consistency rows: a[m + j] = z_j for j < P (mpc.rs:299-312)
-        MG_HIP(hipMemcpyAsync(a + (size_t)m_ * 8, zz, P_ * 32, hipMemcpyDeviceToDevice, s));
+        MG_HIP(hipMemcpy2DAsync(a + (size_t)m_ * 8, D * 32, zz, V_ * 32, P_ * 32, k, hipMemcpyDeviceToDevice, s));
         // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
-        if ((rc = fr_->qap_quotient(a, b, c, log_d_, s))) return rc;
-        MG_HIP(hipEventRecord(w->h_ready, s));
+        if ((rc = fr_->qap_quotient(a, b, c, log_d_, s, (u32)k))) return rc;
+        return MG_OK;
+    }
+    // H2D(z), recording z_ready
+    int upload_z(ProveWs *w, const uint64_t *z) {
+        int rc = reserve_witness_map(w);
+        if (rc) return rc;
+        MG_HIP(hipMemcpyAsync(w->z.p, z, (size_t)w->k * V_ * 32, hipMemcpyHostToDevice, w->stream));
+        MG_HIP(hipEventRecord(w->z_ready, w->stream));
+        return MG_OK;
+    }
+    // witness map after upload_z; records h_ready at the end
+    int launch_witness_map(ProveWs *w, bool use_graph = false) {
+        int rc;
+        if (use_graph) {
+            MG_HIP(hipGraphLaunch(w->g_wm, w->stream));
+        } else if ((rc = enqueue_witness_map_body(w))) {
+            return rc;
+        }
+        MG_HIP(hipEventRecord(w->h_ready, w->stream));
         return MG_OK;
     }
 
@@ -295,7 +357,8 @@ class ProverImpl : public Prover {
         if (!have_r1cs_) return MG_ERR_STATE;
         ProveWs *w = ws_acquire();
         if (!w) return MG_ERR_HIP;
-        int rc = launch_witness_map(w, z);
+        int rc = upload_z(w, z);
+        if (!rc) rc = launch_witness_map(w);
         if (!rc) {
             const size_t D = (size_t)1 << log_d_;
             std::vector<uint64_t> tmp(D * 4);
@@ -318,103 +381,162 @@ class ProverImpl : public Prover {
         return rc;
     }
 
-    // enqueue the whole GPU side of one proof: witness map on w->stream, the five MSMs forked onto their own
-    // streams and joined back. Identical in eager mode and under stream capture.
-    int enqueue_proof(ProveWs *w, const uint64_t *z_src) {
+    struct MsmArgs {
+        const BaseSet *bs[5];
+        const u32 *sc[5];
+        size_t cnt[5], stride[5];
+    };
+    MsmArgs msm_args(const ProveWs *w) const {
         const size_t D = (size_t)1 << log_d_;
-        int rc = launch_witness_map(w, z_src);
-        if (rc) return rc;
         const u32 *dz = w->z.as<u32>();
-        const BaseSet *bs[5] = {a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_};
-        const u32 *sc[5] = {dz + 8, dz + 8, dz + 8, dz + (size_t)P_ * 8, w->a.as<u32>()};
-        const size_t cnt[5] = {(size_t)V_ - 1, (size_t)V_ - 1, (size_t)V_ - 1, (size_t)(V_ - P_), D};
+        // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
+        // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
+        return MsmArgs{{a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_},
+                       {dz + 8, dz + 8, dz + 8, dz + (size_t)P_ * 8, w->a.as<u32>()},
+                       {(size_t)V_ - 1, (size_t)V_ - 1, (size_t)V_ - 1, (size_t)(V_ - P_), D},
+                       {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * 8}};
+    }
+    static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
+
+    // enqueue the whole GPU side of one proof: witness map on w->stream, the five MSMs forked onto their
+    // streams with events and joined back. use_graphs replays the captured per-stream graphs instead of
+    // enqueuing the kernels; the event structure is identical.
+    int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
+        int rc = upload_z(w, z_src);
+        if (rc) return rc;
+        const MsmArgs a = msm_args(w);
+        // the witness map goes first: witness map -> h MSM is as long a chain as the G2 MSM (measured: enqueuing
+        // the G2 MSM ahead of it costs 0.3 ms per proof)
+        if ((rc = launch_witness_map(w, use_graphs))) return rc;
         for (int i = 0; i < 5; ++i) {
-            // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
-            // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-            hipStream_t ms = w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream;
+            hipStream_t ms = msm_stream(w, i);
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->z_ready, 0));
-            if ((rc = w->me[i]->msm_launch(bs[i], sc[i], cnt[i], true, 0, w->mw[i]))) return rc;
+            if (use_graphs) {
+                MG_HIP(hipGraphLaunch(w->g_msm[i], ms));
+                MG_HIP(hipEventRecord(w->mw[i]->done, ms));
+                w->mw[i]->pending = 1;
+            } else if ((rc = w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]))) {
+                return rc;
+            }
         }
         for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
-            hipStream_t ms = w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream;
+            hipStream_t ms = msm_stream(w, i);
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         return MG_OK;
     }
 
+    // capture one single-stream segment into an executable graph
+    template <class Fn> static bool capture_segment(hipStream_t s, hipGraphExec_t *out, Fn &&body) {
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+        const int rc = body();
+        hipGraph_t graph = nullptr;
+        const hipError_t e = hipStreamEndCapture(s, &graph);
+        bool ok = !rc && e == hipSuccess && graph && hipGraphInstantiate(out, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) hipGraphDestroy(graph);
+        if (!ok) {
+            *out = nullptr;
+            (void)hipGetLastError();
+        }
+        return ok;
+    }
+    // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
+    bool build_graphs(ProveWs *w) {
+        if (graph_mode() == GRAPH_SINGLE) {
+            const bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_proof(w, (const uint64_t *)w->h_z, false); });
+            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
+            if (!ok1) w->no_graph = true;
+            w->graphs_ready = ok1;
+            return ok1;
+        }
+        bool ok = capture_segment(w->stream, &w->g_wm, [&] { return enqueue_witness_map_body(w); });
+        const MsmArgs a = msm_args(w);
+        for (int i = 0; ok && i < 5; ++i) {
+            w->mw[i]->capturing = true; // no event records inside the capture: the replay path records `done`
+            ok = capture_segment(msm_stream(w, i), &w->g_msm[i], [&] {
+                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]);
+            });
+            w->mw[i]->capturing = false;
+            w->mw[i]->pending = 0;
+        }
+        if (!ok) {
+            w->drop_graphs();
+            w->no_graph = true;
+        }
+        w->graphs_ready = ok;
+        return ok;
+    }
+
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
+        return prove_batch(1, z, r, s, proof_out);
+    }
+
+    // k proofs of this circuit in ONE pass of the GPU pipeline (k = 1: a single proof). The kernels are the same;
+    // every (assignment, window) pair is its own bucket segment and the NTT / SpMV grids get a batch dimension,
+    // so a batch costs one chain of latency-bound launches instead of k.
+    int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (!have_r1cs_) return MG_ERR_STATE;
-        ProveWs *w = ws_acquire();
+        if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
+        const u32 k = (u32)k64;
+        ProveWs *w = ws_acquire(k);
         if (!w) return MG_ERR_HIP;
-        const bool r_zero = (r[0] | r[1] | r[2] | r[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
         int rc = MG_OK;
-        if (w->h_z_cap < V_ * 32) {
+        const size_t zbytes = (size_t)k * V_ * 32;
+        if (w->h_z_cap < zbytes) {
             if (w->h_z) hipHostFree(w->h_z);
             w->h_z = nullptr;
             w->h_z_cap = 0;
-            if (hipHostMalloc(&w->h_z, V_ * 32, hipHostMallocDefault) != hipSuccess) {
+            if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) {
                 ws_release(w);
                 return MG_ERR_OOM;
             }
-            w->h_z_cap = V_ * 32;
+            w->h_z_cap = zbytes;
         }
-        std::memcpy(w->h_z, z, V_ * 32);
-        bool launched = false;
-        if (w->exec) {
-            hipError_t e = hipGraphLaunch(w->exec, w->stream);
+        std::memcpy(w->h_z, z, zbytes);
+        if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2) build_graphs(w);
+        if (w->graphs_ready && w->g_all) {
+            hipError_t e = hipGraphLaunch(w->g_all, w->stream);
             if (e == hipSuccess) {
                 for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
-                launched = true;
             } else {
-                hipGraphExecDestroy(w->exec);
-                w->exec = nullptr;
+                set_last_hip_error(e, "hipGraphLaunch(proof)", __FILE__, __LINE__);
+                rc = MG_ERR_HIP;
+                w->drop_graphs();
                 w->no_graph = true;
             }
-        } else if (graphs_enabled() && !w->no_graph && w->eager_runs >= 2) {
-            // every buffer has its final size: capture this proof's launches and replay them from now on
-            if (hipStreamBeginCapture(w->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                int crc = enqueue_proof(w, (const uint64_t *)w->h_z);
-                hipGraph_t graph = nullptr;
-                hipError_t e = hipStreamEndCapture(w->stream, &graph);
-                if (!crc && e == hipSuccess && graph &&
-                    hipGraphInstantiate(&w->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                    hipGraphDestroy(graph);
-                    if (hipGraphLaunch(w->exec, w->stream) == hipSuccess) {
-                        for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
-                        launched = true;
-                    }
-                } else {
-                    if (graph) hipGraphDestroy(graph);
-                    w->exec = nullptr;
-                }
-                if (!launched) {
-                    (void)hipGetLastError();
-                    w->no_graph = true;
-                    for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
-                }
-            } else {
+        } else if (w->graphs_ready) {
+            rc = enqueue_proof(w, (const uint64_t *)w->h_z, true);
+            if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
+                hipStreamSynchronize(w->stream);
+                w->drop_graphs();
                 w->no_graph = true;
             }
-        }
-        if (!launched) {
-            rc = enqueue_proof(w, (const uint64_t *)w->h_z);
+        } else {
+            rc = enqueue_proof(w, (const uint64_t *)w->h_z, false);
             w->eager_runs++;
         }
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
         // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2 are fixed-base (64 table additions each)
-        u64 rc4[4], sc4[4], rs_m[4], rs4[4];
-        HostPoint t_rd, t_sd, t_rsd, t_sd2;
+        struct Blind {
+            u64 rc4[4], sc4[4], rs4[4];
+            HostPoint t_rd, t_sd, t_rsd, t_sd2;
+        };
+        std::vector<Blind> bl(k);
         if (!rc) {
-            fr_->fr_to_canonical(r, rc4);
-            fr_->fr_to_canonical(s, sc4);
-            fr_->fr_mul(r, s, rs_m);
-            fr_->fr_to_canonical(rs_m, rs4);
-            g1_->hp_table_mul(delta1_tab_, rc4, &t_rd);
-            g1_->hp_table_mul(delta1_tab_, sc4, &t_sd);
-            g1_->hp_table_mul(delta1_tab_, rs4, &t_rsd);
-            g2_->hp_table_mul(delta2_tab_, sc4, &t_sd2);
+            for (u32 q = 0; q < k; ++q) {
+                Blind &b = bl[q];
+                u64 rs_m[4];
+                fr_->fr_to_canonical(r + 4 * q, b.rc4);
+                fr_->fr_to_canonical(s + 4 * q, b.sc4);
+                fr_->fr_mul(r + 4 * q, s + 4 * q, rs_m);
+                fr_->fr_to_canonical(rs_m, b.rs4);
+                g1_->hp_table_mul(delta1_tab_, b.rc4, &b.t_rd);
+                g1_->hp_table_mul(delta1_tab_, b.sc4, &b.t_sd);
+                g1_->hp_table_mul(delta1_tab_, b.rs4, &b.t_rsd);
+                g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
+            }
         }
-        HostPoint res[5];
+        std::vector<HostPoint> res((size_t)5 * k); // res[i * k + q]: MSM i of proof q
         {
             hipError_t e = hipStreamSynchronize(w->stream); // every MSM stream has been joined into it
             if (e != hipSuccess && !rc) {
@@ -423,7 +545,7 @@ class ProverImpl : public Prover {
             }
             for (int i = 0; i < 5; ++i) {
                 if (w->mw[i]->pending) {
-                    int rc2 = w->me[i]->msm_finish(w->mw[i], &res[i], true);
+                    int rc2 = w->me[i]->msm_finish(w->mw[i], &res[(size_t)i * k], true);
                     if (!rc) rc = rc2;
                 } else {
                     hipStreamSynchronize(w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream);
@@ -435,29 +557,35 @@ class ProverImpl : public Prover {
         if (rc) return rc;
 
         // ---- serial assembly on the host
-        HostPoint g_a = res[0];
-        g1_->hp_add(&g_a, &a0_alpha_);
-        g1_->hp_add(&g_a, &t_rd);
-        HostPoint g1_b;
-        g1_->hp_set_inf(&g1_b);
-        if (!r_zero) {
-            g1_b = res[1];
-            g1_->hp_add(&g1_b, &b10_beta_);
-            g1_->hp_add(&g1_b, &t_sd);
-        }
-        HostPoint g2_b = res[2];
-        g2_->hp_add(&g2_b, &b20_beta_);
-        g2_->hp_add(&g2_b, &t_sd2);
-        HostPoint g_c;
-        g1_->hp_mul2(&g_a, sc4, &g1_b, rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
-        g1_->hp_neg(&t_rsd);
-        g1_->hp_add(&g_c, &t_rsd);
-        g1_->hp_add(&g_c, &res[3]);
-        g1_->hp_add(&g_c, &res[4]);
         const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
-        g1_->hp_serialize(&g_a, proof_out, true);
-        g2_->hp_serialize(&g2_b, proof_out + b1, true);
-        g1_->hp_serialize(&g_c, proof_out + b1 + b2, true);
+        for (u32 q = 0; q < k; ++q) {
+            Blind &b = bl[q];
+            const uint64_t *rq = r + 4 * q;
+            const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
+            HostPoint g_a = res[0 * (size_t)k + q];
+            g1_->hp_add(&g_a, &a0_alpha_);
+            g1_->hp_add(&g_a, &b.t_rd);
+            HostPoint g1_b;
+            g1_->hp_set_inf(&g1_b);
+            if (!r_zero) {
+                g1_b = res[1 * (size_t)k + q];
+                g1_->hp_add(&g1_b, &b10_beta_);
+                g1_->hp_add(&g1_b, &b.t_sd);
+            }
+            HostPoint g2_b = res[2 * (size_t)k + q];
+            g2_->hp_add(&g2_b, &b20_beta_);
+            g2_->hp_add(&g2_b, &b.t_sd2);
+            HostPoint g_c;
+            g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
+            g1_->hp_neg(&b.t_rsd);
+            g1_->hp_add(&g_c, &b.t_rsd);
+            g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
+            g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
+            uint8_t *out = proofs_out + (size_t)q * (2 * b1 + b2);
+            g1_->hp_serialize(&g_a, out, true);
+            g2_->hp_serialize(&g2_b, out + b1, true);
+            g1_->hp_serialize(&g_c, out + b1 + b2, true);
+        }
         return MG_OK;
     }
 };

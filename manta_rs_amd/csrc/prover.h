@@ -19,10 +19,13 @@ class FrEngine {
     // (ark-poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place semantics).
     virtual int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) = 0;
     // out[i] = sum_k val[k] * z[col[k]] over row i, i < m
-    virtual int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s) = 0;
+    // (batch members: z vectors z_stride u32 apart, outputs out_stride u32 apart)
+    virtual int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s, u32 batch = 1,
+                     size_t z_stride = 0, size_t out_stride = 0) = 0;
     // a, b, c = constraint evaluations over the domain -> a = coefficients of h = (AB - C)/Z in
     // bit-reversed order (ifft, coset fft x3, pointwise, coset ifft; fused, permutation-free)
-    virtual int qap_quotient(u32 *d_a, u32 *d_b, u32 *d_c, unsigned log_n, hipStream_t s) = 0;
+    // batch > 1: a, b, c each hold `batch` vectors back to back
+    virtual int qap_quotient(u32 *d_a, u32 *d_b, u32 *d_c, unsigned log_n, hipStream_t s, u32 batch = 1) = 0;
     // a[i] = (a[i]*b[i] - c[i]) * (g^D - 1)^-1
     virtual int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) = 0;
     // host-side Fr helpers (Montgomery in/out unless noted)
@@ -39,6 +42,9 @@ class Prover {
     virtual ~Prover() {}
     virtual int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) = 0;
     virtual int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) = 0;
+    // k proofs of the same circuit in one pass of the GPU pipeline: z = k assignments back to back, r and s = k
+    // field elements each, proofs_out = k encoded proofs back to back
+    virtual int prove_batch(u64 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) = 0;
     virtual int witness_map_host(const uint64_t *z, uint64_t *h_out) = 0;
     virtual u64 domain_size() const = 0;
 };

@@ -46,10 +46,15 @@ void DevBuf::release() {
     cap = 0;
 }
 
-// Streams that originate a graph capture are pooled for the life of the process and never destroyed: the
-// HIP runtime this library is loaded next to (libamdhip64 of ROCm 7.0) dereferences the destroyed origin
-// stream of an EARLIER capture inside hip::Graph::UpdateStreams when a LATER exec is launched (seen as a
-// segfault in hipGraphLaunch once a ProvingContext had been dropped and another one captured its proofs).
+// Proof-slot streams (the streams graphs are captured from and launched on) are HIGH-PRIORITY streams, pooled
+// for the life of the process and never destroyed. Both properties work around one defect of the HIP runtime
+// this library is loaded next to (libamdhip64 of ROCm 7.0, hip::Graph::UpdateStreams): when a multi-branch
+// graph is launched, the exec's internal parallel streams that share a hardware queue with the launch stream
+// are skipped, but only ONE spare stream exists -- if two of them alias the launch stream's queue the loop
+// reads past the vector and hipGraphLaunch segfaults (seen about once in ten processes after contexts had
+// come and gone; stream destruction unbalances the queue use counts and made it 7 in 8). The exec's internal
+// streams are normal-priority; a high-priority launch stream lives in the other hardware-queue pool and can
+// never alias them.
 static std::mutex g_stream_mu;
 static std::vector<hipStream_t> g_stream_pool;
 hipStream_t stream_pool_get() {
@@ -62,7 +67,9 @@ hipStream_t stream_pool_get() {
         }
     }
     hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
+    if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
     return s;
 }
 void stream_pool_put(hipStream_t s) {

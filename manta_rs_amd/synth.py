@@ -217,6 +217,38 @@ def make_circuit(curve: int, m: int, V: int, P: int, seed: int = 0x4D414E5441_00
                    to_mont(z, p, 4))
 
 
+def reassign(c: Circuit, seed: int) -> Circuit:
+    """Another satisfying assignment of the same circuit (same matrices): fresh instance values, fresh boolean
+    witnesses, every gate output recomputed from its defining row -- distinct proofs of one ProvingContext."""
+    p = FR_MODULUS[c.curve]
+    rng = XorShift(seed)
+    Rinv = pow(1 << 256, -1, p)
+
+    def rows(M):
+        vals = [v * Rinv % p for v in limbs_to_ints(M.val)] if len(M.col) else []
+        return [[(int(M.col[k]), vals[k]) for k in range(M.row_ptr[i], M.row_ptr[i + 1])] for i in range(c.m)]
+
+    A, B, C = rows(c.A), rows(c.B), rows(c.C)
+    z = [0] * c.V
+    z[0] = 1
+    for j in range(1, c.P):
+        z[j] = rng.field(p)
+    nw = c.V - c.P
+    for k in range(min(nw, c.m)):
+        v = c.P + k
+        if not C[k]:  # boolean witness: v * (1 - v) = 0
+            z[v] = rng.below(2)
+        else:         # gate with output v: (sum A)(sum B) = z[v]
+            sa = sum(cf * z[i] for i, cf in A[k]) % p
+            sb = sum(cf * z[i] for i, cf in B[k]) % p
+            assert C[k] == [(v, 1)]
+            z[v] = sa * sb % p
+    for k in range(c.m, nw):
+        z[c.P + k] = rng.field(p)
+    out = dataclasses.replace(c, z_int=z, z=to_mont(z, p, 4))
+    return out
+
+
 def make_shape(curve: int, name: str, seed: int = 0x4D414E5441_0001) -> Circuit:
     D, V, P = SHAPES[name]
     return make_circuit(curve, D - P, V, P, seed)

@@ -241,3 +241,42 @@ def test_contexts_created_and_dropped_between_captured_proofs(gpu):
             assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == want
         del ctx
         gc.collect()
+
+
+@pytest.mark.parametrize("curve,k", [(0, 1), (0, 3), (0, 8), (1, 2)])
+def test_prove_batch_matches_single_proofs_and_oracle(gpu, curve, k):
+    """mg_groth16_prove_batch: k different assignments of one circuit, different (r, s) each, one pass of the GPU
+    pipeline -- every proof byte-identical to the oracle's (and so to mg_groth16_prove)."""
+    c0 = synth.make_circuit(curve, 300, 260, 4, seed=60)
+    pk = O.groth16_setup(c0, H.toxic(curve, seed=11))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c0))
+    zs = [synth.reassign(c0, seed=200 + q) for q in range(k)]
+    rs = H.rand_fr_mont(curve, 2 * k, seed=79)
+    for rep in range(4):  # eager, eager, capture, replay
+        got = gpu.Groth16.prove_batch(ctx, np.stack([z.z for z in zs]), rs[:k], rs[k:])
+        assert len(got) == k
+        for q in range(k):
+            want = O.groth16_prove(zs[q], pk, rs[q], rs[k + q])
+            assert got[q] == want, (rep, q)
+            assert O.groth16_verify(curve, pk, zs[q].z[1:c0.P], got[q]) == 1
+    # interleave with single proofs on the same context (different slot pool)
+    assert gpu.Groth16.prove_with_randomness(ctx, zs[0].z, rs[0], rs[k]) == O.groth16_prove(zs[0], pk, rs[0], rs[k])
+
+
+def test_prove_batch_real_shape_with_r_zero_member(gpu):
+    """ToPrivate-shape circuit, batch of 4 with one member's r = 0 (that member skips g1_b like create_proof)."""
+    curve = 0
+    c = synth.make_shape(curve, "to_private")
+    pk = O.groth16_setup(c, H.toxic(curve, seed=12))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    k = 4
+    rs = H.rand_fr_mont(curve, 2 * k, seed=80).copy()
+    rs[2] = 0
+    zs = np.stack([c.z] * k)
+    got = gpu.Groth16.prove_batch(ctx, zs, rs[:k], rs[k:])
+    for q in range(k):
+        assert got[q] == O.groth16_prove(c, pk, rs[q], rs[k + q]), q
+    with pytest.raises(gpu.MantaGpuError):
+        gpu.Groth16.prove_batch(ctx, np.stack([c.z] * 2000), np.zeros((2000, 4), np.uint64), np.zeros((2000, 4), np.uint64))
