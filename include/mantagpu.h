@@ -87,6 +87,23 @@ int mg_points_sum(mg_curve_t curve, int group, const uint64_t *affine_mont, size
  * synthetic base generation; key generation as in ark-groth16 generate_parameters) */
 int mg_fixed_base_mul(mg_curve_t curve, int group, const uint64_t *base_affine_mont, const uint64_t *d_scalars,
                       size_t n, uint64_t *d_out_affine_mont);
+/* Element-wise group operations on host arrays of n affine points, computed on the GPU with the MSM kernels' own
+ * device functions (mixed / general addition, doubling, double-and-add) and normalised with the batched
+ * Montgomery-trick inversion -- the primitive menu the reference itself benchmarks and cross-checks
+ * (manta-benchmark/src/ecc.rs:30-128, consistency tests :138-172):
+ *   MG_EC_ADD_MIXED  out = a + b   `projective += affine`            (ecc.rs:69-74)
+ *   MG_EC_ADD        out = a + b   `projective += projective`        (ecc.rs:78-83)
+ *   MG_EC_DOUBLE     out = 2a      (b unused)
+ *   MG_EC_MUL        out = [k]a    b = n x 4 u64 canonical scalars   (ecc.rs:87-101)
+ *   MG_EC_SUB_MIXED  out = a - b
+ * out = n affine points (batch normalisation, ecc.rs:114-119). */
+#define MG_EC_ADD_MIXED 0
+#define MG_EC_ADD 1
+#define MG_EC_DOUBLE 2
+#define MG_EC_MUL 3
+#define MG_EC_SUB_MIXED 4
+int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t *a_affine, const uint64_t *b, size_t n,
+                      uint64_t *out_affine);
 /* arkworks canonical serialisation of one affine point (compressed: 32/48/64/96 B) */
 int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine_mont, int compressed, uint8_t *out);
 

@@ -53,7 +53,7 @@ _sz = ctypes.c_size_t
 EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
-    "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_point_serialize", "mg_ntt",
+    "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_ec_elementwise", "mg_point_serialize", "mg_ntt",
     "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
 ]
@@ -213,6 +213,20 @@ def points_sum(curve, group, points):
 def fixed_base_mul(curve, group, base, d_scalars: DeviceBuffer, n) -> DeviceBuffer:
     out = DeviceBuffer(n * affine_limbs(curve, group) * 8)
     _chk(LIB.mg_fixed_base_mul(curve, group, _p(_u64(base)), d_scalars.ptr, _sz(n), out.ptr), "mg_fixed_base_mul")
+    return out
+
+
+EC_ADD_MIXED, EC_ADD, EC_DOUBLE, EC_MUL, EC_SUB_MIXED = range(5)
+
+
+def ec_elementwise(curve, group, op, a, b=None) -> np.ndarray:
+    """Element-wise group operation on arrays of affine points (`mg_ec_elementwise`; the ecc.rs primitive menu):
+    a, b = [n, limbs] uint64 affine points (b = [n, 4] canonical scalars for EC_MUL, unused for EC_DOUBLE)."""
+    a = _u64(a)
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    bb = _p(_u64(b)) if b is not None else None
+    _chk(LIB.mg_ec_elementwise(curve, group, op, _p(a), bb, _sz(n), _p(out)), "mg_ec_elementwise")
     return out
 
 

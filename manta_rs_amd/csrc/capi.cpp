@@ -171,6 +171,14 @@ MG_API int mg_fixed_base_mul(mg_curve_t curve, int group, const uint64_t *base_a
     return e->fixed_base_mul((const u32 *)base_affine, (const u32 *)d_scalars, n, (u32 *)d_out_affine, nullptr);
     MG_CATCH
 }
+MG_API int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t *a_affine, const uint64_t *b,
+                             size_t n, uint64_t *out_affine) {
+    MG_TRY
+    GroupEngine *e = get_engine((int)curve, group);
+    if (!e) return MG_ERROR_INVALID_ARGUMENT;
+    return e->ec_elementwise(op, (const u32 *)a_affine, (const u32 *)b, n, (u32 *)out_affine);
+    MG_CATCH
+}
 MG_API int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine, int compressed, uint8_t *out) {
     MG_TRY
     GroupEngine *e = get_engine((int)curve, group);

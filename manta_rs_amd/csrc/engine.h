@@ -138,6 +138,9 @@ class GroupEngine {
     // synthetic base generation and key generation (fixed-base batch multiplication).
     virtual int fixed_base_mul(const u32 *base_affine_host, const u32 *d_scalars, size_t n, u32 *d_out_affine,
                                hipStream_t s) = 0;
+    // element-wise group operations on host arrays of affine points (the primitive menu of
+    // manta-benchmark/src/ecc.rs; op codes in mantagpu.h), run with the MSM kernels' device functions
+    virtual int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) = 0;
     // sum of affine points (device) -> host point
     virtual int sum_affine(const u32 *d_pts, size_t n, HostPoint *out) = 0;
 

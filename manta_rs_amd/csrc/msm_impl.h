@@ -457,6 +457,52 @@ __global__ __launch_bounds__(256) void fixed_base_mul_kernel(const u32 *__restri
     acc.store(out_xyzz + i * XYZZ<F>::WORDS);
 }
 
+// Element-wise group operations on arrays of affine points (arkworks format in, XYZZ in arkworks format out,
+// normalised by xyzz_to_affine_batch) computed with the MSM kernels' own device functions in their internal
+// field representation -- the primitive menu of manta-benchmark/src/ecc.rs:30-128 (mixed add :69-74, projective
+// add :78-83, scalar multiplication :87-101, batch normalisation :114-119) as a parity-test surface.
+//   op 0: P + Q via madd (projective += affine)      op 1: P + Q via the general add (projective += projective)
+//   op 2: 2P                                          op 3: [k]P, k = 4 x u64 canonical (double-and-add over madd)
+//   op 4: P - Q via madd with the negate flag
+template <class F>
+__global__ __launch_bounds__(256) void ec_elementwise_kernel(int op, const u32 *__restrict__ a, const u32 *__restrict__ b,
+                                                             size_t n, u32 *__restrict__ out_xyzz_std) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef typename F::Std S;
+    auto load_affine = [](const u32 *p) {
+        const Affine<S> s = Affine<S>::load(p);
+        Affine<F> r;
+        if (s.is_inf()) {
+            r.x = F::zero();
+            r.y = F::zero();
+        } else {
+            r.x = F::from_std(s.x);
+            r.y = F::from_std(s.y);
+        }
+        return r;
+    };
+    const Affine<F> pa = load_affine(a + i * Affine<S>::WORDS);
+    XYZZ<F> acc = XYZZ<F>::from_affine(pa);
+    if (op == 0 || op == 4) {
+        acc.madd(load_affine(b + i * Affine<S>::WORDS), op == 4);
+    } else if (op == 1) {
+        acc.add(XYZZ<F>::from_affine(load_affine(b + i * Affine<S>::WORDS)));
+    } else if (op == 2) {
+        acc = XYZZ<F>::dbl(acc);
+    } else {
+        acc = XYZZ<F>::inf();
+        for (int limb = 7; limb >= 0; --limb) {
+            const u32 w = b[i * 8 + limb];
+            for (int bit = 31; bit >= 0; --bit) {
+                acc = XYZZ<F>::dbl(acc);
+                if ((w >> bit) & 1) acc.madd(pa, false);
+            }
+        }
+    }
+    acc.store_std(out_xyzz_std + i * XYZZ<S>::WORDS);
+}
+
 // per-thread partial sums of affine points (strided), output XYZZ partials
 template <class F>
 __global__ __launch_bounds__(256) void sum_affine_kernel(const u32 *__restrict__ pts, size_t n, u32 T,
@@ -891,6 +937,34 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (e != hipSuccess) {
             set_last_hip_error(e, "fixed_base_mul", __FILE__, __LINE__);
             return MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+
+    int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) override {
+        if (op < 0 || op > 4 || !a_host || !out_affine_host || n == 0 || (op != 2 && !b_host)) return MG_ERR_ARG;
+        const size_t ab = n * AW_IO * 4, bb = op == 3 ? n * 32 : ab;
+        u32 *da = nullptr, *db = nullptr, *tmp = nullptr, *dout = nullptr;
+        hipError_t e = hipMalloc((void **)&da, ab);
+        if (e == hipSuccess) e = hipMalloc((void **)&db, bb);
+        if (e == hipSuccess) e = hipMalloc((void **)&tmp, n * XW_IO * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&dout, ab);
+        if (e == hipSuccess) e = hipMemcpy(da, a_host, ab, hipMemcpyHostToDevice);
+        if (e == hipSuccess && op != 2) e = hipMemcpy(db, b_host, bb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, op, da, db, n, tmp);
+            constexpr int KB = 16;
+            hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, 0, tmp, n, dout,
+                               (u32)AW_IO);
+            e = hipMemcpy(out_affine_host, dout, ab, hipMemcpyDeviceToHost);
+        }
+        hipFree(da);
+        hipFree(db);
+        hipFree(tmp);
+        hipFree(dout);
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "ec_elementwise", __FILE__, __LINE__);
+            return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
         }
         return MG_OK;
     }
