@@ -107,11 +107,10 @@ __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ sca
 // --------------------------------------------------------------------------------------------
 // K7a: chunk accumulate
 // --------------------------------------------------------------------------------------------
-#ifndef MG_ACC_WAVES
-#define MG_ACC_WAVES 1
-#endif
+// (179 VGPRs for BLS12-381 G1 -> two wavefronts per SIMD, which already saturates the integer pipe; forcing
+// three through the launch bounds spills and is slower, software-prefetching the gather changes nothing)
 template <class F>
-__global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+__global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
                                                          u32 astride, u32 *__restrict__ buckets,
                                                          u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T) {
@@ -128,21 +127,8 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
     }
     XYZZ<F> acc = XYZZ<F>::inf();
     bool first = true;
-#ifdef MG_ACC_PREFETCH
-    // software pipeline: the gather of entry j+1 is in flight while entry j is being added
-    u32 v_next = vals[begin];
-    Affine<F> p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * astride);
-#endif
     for (size_t j = begin; j < end; ++j) {
         const u32 k = keys[j];
-#ifdef MG_ACC_PREFETCH
-        const u32 v = v_next;
-        const Affine<F> p = p_next;
-        if (j + 1 < end) {
-            v_next = vals[j + 1];
-            p_next = Affine<F>::load(bases + (size_t)(v_next & 0x7fffffffu) * astride);
-        }
-#endif
         if (k != cur) {
             if (first) {
                 pkeys[2 * t] = cur;
@@ -155,10 +141,8 @@ __global__ __launch_bounds__(256, MG_ACC_WAVES) void accumulate_chunks(const u32
             cur = k;
             if (k == invalid) break;
         }
-#ifndef MG_ACC_PREFETCH
         const u32 v = vals[j];
         const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * astride);
-#endif
         acc.madd(p, (v >> 31) != 0);
     }
     if (first) { // the whole chunk is one run

@@ -280,3 +280,27 @@ def test_prove_batch_real_shape_with_r_zero_member(gpu):
         assert got[q] == O.groth16_prove(c, pk, rs[q], rs[k + q]), q
     with pytest.raises(gpu.MantaGpuError):
         gpu.Groth16.prove_batch(ctx, np.stack([c.z] * 2000), np.zeros((2000, 4), np.uint64), np.zeros((2000, 4), np.uint64))
+
+
+def test_prove_bls12_381_at_circuit_size(gpu):
+    """BLS12-381 (the curve of BASELINE's synthetic configs) at a real circuit size -- D = 2^15, V = 2^15 - 200:
+    the 14-limb reduced-radix G1/G2 kernels, precomputed c = 8 tables, hipGraph replay and a batch of 3, all
+    byte-identical to the oracle and pairing-verified. (D = V = 2^20 is `tools/config3_bls_2_20.py`.)"""
+    from manta_rs_amd import keygen
+    curve = 1
+    D = 1 << 15
+    c = synth.make_circuit(curve, D - 16, D - 200, 16, seed=0x4D414E5441_0005)
+    assert c.D == D
+    pk = keygen.generate(c, synth.from_mont(H.toxic(curve, seed=13), synth.FR_MODULUS[curve]))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(curve, 6, seed=555)
+    want = O.groth16_prove(c, pk, rs[0], rs[1])
+    for _ in range(4):  # eager, eager, capture, replay
+        assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == want
+    assert O.groth16_verify(curve, pk, c.z[1:c.P], want) == 1
+    got = gpu.Groth16.prove_batch(ctx, np.stack([c.z] * 3), rs[0:6:2], rs[1:6:2])
+    assert got[0] == want
+    for q in (1, 2):
+        assert got[q] == O.groth16_prove(c, pk, rs[2 * q], rs[2 * q + 1])
+        assert O.groth16_verify(curve, pk, c.z[1:c.P], got[q]) == 1
