@@ -121,6 +121,7 @@ class ProverImpl : public Prover {
     unsigned log_d_ = 0;
     bool have_r1cs_ = false;
     BaseSet *a_bs_ = nullptr, *b1_bs_ = nullptr, *b2_bs_ = nullptr, *h_bs_ = nullptr, *l_bs_ = nullptr;
+    BaseSet *h_bs_wide_ = nullptr; // the h query again with wider windows, for batched passes (nullptr: same as h_bs_)
     HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
     HostPoint a0_alpha_, b10_beta_, b20_beta_; // constant terms of g_a, g1_b, g2_b folded once
     void *delta1_tab_ = nullptr, *delta2_tab_ = nullptr; // fixed-base tables for r*delta, s*delta, rs*delta
@@ -134,6 +135,7 @@ class ProverImpl : public Prover {
         if (a_bs_) g1_->bases_destroy(a_bs_);
         if (b1_bs_) g1_->bases_destroy(b1_bs_);
         if (h_bs_) g1_->bases_destroy(h_bs_);
+        if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
         if (l_bs_) g1_->bases_destroy(l_bs_);
         if (b2_bs_) g2_->bases_destroy(b2_bs_);
         if (delta1_tab_) g1_->hp_table_free(delta1_tab_);
@@ -243,8 +245,17 @@ class ProverImpl : public Prover {
                 if (src < h_len_) std::memcpy(&perm[p * w1], &h_query_host_[src * w1], w1 * 4);
             }
             if (h_bs_) g1_->bases_destroy(h_bs_);
-            h_bs_ = nullptr;
-            if ((rc = g1_->bases_create(perm.data(), D, false, pre_c_for(D), &h_bs_))) return rc;
+            if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
+            h_bs_ = h_bs_wide_ = nullptr;
+            // The h MSM is the one with dense, uniform scalars -- half of all the mixed additions of a proof at
+            // c = 8. Wider windows halve them, but lengthen its bucket reduce: measured on PrivateTransfer,
+            // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32) but 2-5 % slower
+            // single proofs. The table is small (80 MB), so single proofs keep c = 8 and batches get their own.
+            int ch = pre_c_for(D), ch_wide = ch;
+            if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
+            if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
+            if ((rc = g1_->bases_create(perm.data(), D, false, ch, &h_bs_))) return rc;
+            if (ch_wide != ch && (rc = g1_->bases_create(perm.data(), D, false, ch_wide, &h_bs_wide_))) return rc;
         }
         // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them
         for (auto &kv : ws_free_)
@@ -391,7 +402,7 @@ class ProverImpl : public Prover {
         const u32 *dz = w->z.as<u32>();
         // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
         // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-        return MsmArgs{{a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_},
+        return MsmArgs{{a_bs_, b1_bs_, b2_bs_, l_bs_, (w->k >= 4 && h_bs_wide_) ? h_bs_wide_ : h_bs_},
                        {dz + 8, dz + 8, dz + 8, dz + (size_t)P_ * 8, w->a.as<u32>()},
                        {(size_t)V_ - 1, (size_t)V_ - 1, (size_t)V_ - 1, (size_t)(V_ - P_), D},
                        {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * 8}};
