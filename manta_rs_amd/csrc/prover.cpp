@@ -484,12 +484,28 @@ class ProverImpl : public Prover {
 
     // k proofs of this circuit in ONE pass of the GPU pipeline (k = 1: a single proof). The kernels are the same;
     // every (assignment, window) pair is its own bucket segment and the NTT / SpMV grids get a batch dimension,
-    // so a batch costs one chain of latency-bound launches instead of k.
+    // so a batch costs one chain of latency-bound launches instead of k. (Splitting a batch into two passes in
+    // flight, to assemble one half on the host while the GPU works on the other, was measured and gains nothing:
+    // the smaller passes lose what the overlap wins. Two calling threads with a batch each do overlap.)
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (!have_r1cs_) return MG_ERR_STATE;
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
-        const u32 k = (u32)k64;
-        ProveWs *w = ws_acquire(k);
+        Pass p;
+        const int rc = launch_pass(p, (u32)k64, z, r, s, proofs_out);
+        return finish_pass(p, rc);
+    }
+
+    struct Pass {
+        ProveWs *w = nullptr;
+        u32 k = 0;
+        const uint64_t *r = nullptr, *s = nullptr;
+        uint8_t *out = nullptr;
+    };
+
+    // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
+    int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out) {
+        p.k = k, p.r = r, p.s = s, p.out = out;
+        ProveWs *w = p.w = ws_acquire(k);
         if (!w) return MG_ERR_HIP;
         int rc = MG_OK;
         const size_t zbytes = (size_t)k * V_ * 32;
@@ -497,10 +513,7 @@ class ProverImpl : public Prover {
             if (w->h_z) hipHostFree(w->h_z);
             w->h_z = nullptr;
             w->h_z_cap = 0;
-            if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) {
-                ws_release(w);
-                return MG_ERR_OOM;
-            }
+            if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) return MG_ERR_OOM;
             w->h_z_cap = zbytes;
         }
         std::memcpy(w->h_z, z, zbytes);
@@ -526,6 +539,15 @@ class ProverImpl : public Prover {
             rc = enqueue_proof(w, (const uint64_t *)w->h_z, false);
             w->eager_runs++;
         }
+        return rc;
+    }
+
+    // host side of a pass: blinding terms while the GPU works, wait, fold the MSM results, assemble and encode
+    int finish_pass(Pass &p, int rc) {
+        ProveWs *w = p.w;
+        if (!w) return rc ? rc : MG_ERR_HIP;
+        const u32 k = p.k;
+        const uint64_t *r = p.r, *s = p.s;
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
         // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2 are fixed-base (64 table additions each)
         struct Blind {
@@ -565,6 +587,7 @@ class ProverImpl : public Prover {
             }
         }
         ws_release(w);
+        p.w = nullptr;
         if (rc) return rc;
 
         // ---- serial assembly on the host
@@ -592,7 +615,7 @@ class ProverImpl : public Prover {
             g1_->hp_add(&g_c, &b.t_rsd);
             g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
             g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
-            uint8_t *out = proofs_out + (size_t)q * (2 * b1 + b2);
+            uint8_t *out = p.out + (size_t)q * (2 * b1 + b2);
             g1_->hp_serialize(&g_a, out, true);
             g2_->hp_serialize(&g2_b, out + b1, true);
             g1_->hp_serialize(&g_c, out + b1 + b2, true);
