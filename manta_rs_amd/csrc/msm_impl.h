@@ -702,13 +702,16 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             p.Wb = p.W;
         }
         p.B = 1u << (p.c - 1);
-        // entries per lane: one full round of lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131k) when the MSM is
-        // large, never fewer than 8 per lane; longer chunks mean fewer partials for the merge levels
-        // (measured at 2^20: L = 64 / 128 / 192 / 256 -> 295 / 312 / 316 / 301 Mscalar/s)
+        // entries per lane. Large MSMs: one full round of lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131k), longer
+        // chunks mean fewer partials for the merge levels (measured at 2^20: L = 64 / 128 / 192 / 256 -> 295 / 312 /
+        // 316 / 301 Mscalar/s). Proof-sized MSMs are latency chains -- L mixed additions, then the merge levels --
+        // and shorter chunks shorten the chain (PrivateTransfer: L = 4 / 6 / 8 / 11 / 16 -> 581 / 610 / 595 / 573 /
+        // 564 proofs/s), so they get twice the lanes, never fewer than 6 entries each.
         const size_t M = n * (size_t)p.W * batch;
-        size_t L = M / (96 * 1024);
-        if (L < 8) L = 8;
+        size_t L = M < ((size_t)8 << 20) ? M / (192 * 1024) : M / (96 * 1024);
+        if (L < 6) L = 6;
         if (L > 192) L = 192;
+        if (batch > 1 && L > 96) L = 96; // batched proofs: most digit entries are invalid (sorted last), keep the lanes plentiful
         if (const char *e = getenv("MANTA_MSM_L")) L = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : L;
         p.L = (u32)L;
         return p;
