@@ -702,16 +702,25 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             p.Wb = p.W;
         }
         p.B = 1u << (p.c - 1);
-        // entries per lane. Large MSMs: one full round of lanes (256 CUs x 4 SIMDs x 2 waves x 64 = 131k), longer
-        // chunks mean fewer partials for the merge levels (measured at 2^20: L = 64 / 128 / 192 / 256 -> 295 / 312 /
-        // 316 / 301 Mscalar/s). Proof-sized MSMs are latency chains -- L mixed additions, then the merge levels --
-        // and shorter chunks shorten the chain (PrivateTransfer: L = 4 / 6 / 8 / 11 / 16 -> 581 / 610 / 595 / 573 /
-        // 564 proofs/s), so they get twice the lanes, never fewer than 6 entries each.
+        // entries per lane. Large MSMs: the grid is a whole number of rounds of 2 wavefronts per SIMD (256 CUs x
+        // 4 SIMDs x 2 x 64 = 131 072 lanes) -- the accumulate kernel holds two waves per SIMD, so 1.5 rounds leave
+        // half the SIMDs idle for a third of the kernel (measured at 2^20, stand-alone kernel: L = 128 -> 2.94 ms,
+        // L = 170 (1536 waves) -> 3.71 ms, L = 192 -> 4.14 ms; 328 / 322 / 327 Mscalar/s pipelined, 248 / 212 / 194
+        // one MSM at a time). Longer chunks mean fewer partials for the merge levels, hence as few rounds as keep
+        // L <= 192. Proof-sized MSMs are latency chains -- L mixed additions, then the merge levels -- and shorter
+        // chunks shorten the chain (PrivateTransfer: L = 4 / 6 / 8 / 11 / 16 -> 581 / 610 / 595 / 573 / 564
+        // proofs/s), so they get twice the lanes, never fewer than 6 entries each. Batched proofs: most digit
+        // entries are invalid (sorted last), so the lanes are kept plentiful (L <= 96).
         const size_t M = n * (size_t)p.W * batch;
-        size_t L = M < ((size_t)8 << 20) ? M / (192 * 1024) : M / (96 * 1024);
-        if (L < 6) L = 6;
-        if (L > 192) L = 192;
-        if (batch > 1 && L > 96) L = 96; // batched proofs: most digit entries are invalid (sorted last), keep the lanes plentiful
+        size_t L;
+        if (M < ((size_t)8 << 20)) {
+            L = M / (192 * 1024);
+            if (L < 6) L = 6;
+        } else {
+            const size_t round = 128 * 1024, lmax = batch > 1 ? 96 : 192;
+            const size_t rounds = (M + round * lmax - 1) / (round * lmax);
+            L = (M + round * rounds - 1) / (round * rounds);
+        }
         if (const char *e = getenv("MANTA_MSM_L")) L = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : L;
         p.L = (u32)L;
         return p;
