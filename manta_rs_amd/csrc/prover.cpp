@@ -33,23 +33,25 @@ FrEngine *get_ntt_engine(int curve) {
 namespace {
 
 // One in-flight proof (or batch of proofs): device scratch for the witness map, its five MSM workspaces (each
-// with its own stream), a pinned copy of z, and -- after two eager runs that size every buffer -- six captured
-// hipGraphs: the witness map and each MSM, every one a SINGLE-stream capture replayed on its own stream with
-// the same event fork/join as the eager path (~90 launches become 6 hipGraphLaunch + 12 event calls: the prover
-// is launch-bound at manta-pay circuit sizes, and concurrent host threads stop contending on the runtime).
-// One graph over all six streams saved another ~20 us per proof but crashed inside hipGraphLaunch
-// (hip::Graph::UpdateStreams) about once in ten processes after earlier contexts had come and gone; linear
-// single-stream graphs have no parallel branches for the runtime to re-map.
+// with its own stream), a pinned copy of z, and -- after two eager runs that size every buffer -- captured
+// hipGraphs of the GPU side (~90 launches: the prover is launch-bound at manta-pay circuit sizes, and
+// concurrent host threads stop contending on the runtime). Default ("single"): two graphs, the G2 MSM alone on
+// its stream and everything else (witness map, four G1 MSMs forked and joined) on the slot's main stream, so
+// that the host can take the G1 results and assemble A and C while the G2 MSM -- the longest chain -- is still
+// running. "split": six single-stream graphs with eager event fork/join (no multi-branch graph at all; 15 %
+// slower). The launch streams are high-priority pooled streams: see stream_pool_get() for the runtime defect
+// that makes this necessary for multi-branch graphs.
 struct ProveWs {
     DevBuf z, a, b, c;
-    hipStream_t stream = nullptr;          // witness map, then the h MSM; everything is joined back into it
-    hipStream_t side[2] = {nullptr, nullptr}; // [0]: the G2 MSM (the longest chain); [1]: a, b_g1, l one after another
-    hipEvent_t z_ready = nullptr, h_ready = nullptr;
+    hipStream_t stream = nullptr;             // witness map (and the launch stream of the main graph); the G1 MSMs join back into it
+    hipStream_t side[2] = {nullptr, nullptr}; // [0]: the G2 MSM (the longest chain); [1]: a, b_g1, l in MANTA_PROVE_STREAMS=3 mode
+    hipEvent_t z_ready = nullptr, h_ready = nullptr, fork = nullptr;
     MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     GroupEngine *me[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     void *h_z = nullptr; // pinned staging of the assignment
     size_t h_z_cap = 0;
-    hipGraphExec_t g_all = nullptr;                                         // "single" mode: the whole proof, all streams
+    hipGraphExec_t g_all = nullptr; // "single" mode: witness map + the four G1 MSMs, forked and joined on `stream`
+    hipGraphExec_t g_g2 = nullptr;  // "single" mode: the G2 MSM, alone on its own stream
     hipGraphExec_t g_wm = nullptr;                                          // witness map body (main stream)
     hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
     bool graphs_ready = false;
@@ -58,7 +60,8 @@ struct ProveWs {
     bool no_graph = false;
     void drop_graphs() {
         if (g_all) hipGraphExecDestroy(g_all);
-        g_all = nullptr;
+        if (g_g2) hipGraphExecDestroy(g_g2);
+        g_all = g_g2 = nullptr;
         if (g_wm) hipGraphExecDestroy(g_wm);
         g_wm = nullptr;
         for (int i = 0; i < 5; ++i) {
@@ -81,6 +84,7 @@ struct ProveWs {
         if (h_z) hipHostFree(h_z);
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
+        if (fork) hipEventDestroy(fork);
         stream_pool_put(stream); // never destroyed: see stream_pool_get()
         stream_pool_put(side[0]);
         stream_pool_put(side[1]);
@@ -281,7 +285,8 @@ class ProverImpl : public Prover {
         w->k = k;
         if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
             !(w->side[1] = stream_pool_get()) || hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&w->fork, hipEventDisableTiming) != hipSuccess) {
             delete w;
             return nullptr;
         }
@@ -299,6 +304,7 @@ class ProverImpl : public Prover {
         // Fewer streams = fewer hardware queues per proof in flight (the runtime multiplexes streams onto
         // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
         // stream per MSM.
+        w->mw[2]->run_on = w->side[0]; // the G2 MSM (the critical path) gets a high-priority stream of its own
         if (prove_streams() == 3) {
             w->mw[0]->run_on = w->side[1];
             w->mw[1]->run_on = w->side[1];
@@ -409,32 +415,59 @@ class ProverImpl : public Prover {
     }
     static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
 
-    // enqueue the whole GPU side of one proof: witness map on w->stream, the five MSMs forked onto their
-    // streams with events and joined back. use_graphs replays the captured per-stream graphs instead of
-    // enqueuing the kernels; the event structure is identical.
-    int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
-        int rc = upload_z(w, z_src);
-        if (rc) return rc;
+    // The GPU side of a pass is two independent pieces that only share the uploaded assignment:
+    //   part A, on w->stream: witness map, then the four G1 MSMs (a, b_g1, l from z; h from the witness map)
+    //           forked onto their streams with events and joined back;
+    //   part B, on the G2 MSM's stream: the G2 MSM -- the longest chain of a proof.
+    // The host waits for part A first and does the G1 half of the assembly (s*A + r*B1 is ~0.15 ms of host work)
+    // while part B is still running. use_graphs replays the per-stream graphs of the "split" mode instead of
+    // enqueuing kernels; the event structure is identical.
+    static bool in_part_a(int i) { return i != 2; }
+    int enqueue_msm(ProveWs *w, const MsmArgs &a, int i, bool use_graphs) {
+        if (use_graphs) {
+            hipStream_t ms = msm_stream(w, i);
+            MG_HIP(hipGraphLaunch(w->g_msm[i], ms));
+            MG_HIP(hipEventRecord(w->mw[i]->done, ms));
+            w->mw[i]->pending = 1;
+            return MG_OK;
+        }
+        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]);
+    }
+    int enqueue_part_a(ProveWs *w, bool use_graphs) {
+        int rc;
         const MsmArgs a = msm_args(w);
-        // the witness map goes first: witness map -> h MSM is as long a chain as the G2 MSM (measured: enqueuing
-        // the G2 MSM ahead of it costs 0.3 ms per proof)
+        MG_HIP(hipEventRecord(w->fork, w->stream)); // z is on the device (upload_z ran on this stream)
         if ((rc = launch_witness_map(w, use_graphs))) return rc;
         for (int i = 0; i < 5; ++i) {
+            if (!in_part_a(i)) continue;
             hipStream_t ms = msm_stream(w, i);
-            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->z_ready, 0));
-            if (use_graphs) {
-                MG_HIP(hipGraphLaunch(w->g_msm[i], ms));
-                MG_HIP(hipEventRecord(w->mw[i]->done, ms));
-                w->mw[i]->pending = 1;
-            } else if ((rc = w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]))) {
-                return rc;
-            }
+            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
+            if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }
         for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
             hipStream_t ms = msm_stream(w, i);
-            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
+            if (in_part_a(i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         return MG_OK;
+    }
+    int enqueue_part_b(ProveWs *w, bool use_graphs) { return enqueue_msm(w, msm_args(w), 2, use_graphs); }
+
+    int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
+        int rc = upload_z(w, z_src);
+        if (rc) return rc;
+        hipStream_t g2s = msm_stream(w, 2);
+        if (w->g_all && w->g_g2) { // "single" mode replay
+            // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
+            // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
+            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
+            MG_HIP(hipGraphLaunch(w->g_g2, g2s));
+            MG_HIP(hipGraphLaunch(w->g_all, w->stream));
+            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
+            return MG_OK;
+        }
+        if ((rc = enqueue_part_a(w, use_graphs))) return rc;
+        if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
+        return enqueue_part_b(w, use_graphs);
     }
 
     // capture one single-stream segment into an executable graph
@@ -454,9 +487,17 @@ class ProverImpl : public Prover {
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
         if (graph_mode() == GRAPH_SINGLE) {
-            const bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_proof(w, (const uint64_t *)w->h_z, false); });
+            bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_part_a(w, false); });
+            if (ok1) {
+                w->mw[2]->capturing = true; // a linear capture: nothing waits on its `done` event
+                ok1 = capture_segment(msm_stream(w, 2), &w->g_g2, [&] { return enqueue_part_b(w, false); });
+                w->mw[2]->capturing = false;
+            }
             for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
-            if (!ok1) w->no_graph = true;
+            if (!ok1) {
+                w->drop_graphs();
+                w->no_graph = true;
+            }
             w->graphs_ready = ok1;
             return ok1;
         }
@@ -518,20 +559,11 @@ class ProverImpl : public Prover {
         }
         std::memcpy(w->h_z, z, zbytes);
         if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2) build_graphs(w);
-        if (w->graphs_ready && w->g_all) {
-            hipError_t e = hipGraphLaunch(w->g_all, w->stream);
-            if (e == hipSuccess) {
-                for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
-            } else {
-                set_last_hip_error(e, "hipGraphLaunch(proof)", __FILE__, __LINE__);
-                rc = MG_ERR_HIP;
-                w->drop_graphs();
-                w->no_graph = true;
-            }
-        } else if (w->graphs_ready) {
-            rc = enqueue_proof(w, (const uint64_t *)w->h_z, true);
+        if (w->graphs_ready) {
+            rc = enqueue_proof(w, (const uint64_t *)w->h_z, graph_mode() == GRAPH_SPLIT);
             if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
                 hipStreamSynchronize(w->stream);
+                hipStreamSynchronize(msm_stream(w, 2));
                 w->drop_graphs();
                 w->no_graph = true;
             }
@@ -570,55 +602,62 @@ class ProverImpl : public Prover {
             }
         }
         std::vector<HostPoint> res((size_t)5 * k); // res[i * k + q]: MSM i of proof q
-        {
-            hipError_t e = hipStreamSynchronize(w->stream); // every MSM stream has been joined into it
+        auto collect = [&](hipStream_t s, bool part_a) { // wait for one part and fold its MSMs
+            hipError_t e = hipStreamSynchronize(s);
             if (e != hipSuccess && !rc) {
                 set_last_hip_error(e, "prove: hipStreamSynchronize", __FILE__, __LINE__);
                 rc = MG_ERR_HIP;
             }
             for (int i = 0; i < 5; ++i) {
+                if (in_part_a(i) != part_a) continue;
                 if (w->mw[i]->pending) {
                     int rc2 = w->me[i]->msm_finish(w->mw[i], &res[(size_t)i * k], true);
                     if (!rc) rc = rc2;
                 } else {
-                    hipStreamSynchronize(w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream);
+                    hipStreamSynchronize(msm_stream(w, i));
                     if (!rc) rc = MG_ERR_STATE;
                 }
             }
+        };
+        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
+        // ---- part A is back: the G1 side of the assembly runs while the G2 MSM finishes
+        collect(w->stream, true); // every G1 MSM stream has been joined into it
+        if (!rc) {
+            for (u32 q = 0; q < k; ++q) {
+                Blind &b = bl[q];
+                const uint64_t *rq = r + 4 * q;
+                const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
+                HostPoint g_a = res[0 * (size_t)k + q];
+                g1_->hp_add(&g_a, &a0_alpha_);
+                g1_->hp_add(&g_a, &b.t_rd);
+                HostPoint g1_b;
+                g1_->hp_set_inf(&g1_b);
+                if (!r_zero) {
+                    g1_b = res[1 * (size_t)k + q];
+                    g1_->hp_add(&g1_b, &b10_beta_);
+                    g1_->hp_add(&g1_b, &b.t_sd);
+                }
+                HostPoint g_c;
+                g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
+                g1_->hp_neg(&b.t_rsd);
+                g1_->hp_add(&g_c, &b.t_rsd);
+                g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
+                g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
+                uint8_t *out = p.out + (size_t)q * (2 * b1 + b2);
+                g1_->hp_serialize(&g_a, out, true);
+                g1_->hp_serialize(&g_c, out + b1 + b2, true);
+            }
         }
+        // ---- part B: the G2 element
+        collect(msm_stream(w, 2), false);
         ws_release(w);
         p.w = nullptr;
         if (rc) return rc;
-
-        // ---- serial assembly on the host
-        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
         for (u32 q = 0; q < k; ++q) {
-            Blind &b = bl[q];
-            const uint64_t *rq = r + 4 * q;
-            const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
-            HostPoint g_a = res[0 * (size_t)k + q];
-            g1_->hp_add(&g_a, &a0_alpha_);
-            g1_->hp_add(&g_a, &b.t_rd);
-            HostPoint g1_b;
-            g1_->hp_set_inf(&g1_b);
-            if (!r_zero) {
-                g1_b = res[1 * (size_t)k + q];
-                g1_->hp_add(&g1_b, &b10_beta_);
-                g1_->hp_add(&g1_b, &b.t_sd);
-            }
             HostPoint g2_b = res[2 * (size_t)k + q];
             g2_->hp_add(&g2_b, &b20_beta_);
-            g2_->hp_add(&g2_b, &b.t_sd2);
-            HostPoint g_c;
-            g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
-            g1_->hp_neg(&b.t_rsd);
-            g1_->hp_add(&g_c, &b.t_rsd);
-            g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
-            g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
-            uint8_t *out = p.out + (size_t)q * (2 * b1 + b2);
-            g1_->hp_serialize(&g_a, out, true);
-            g2_->hp_serialize(&g2_b, out + b1, true);
-            g1_->hp_serialize(&g_c, out + b1 + b2, true);
+            g2_->hp_add(&g2_b, &bl[q].t_sd2);
+            g2_->hp_serialize(&g2_b, p.out + (size_t)q * (2 * b1 + b2) + b1, true);
         }
         return MG_OK;
     }
