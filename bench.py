@@ -287,8 +287,10 @@ def prove_main(args):
 
     run(args.warmup if K == 1 else max(args.warmup, 4 * K * args.threads), args.threads)  # slots capture their graphs on the 3rd call
     # sequential latency (one proof at a time)
-    t0 = time.perf_counter()
     nlat = min(5, args.steps)
+    for i in range(4):  # whichever slot serves a lone caller has captured its graphs after three passes
+        api.Groth16.prove_with_randomness(ctx, c.z, rs[i % nrs][0], rs[i % nrs][1])
+    t0 = time.perf_counter()
     for i in range(nlat):
         api.Groth16.prove_with_randomness(ctx, c.z, rs[i][0], rs[i][1])
     lat_ms = (time.perf_counter() - t0) / nlat * 1e3
