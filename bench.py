@@ -252,7 +252,12 @@ def prove_main(args):
     first = api.Groth16.prove_with_randomness(ctx, c.z, rs[0][0], rs[0][1])
 
     K = max(1, args.batch)
-    zK = np.ascontiguousarray(np.stack([c.z] * K)) if K > 1 else None
+    # the assignment lives in page-locked memory (mg_host_alloc), as a host integration would keep it: the
+    # library then DMAs it from there instead of staging a copy first
+    z1_pin = api.PinnedArray.like(c.z)
+    z1 = z1_pin.array
+    zK_pin = api.PinnedArray.like(np.stack([c.z] * K)) if K > 1 else None
+    zK = zK_pin.array if K > 1 else None
 
     def run(steps, threads):
         idx = iter(range(0, steps, K))
@@ -266,7 +271,7 @@ def prove_main(args):
                 if i is None:
                     return
                 if K == 1:
-                    out[i] = api.Groth16.prove_with_randomness(ctx, c.z, rs[i % nrs][0], rs[i % nrs][1])
+                    out[i] = api.Groth16.prove_with_randomness(ctx, z1, rs[i % nrs][0], rs[i % nrs][1])
                 else:  # one pass of the GPU pipeline for proofs i .. i+K-1 (the last batch wraps around)
                     sel = [(i + q) % nrs for q in range(K)]
                     got = api.Groth16.prove_batch(ctx, zK, rs[sel, 0], rs[sel, 1])
@@ -289,10 +294,10 @@ def prove_main(args):
     # sequential latency (one proof at a time)
     nlat = min(5, args.steps)
     for i in range(4):  # whichever slot serves a lone caller has captured its graphs after three passes
-        api.Groth16.prove_with_randomness(ctx, c.z, rs[i % nrs][0], rs[i % nrs][1])
+        api.Groth16.prove_with_randomness(ctx, z1, rs[i % nrs][0], rs[i % nrs][1])
     t0 = time.perf_counter()
     for i in range(nlat):
-        api.Groth16.prove_with_randomness(ctx, c.z, rs[i][0], rs[i][1])
+        api.Groth16.prove_with_randomness(ctx, z1, rs[i][0], rs[i][1])
     lat_ms = (time.perf_counter() - t0) / nlat * 1e3
     barrier()
     t0 = time.perf_counter()
@@ -325,7 +330,7 @@ def prove_main(args):
                 "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": f"Groth16 prove, shape-exact synthetic {args.shape} circuit (D={D}, V={V}, P={P}), BN254",
-                           "host_threads": args.threads, "proofs_per_call": K, "sequential_latency_ms": round(lat_ms, 3),
+                           "host_threads": args.threads, "proofs_per_call": K, "assignment_memory": "page-locked (mg_host_alloc)", "sequential_latency_ms": round(lat_ms, 3),
                            "setup_s": round(setup_s, 2)},
                 "roofline": {"bound": "hbm", "achieved": round(algo_bytes * args.steps / dt / 1e9, 3), "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": round(algo_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 6),

@@ -57,6 +57,12 @@ int mg_free(void *dptr);
 int mg_memcpy_h2d(void *dptr, const void *hptr, size_t bytes);
 int mg_memcpy_d2h(void *hptr, const void *dptr, size_t bytes);
 int mg_device_synchronize(void);
+/* Page-locked host memory. An assignment (`z_mont`) that lives in a buffer from mg_host_alloc -- or in any
+ * memory the caller registered with HIP -- is DMA'd to the GPU straight from where it is; any other buffer is
+ * first copied into the library's own pinned staging area (0.1 ms for the 1.1 MB PrivateTransfer assignment). The
+ * Rust shim can collect `instance || witness` directly into such a buffer. */
+int mg_host_alloc(void **hptr, size_t bytes);
+int mg_host_free(void *hptr);
 /* Measurement hook (bench.py roofline leg): when on, each MSM brackets its dominant kernel (bucket
  * accumulate) with HIP events on the stream it is launched on; mg_last_accumulate_ms() returns the
  * duration of the calling thread's most recently finished MSM. Off by default. */

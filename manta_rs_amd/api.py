@@ -52,7 +52,7 @@ _sz = ctypes.c_size_t
 
 EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
-    "mg_memcpy_d2h", "mg_device_synchronize", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
+    "mg_memcpy_d2h", "mg_device_synchronize", "mg_host_alloc", "mg_host_free", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_ec_elementwise", "mg_point_serialize", "mg_ntt",
     "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
@@ -92,6 +92,38 @@ def last_accumulate_ms():
 
 def synchronize():
     _chk(LIB.mg_device_synchronize(), "mg_device_synchronize")
+
+
+class PinnedArray:
+    """A numpy array in page-locked host memory (`mg_host_alloc`): assignments kept in one are uploaded to the GPU
+    without the library's staging copy. `PinnedArray.like(arr).array` is a pinned copy of `arr`."""
+
+    def __init__(self, shape, dtype=np.uint64):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = _vp()
+        _chk(LIB.mg_host_alloc(ctypes.byref(ptr), _sz(self.nbytes)), "mg_host_alloc")
+        self._ptr = ptr
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    @classmethod
+    def like(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        p = cls(arr.shape, arr.dtype)
+        p.array[...] = arr
+        return p
+
+    def free(self):
+        if self._ptr is not None and self._ptr.value:
+            self.array = None
+            LIB.mg_host_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

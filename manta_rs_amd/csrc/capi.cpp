@@ -57,6 +57,15 @@ MG_API int mg_free(void *dptr) {
     MG_HIP(hipFree(dptr));
     return MG_SUCCESS;
 }
+MG_API int mg_host_alloc(void **hptr, size_t bytes) {
+    if (!hptr) return MG_ERROR_INVALID_ARGUMENT;
+    MG_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return MG_SUCCESS;
+}
+MG_API int mg_host_free(void *hptr) {
+    MG_HIP(hipHostFree(hptr));
+    return MG_SUCCESS;
+}
 MG_API int mg_memcpy_h2d(void *d, const void *h, size_t bytes) {
     MG_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
     return MG_SUCCESS;

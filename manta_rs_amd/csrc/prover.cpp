@@ -565,6 +565,15 @@ class ProverImpl : public Prover {
         uint8_t *out = nullptr;
     };
 
+    static bool is_page_locked(const void *p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+            (void)hipGetLastError(); // ordinary pageable memory is "invalid value" to the runtime
+            return false;
+        }
+        return a.type == hipMemoryTypeHost;
+    }
+
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
     int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out) {
         p.k = k, p.r = r, p.s = s, p.out = out;
@@ -572,17 +581,23 @@ class ProverImpl : public Prover {
         if (!w) return MG_ERR_HIP;
         int rc = MG_OK;
         const size_t zbytes = (size_t)k * V_ * 32;
-        if (w->h_z_cap < zbytes) {
-            if (w->h_z) hipHostFree(w->h_z);
-            w->h_z = nullptr;
-            w->h_z_cap = 0;
-            if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) return MG_ERR_OOM;
-            w->h_z_cap = zbytes;
+        // the assignment is uploaded from where it is if the caller keeps it in page-locked memory
+        // (mg_host_alloc), else through the slot's pinned staging copy
+        const uint64_t *z_src = z;
+        if (!is_page_locked(z)) {
+            if (w->h_z_cap < zbytes) {
+                if (w->h_z) hipHostFree(w->h_z);
+                w->h_z = nullptr;
+                w->h_z_cap = 0;
+                if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) return MG_ERR_OOM;
+                w->h_z_cap = zbytes;
+            }
+            std::memcpy(w->h_z, z, zbytes);
+            z_src = (const uint64_t *)w->h_z;
         }
-        std::memcpy(w->h_z, z, zbytes);
         if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2) build_graphs(w);
         if (w->graphs_ready) {
-            rc = enqueue_proof(w, (const uint64_t *)w->h_z, graph_mode() == GRAPH_SPLIT);
+            rc = enqueue_proof(w, z_src, graph_mode() == GRAPH_SPLIT);
             if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
                 hipStreamSynchronize(w->stream);
                 hipStreamSynchronize(msm_stream(w, 2));
@@ -590,7 +605,7 @@ class ProverImpl : public Prover {
                 w->no_graph = true;
             }
         } else {
-            rc = enqueue_proof(w, (const uint64_t *)w->h_z, false);
+            rc = enqueue_proof(w, z_src, false);
             w->eager_runs++;
         }
         return rc;

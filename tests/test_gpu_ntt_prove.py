@@ -304,3 +304,24 @@ def test_prove_bls12_381_at_circuit_size(gpu):
     for q in (1, 2):
         assert got[q] == O.groth16_prove(c, pk, rs[2 * q], rs[2 * q + 1])
         assert O.groth16_verify(curve, pk, c.z[1:c.P], got[q]) == 1
+
+
+def test_page_locked_assignment_is_uploaded_in_place(gpu):
+    """An assignment kept in mg_host_alloc memory skips the library's staging copy; the proofs are the same
+    bytes, single and batched, and an ordinary buffer still works afterwards."""
+    curve = 0
+    c = synth.make_circuit(curve, 500, 400, 6, seed=71)
+    pk = O.groth16_setup(c, H.toxic(curve, seed=14))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(curve, 8, seed=81)
+    want = [O.groth16_prove(c, pk, rs[2 * q], rs[2 * q + 1]) for q in range(4)]
+    zp = gpu.PinnedArray.like(c.z)
+    for _ in range(4):
+        assert gpu.Groth16.prove_with_randomness(ctx, zp.array, rs[0], rs[1]) == want[0]
+    assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[2], rs[3]) == want[1]
+    zk = gpu.PinnedArray.like(np.stack([c.z] * 4))
+    for _ in range(4):
+        assert gpu.Groth16.prove_batch(ctx, zk.array, rs[0:8:2], rs[1:8:2]) == want
+    zp.free()
+    zk.free()
