@@ -141,6 +141,24 @@ typedef struct {
     uint64_t nnz;
 } mg_csr;
 
+/* ---- key generation: the expensive part of `Groth16::compile` (manta-crypto/src/arkworks/groth16.rs:571-586 ->
+ *      ark-groth16 0.3 generate_parameters): every group element of the proving and verifying key is a fixed-base
+ *      multiple of a generator, 3V + D of them in G1 and V in G2 -- computed on the GPU. The caller supplies what
+ *      the reference draws from its RNG, in its order: alpha, beta, gamma, delta (then the two generators), tau --
+ *      all Fr in Montgomery form -- so a seeded RNG reproduces the reference's key. Outputs are caller-allocated
+ *      arrays laid out like the fields of the mg_pk_view struct -- affine Montgomery, infinity = zeros: gamma_abc_g1[n_inputs],
+ *      a_query / b_g1_query / b_g2_query[n_vars], h_query[D - 1] with D = next_pow2(m + n_inputs),
+ *      l_query[n_vars - n_inputs]. */
+typedef struct mg_pk_out {
+    uint64_t *alpha_g1, *beta_g1, *delta_g1;
+    uint64_t *beta_g2, *gamma_g2, *delta_g2;
+    uint64_t *gamma_abc_g1;
+    uint64_t *a_query, *b_g1_query, *b_g2_query, *h_query, *l_query;
+} mg_pk_out;
+int mg_groth16_setup(mg_curve_t curve, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t num_constraints,
+                     uint64_t n_vars, uint64_t n_inputs, const uint64_t *toxic_mont /* 5 x 4: alpha beta gamma delta tau */,
+                     const uint64_t *g1_generator, const uint64_t *g2_generator, const mg_pk_out *out);
+
 /* Uploads and re-lays the proving key once (lifetime = the Rust ProvingContext). */
 int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
 /* Same, from the key's wire format: arkworks 0.3 `ProvingKey::serialize_unchecked` bytes (uncompressed points,

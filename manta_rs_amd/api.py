@@ -54,7 +54,7 @@ EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_host_alloc", "mg_host_free", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_ec_elementwise", "mg_point_serialize", "mg_ntt",
-    "mg_ntt_device", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
+    "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy",
 ]
 
@@ -322,6 +322,47 @@ class R1CS:
     @classmethod
     def from_circuit(cls, c):
         return cls(c.curve, c.A, c.B, c.C, c.m, c.P, c.z)
+
+
+class _PkOut(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1",
+                                   "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
+
+
+class ProvingKey:
+    """Host arrays in the C ABI's memory format (affine Montgomery limbs, infinity = zeros): the fields of
+    ark_groth16::ProvingKey (incl. its verifying key) that `ProvingContext` and a verifier consume."""
+    pass
+
+
+def groth16_setup(r1cs: "R1CS", n_vars, toxic_mont, g1_generator, g2_generator) -> ProvingKey:
+    """Mirror of `Groth16::compile` (manta-crypto/src/arkworks/groth16.rs:571-586) with the randomness made explicit
+    (`mg_groth16_setup`): toxic_mont = alpha, beta, gamma, delta, tau as Montgomery Fr (5 x 4 u64), the generators as
+    affine points. Every group element of the key is computed on the GPU."""
+    curve, m, P, V = r1cs.curve, r1cs.num_constraints, r1cs.num_instance, int(n_vars)
+    D = 1
+    while D < m + P:
+        D <<= 1
+    w1, w2 = affine_limbs(curve, 1), affine_limbs(curve, 2)
+    pk = ProvingKey()
+    pk.curve, pk.V, pk.P, pk.D, pk.h_len = curve, V, P, D, D - 1
+    shapes = {"alpha_g1": (1, w1), "beta_g1": (1, w1), "delta_g1": (1, w1), "beta_g2": (1, w2), "gamma_g2": (1, w2),
+              "delta_g2": (1, w2), "gamma_abc_g1": (P, w1), "a_query": (V, w1), "b_g1_query": (V, w1),
+              "b_g2_query": (V, w2), "h_query": (D - 1, w1), "l_query": (V - P, w1)}
+    for k, sh in shapes.items():
+        setattr(pk, k, np.zeros(sh, dtype=np.uint64))
+    out = _PkOut(*[_p(getattr(pk, k)) for k, _ in _PkOut._fields_])
+    ms = []
+    for M in (r1cs.A, r1cs.B, r1cs.C):
+        rp = np.ascontiguousarray(M.row_ptr, dtype=np.uint32)
+        col = np.ascontiguousarray(M.col, dtype=np.uint32)
+        val = _u64(M.val)
+        ms.append((rp, col, val, _Csr(_p(rp), _p(col), _p(val), len(col))))
+    tox = _u64(toxic_mont).reshape(5, 4)
+    _chk(LIB.mg_groth16_setup(curve, ctypes.byref(ms[0][3]), ctypes.byref(ms[1][3]), ctypes.byref(ms[2][3]),
+                              ctypes.c_uint64(m), ctypes.c_uint64(V), ctypes.c_uint64(P), _p(tox), _p(_u64(g1_generator)),
+                              _p(_u64(g2_generator)), ctypes.byref(out)), "mg_groth16_setup")
+    return pk
 
 
 class ProvingContext:

@@ -256,6 +256,13 @@ MG_API int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const 
     return ctx->p->set_r1cs(a, b, c, m);
     MG_CATCH
 }
+MG_API int mg_groth16_setup(mg_curve_t curve, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t m, uint64_t n_vars,
+                            uint64_t n_inputs, const uint64_t *toxic, const uint64_t *g1_gen, const uint64_t *g2_gen,
+                            const mg_pk_out *out) {
+    MG_TRY
+    return groth16_setup((int)curve, a, b, c, m, n_vars, n_inputs, toxic, g1_gen, g2_gen, out);
+    MG_CATCH
+}
 MG_API int mg_groth16_prove(const mg_ctx *ctx, const uint64_t *z, const uint64_t r[4], const uint64_t s[4],
                             uint8_t *proof_out) {
     MG_TRY

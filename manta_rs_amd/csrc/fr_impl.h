@@ -367,6 +367,84 @@ template <class FrC> class FrEngineT : public FrEngine {
         HF r = HF::mul(x, y);
         std::memcpy(out, r.v, 32);
     }
+    int setup_scalars(const mg_csr *A, const mg_csr *B, const mg_csr *Cm, u64 m, u64 V, u64 P, unsigned log_d,
+                      const u64 *toxic5, std::vector<u64> &s1, std::vector<u64> &s2) const override {
+        if ((int)log_d > FrC::TWO_ADICITY || V < 2 || P < 1 || P >= V) return MG_ERR_ARG;
+        const size_t D = (size_t)1 << log_d;
+        if (m + P > D) return MG_ERR_ARG;
+        auto ld = [](const u64 *p) {
+            HF x;
+            std::memcpy(x.v, p, 32);
+            return x;
+        };
+        const HF alpha = ld(toxic5), beta = ld(toxic5 + 4), gamma = ld(toxic5 + 8), delta = ld(toxic5 + 12),
+                 tau = ld(toxic5 + 16);
+        if (gamma.is_zero() || delta.is_zero()) return MG_ERR_ARG;
+        HF w; // primitive D-th root of unity
+        w.load_words(FrC::ROOT);
+        for (unsigned i = log_d; i < (unsigned)FrC::TWO_ADICITY; ++i) w = HF::sqr(w);
+        HF tD = tau;
+        for (unsigned i = 0; i < log_d; ++i) tD = HF::sqr(tD);
+        const HF Zt = HF::sub(tD, HF::one()); // Z(tau) = tau^D - 1
+        // L_i(tau) = Z(tau)/D * w^i / (tau - w^i); the D denominators are inverted together
+        std::vector<HF> pw(D), den(D), pref(D + 1);
+        pw[0] = HF::one();
+        for (size_t i = 1; i < D; ++i) pw[i] = HF::mul(pw[i - 1], w);
+        pref[0] = HF::one();
+        for (size_t i = 0; i < D; ++i) {
+            den[i] = HF::sub(tau, pw[i]);
+            if (den[i].is_zero()) return MG_ERR_ARG; // tau inside the domain
+            pref[i + 1] = HF::mul(pref[i], den[i]);
+        }
+        HF inv = HF::inv(pref[D]);
+        HF dD = HF::one();
+        for (unsigned i = 0; i < log_d; ++i) dD = HF::dbl(dD);
+        const HF zd = HF::mul(Zt, HF::inv(dD));
+        std::vector<HF> L(D);
+        for (size_t i = D; i-- > 0;) {
+            const HF di = HF::mul(inv, pref[i]);
+            inv = HF::mul(inv, den[i]);
+            L[i] = HF::mul(HF::mul(zd, pw[i]), di);
+        }
+        std::vector<HF> av(V, HF::zero()), bv(V, HF::zero()), cv(V, HF::zero());
+        const mg_csr *Ms[3] = {A, B, Cm};
+        std::vector<HF> *acc[3] = {&av, &bv, &cv};
+        for (int t = 0; t < 3; ++t) {
+            const mg_csr *M = Ms[t];
+            if (!M || !M->row_ptr || (M->nnz && (!M->col || !M->val)) || M->row_ptr[m] != M->nnz) return MG_ERR_ARG;
+            for (u64 i = 0; i < m; ++i)
+                for (u64 k = M->row_ptr[i]; k < M->row_ptr[i + 1]; ++k) {
+                    if (M->col[k] >= V) return MG_ERR_ARG;
+                    HF &x = (*acc[t])[M->col[k]];
+                    x = HF::add(x, HF::mul(ld(M->val + 4 * k), L[i]));
+                }
+        }
+        for (u64 j = 0; j < P; ++j) av[j] = HF::add(av[j], L[m + j]); // input-consistency rows (mpc.rs:299-312)
+        const HF ginv = HF::inv(gamma), dinv = HF::inv(delta);
+        s1.assign((3 + P + 2 * V + (D - 1) + (V - P)) * 4, 0);
+        s2.assign((3 + V) * 4, 0);
+        auto put = [](std::vector<u64> &dst, size_t idx, const HF &x) {
+            const HF c = HF::from_mont(x);
+            std::memcpy(&dst[idx * 4], c.v, 32);
+        };
+        put(s1, 0, alpha), put(s1, 1, beta), put(s1, 2, delta);
+        put(s2, 0, beta), put(s2, 1, gamma), put(s2, 2, delta);
+        size_t o_abc = 3, o_a = o_abc + P, o_b = o_a + V, o_h = o_b + V, o_l = o_h + (D - 1);
+        for (u64 j = 0; j < V; ++j) {
+            const HF ext = HF::add(HF::add(HF::mul(beta, av[j]), HF::mul(alpha, bv[j])), cv[j]);
+            put(s1, o_a + j, av[j]);
+            put(s1, o_b + j, bv[j]);
+            put(s2, 3 + j, bv[j]);
+            if (j < P) put(s1, o_abc + j, HF::mul(ext, ginv));
+            else put(s1, o_l + (j - P), HF::mul(ext, dinv));
+        }
+        HF cur = HF::mul(Zt, dinv);
+        for (size_t i = 0; i + 1 < D; ++i) {
+            put(s1, o_h + i, cur);
+            cur = HF::mul(cur, tau);
+        }
+        return MG_OK;
+    }
     void fr_to_canonical(const u64 a[4], u64 out[4]) const override {
         HF x;
         std::memcpy(x.v, a, 32);

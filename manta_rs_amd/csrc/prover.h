@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/mantagpu.h"
 #include "engine.h"
+#include <vector>
 
 namespace mg {
 
@@ -31,6 +32,14 @@ class FrEngine {
     // host-side Fr helpers (Montgomery in/out unless noted)
     virtual void fr_mul(const u64 a[4], const u64 b[4], u64 out[4]) const = 0;
     virtual void fr_to_canonical(const u64 a[4], u64 out[4]) const = 0;
+    // Scalars of the Groth16 key for QAP(A, B, C) at the toxic waste (alpha, beta, gamma, delta, tau; Montgomery):
+    //   a_j = sum_i A[i][j] L_i(tau) (+ L_{m+j}(tau) for j < P), b_j, c_j likewise over the domain of size
+    //   2^log_d >= m + P;   gamma_abc_j = (beta a_j + alpha b_j + c_j)/gamma (j < P);   l_j the same over delta
+    //   (j >= P);   h_i = tau^i (tau^D - 1)/delta, i < D - 1.
+    // Outputs are CANONICAL 4 x u64 integers, ready for the fixed-base multiplication kernels:
+    //   s1 = alpha | beta | delta | gamma_abc[P] | a[V] | b[V] | h[D-1] | l[V-P]      s2 = beta | gamma | delta | b[V]
+    virtual int setup_scalars(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, u64 V, u64 P, unsigned log_d,
+                              const u64 *toxic5, std::vector<u64> &s1, std::vector<u64> &s2) const = 0;
 };
 typedef FrEngine NttEngine;
 FrEngine *make_fr_engine_bn254();
@@ -51,5 +60,8 @@ class Prover {
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);
 // arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
 int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out);
+// Groth16 key generation from explicit toxic waste and group generators (setup.cpp)
+int groth16_setup(int curve, const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, u64 n_vars, u64 n_inputs,
+                  const u64 *toxic5, const u64 *g1_gen, const u64 *g2_gen, const mg_pk_out *out);
 
 } // namespace mg

@@ -10,10 +10,9 @@ size D = next_pow2(m + P),
     l_query[j-P] = ((beta a_j + alpha b_j + c_j)/delta) G1  (j >= P),   gamma_abc likewise with gamma (j < P)
     h_query[i] = (tau^i (tau^D - 1)/delta) G1,  i < D-1
 
-Scalars are computed with Python integers on the host; every scalar multiplication runs on the GPU
-through `mg_fixed_base_mul` (key generation is a "next" row -- this is the part of it
-the bench and tests need to obtain *valid* proving keys of the real manta-pay shapes).
-Used by bench.py (prove workload) and tests; never touches oracle/.
+Thin wrapper over `mg_groth16_setup` (csrc/setup.cpp): the O(D + nnz) scalar preparation runs on the host in
+C++, every scalar multiplication on the GPU. Used by bench.py (prove workload) and
+tests to obtain *valid* proving keys of the real manta-pay shapes; never touches oracle/.
 """
 from __future__ import annotations
 
@@ -48,101 +47,17 @@ def generator(curve, group):
     return synth.to_mont(list(coords), q, nl).reshape(-1)
 
 
-class ProvingKey:
-    """Host arrays in the C ABI's memory format (affine Montgomery limbs, infinity = zeros)."""
-    pass
+ProvingKey = api.ProvingKey
 
 
-def _batch_inverse(vals, p):
-    pref = [1] * (len(vals) + 1)
-    for i, v in enumerate(vals):
-        pref[i + 1] = pref[i] * v % p
-    inv = pow(pref[-1], -1, p)
-    out = [0] * len(vals)
-    for i in range(len(vals) - 1, -1, -1):
-        out[i] = inv * pref[i] % p
-        inv = inv * vals[i] % p
-    return out
-
-
-def _csr_cols(c, M):
-    r = synth.FR_MODULUS[c.curve]
-    Rinv = pow(1 << 256, -1, r)
-    # distinct coefficient values are few: decode through a cache keyed by the raw limbs
-    cache = {}
-    vals = []
-    raw = np.ascontiguousarray(M.val).view(np.uint64).reshape(-1, 4)
-    for row in raw:
-        k = row.tobytes()
-        v = cache.get(k)
-        if v is None:
-            v = int.from_bytes(k, "little") * Rinv % r
-            cache[k] = v
-        vals.append(v)
-    return vals
-
-
-def generate(c: synth.Circuit, toxic):
-    """toxic = (tau, alpha, beta, gamma, delta) as Python ints. Returns a ProvingKey whose fields are what
-    `api.ProvingContext` consumes, plus gamma_g2 / gamma_abc_g1 for verification."""
+def generate(c: synth.Circuit, toxic, g1_generator=None, g2_generator=None):
+    """toxic = (tau, alpha, beta, gamma, delta) as Python ints (the order of the oracle's setup). Returns a
+    ProvingKey whose fields are what `api.ProvingContext` consumes, plus gamma_g2 / gamma_abc_g1 for verification.
+    The generators default to the curves' standard ones."""
     curve = c.curve
     r = synth.FR_MODULUS[curve]
     tau, alpha, beta, gamma, delta = [int(t) % r for t in toxic]
-    D, m, P, V = c.D, c.m, c.P, c.V
-    lg = D.bit_length() - 1
-    w = pow(pow(FR_GEN[curve], (r - 1) >> FR_TWO_ADICITY[curve], r), 1 << (FR_TWO_ADICITY[curve] - lg), r)
-    Zt = (pow(tau, D, r) - 1) % r
-    # Lagrange coefficients L_i(tau) = Z(tau)/D * w^i / (tau - w^i)
-    pw = [1] * D
-    for i in range(1, D):
-        pw[i] = pw[i - 1] * w % r
-    den = _batch_inverse([(tau - x) % r for x in pw], r)
-    zd = Zt * pow(D, -1, r) % r
-    L = [zd * x % r * d % r for x, d in zip(pw, den)]
-    a = [0] * V
-    b = [0] * V
-    cc = [0] * V
-    for M, acc in ((c.A, a), (c.B, b), (c.C, cc)):
-        vals = _csr_cols(c, M)
-        rp, col = M.row_ptr, M.col
-        for i in range(m):
-            Li = L[i]
-            for k in range(rp[i], rp[i + 1]):
-                j = col[k]
-                acc[j] = (acc[j] + vals[k] * Li) % r
-    for j in range(P):
-        a[j] = (a[j] + L[m + j]) % r
-    ginv, dinv = pow(gamma, -1, r), pow(delta, -1, r)
-    ext = [(beta * a[j] + alpha * b[j] + cc[j]) % r for j in range(V)]
-    gabc = [ext[j] * ginv % r for j in range(P)]
-    lq = [ext[j] * dinv % r for j in range(P, V)]
-    hz = Zt * dinv % r
-    hq = [0] * (D - 1)
-    cur = hz
-    for i in range(D - 1):
-        hq[i] = cur
-        cur = cur * tau % r
-    fixed1 = [alpha, beta, delta]
-    fixed2 = [beta, gamma, delta]
-    # one batched fixed-base multiply per group
-    s1 = fixed1 + gabc + a + b + hq + lq
-    s2 = fixed2 + b
-    G1, G2 = generator(curve, 1), generator(curve, 2)
-    w1, w2 = api.affine_limbs(curve, 1), api.affine_limbs(curve, 2)
-    d1 = api.fixed_base_mul(curve, 1, G1, api.DeviceBuffer.from_numpy(synth.ints_to_limbs(s1, 4)), len(s1))
-    p1 = d1.to_numpy(shape=(len(s1), w1))
-    d2 = api.fixed_base_mul(curve, 2, G2, api.DeviceBuffer.from_numpy(synth.ints_to_limbs(s2, 4)), len(s2))
-    p2 = d2.to_numpy(shape=(len(s2), w2))
-    pk = ProvingKey()
-    pk.curve, pk.V, pk.P, pk.D, pk.h_len = curve, V, P, D, D - 1
-    o = 0
-    pk.alpha_g1, pk.beta_g1, pk.delta_g1 = p1[0:1].copy(), p1[1:2].copy(), p1[2:3].copy()
-    o = 3
-    pk.gamma_abc_g1 = p1[o:o + P].copy(); o += P
-    pk.a_query = p1[o:o + V].copy(); o += V
-    pk.b_g1_query = p1[o:o + V].copy(); o += V
-    pk.h_query = p1[o:o + D - 1].copy(); o += D - 1
-    pk.l_query = p1[o:o + V - P].copy(); o += V - P
-    pk.beta_g2, pk.gamma_g2, pk.delta_g2 = p2[0:1].copy(), p2[1:2].copy(), p2[2:3].copy()
-    pk.b_g2_query = p2[3:3 + V].copy()
-    return pk
+    tox = synth.to_mont([alpha, beta, gamma, delta, tau], r, 4)
+    g1 = generator(curve, 1) if g1_generator is None else g1_generator
+    g2 = generator(curve, 2) if g2_generator is None else g2_generator
+    return api.groth16_setup(api.R1CS.from_circuit(c), c.V, tox, g1, g2)

@@ -325,3 +325,35 @@ def test_page_locked_assignment_is_uploaded_in_place(gpu):
         assert gpu.Groth16.prove_batch(ctx, zk.array, rs[0:8:2], rs[1:8:2]) == want
     zp.free()
     zk.free()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_groth16_setup_with_custom_generators(gpu, curve):
+    """mg_groth16_setup with the group generators the reference would draw from its RNG (ark-groth16 0.3 samples
+    random g1 / g2 in generate_random_parameters): a key over non-standard generators must still prove and verify,
+    and with the standard generators it is the oracle's key point for point (test_gpu_keygen_matches_oracle_setup)."""
+    from manta_rs_amd import keygen
+    c = synth.make_circuit(curve, 300, 220, 5, seed=91)
+    r = synth.FR_MODULUS[curve]
+    k1 = synth.ints_to_limbs([0x1234567 % r], 4)[0]
+    k2 = synth.ints_to_limbs([0x7654321 % r], 4)[0]
+    g1 = O.g_mul(curve, 1, keygen.generator(curve, 1), k1)
+    g2 = O.g_mul(curve, 2, keygen.generator(curve, 2), k2)
+    toxic = synth.from_mont(H.toxic(curve, seed=15), r)
+    pk = keygen.generate(c, toxic, g1, g2)
+    assert not (pk.a_query == keygen.generate(c, toxic).a_query).all()
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(curve, 2, seed=82)
+    proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    assert proof == O.groth16_prove(c, pk, rs[0], rs[1])
+    assert O.groth16_verify(curve, pk, c.z[1:c.P], proof) == 1
+    # error codes: tau inside the evaluation domain, gamma = 0
+    bad = list(toxic)
+    bad[0] = 1  # tau = 1 = w^0
+    with pytest.raises(gpu.MantaGpuError):
+        keygen.generate(c, bad)
+    bad = list(toxic)
+    bad[3] = 0  # gamma
+    with pytest.raises(gpu.MantaGpuError):
+        keygen.generate(c, bad)
