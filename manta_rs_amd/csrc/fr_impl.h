@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void scale_const_kernel(u32 *__restrict__ data
 // `post` (optional) multiplies element i by post[i] on the way out (n^-1 and coset powers, tabulated in
 // the order the pass leaves the data in), so scaling never costs a pass of its own.
 template <class FrC, bool DIF>
-__global__ __launch_bounds__(256) void ntt_pass_kernel(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
+__global__ __launch_bounds__(1024) void ntt_pass_kernel(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
                                                        const u32 *__restrict__ tw, unsigned lg, unsigned s0,
                                                        unsigned ns, unsigned cb, const u32 *__restrict__ post) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
@@ -279,6 +279,13 @@ template <class FrC> class FrEngineT : public FrEngine {
         return MG_OK;
     }
 
+    static u32 ntt_threads() {
+        static const u32 v = [] {
+            const char *e = getenv("MANTA_NTT_THREADS");
+            return (u32)(e ? atoi(e) : 0);
+        }();
+        return v;
+    }
     // all stages of one transform over up to 3 vectors as LDS-fused passes of <= 10 stages
     template <bool DIF>
     static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw, unsigned lg, const u32 *post, hipStream_t s,
@@ -297,7 +304,11 @@ template <class FrC> class FrEngineT : public FrEngine {
             const u32 blocks = (u32)(((size_t)1 << lg) >> (ns + cb));
             const size_t lds = ((size_t)32 << (ns + cb));
             const bool last = p + 1 == npass;
-            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec, batch), dim3(256), lds, s, d0, d1, d2, tw, lg, s0,
+            // one butterfly per thread and stage when the tile is full (2048 elements -> 1024 threads = 4 wavefronts
+            // per SIMD): a pass is a chain of dependent multiplications, more resident waves hide its latency
+            const u32 tot = 1u << (ns + cb);
+            const u32 threads = ntt_threads() ? ntt_threads() : (tot >= 2048 ? 1024u : tot >= 1024 ? 512u : 256u);
+            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw, lg, s0,
                                ns, cb, last ? post : (const u32 *)nullptr);
             done += ns;
         }
