@@ -307,7 +307,7 @@ template <class FrC> class FrEngineT : public FrEngine {
             // one butterfly per thread and stage when the tile is full (2048 elements -> 1024 threads = 4 wavefronts
             // per SIMD): a pass is a chain of dependent multiplications, more resident waves hide its latency
             const u32 tot = 1u << (ns + cb);
-            const u32 threads = ntt_threads() ? ntt_threads() : (tot >= 2048 ? 1024u : tot >= 1024 ? 512u : 256u);
+            const u32 threads = ntt_threads() ? ntt_threads() : (tot >= 2048 ? 1024u : tot >= 128 ? tot / 2 : 64u);
             hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw, lg, s0,
                                ns, cb, last ? post : (const u32 *)nullptr);
             done += ns;
