@@ -82,9 +82,13 @@ size_t mg_bases_device_bytes(const mg_bases *bases);
 /* Host-to-host convenience: result = sum_i scalars[i] * bases[i], i < n <= len(bases).
  * scalars: n x 4 u64 canonical. out: affine Montgomery (infinity = zeros). */
 int mg_msm(const mg_bases *bases, const uint64_t *scalars_canonical, size_t n, uint64_t *out_affine_mont);
-/* Scalars already resident in HBM (the timed path). scalars_mont != 0: scalars are Montgomery Fr and
- * `into_repr` is applied on the device. window_bits = 0 lets the library choose. */
-int mg_msm_launch(const mg_bases *bases, const uint64_t *d_scalars, size_t n, int scalars_mont, int window_bits,
+/* Scalars already resident in HBM (the timed path). `scalar_flags`: MG_SCALARS_MONT -- the scalars are Montgomery Fr
+ * and are converted on the device (`into_repr`), else canonical; MG_SCALARS_SPARSE -- a hint that many digits are
+ * zero (a witness: mostly 0 / 1 / small values), the zero digits are then compacted away before the sort.
+ * window_bits = 0 lets the library choose. Returns immediately; mg_msm_finish waits and writes the affine result. */
+#define MG_SCALARS_MONT 1
+#define MG_SCALARS_SPARSE 2
+int mg_msm_launch(const mg_bases *bases, const uint64_t *d_scalars, size_t n, int scalar_flags, int window_bits,
                   mg_msm_job **job);
 int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine_mont); /* waits, folds, frees the job */
 /* sum of the registered points themselves (multi-GPU partial-point reduction, tests) */

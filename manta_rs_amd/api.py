@@ -226,11 +226,12 @@ class VariableBaseMSM:
         return out
 
     @staticmethod
-    def launch(bases: Bases, d_scalars, n, scalars_mont=False, window_bits=0) -> MsmJob:
+    def launch(bases: Bases, d_scalars, n, scalars_mont=False, window_bits=0, sparse=False) -> MsmJob:
         """Scalars already in HBM (DeviceBuffer or raw pointer); returns a job to `finish()`."""
         ptr = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else d_scalars
         h = _vp()
-        _chk(LIB.mg_msm_launch(bases.handle, ptr, _sz(n), int(scalars_mont), int(window_bits), ctypes.byref(h)),
+        _chk(LIB.mg_msm_launch(bases.handle, ptr, _sz(n), int(bool(scalars_mont)) | (2 if sparse else 0), int(window_bits),
+                               ctypes.byref(h)),
              "mg_msm_launch")
         return MsmJob(bases, h)
 

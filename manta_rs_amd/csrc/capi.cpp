@@ -107,13 +107,14 @@ MG_API void mg_bases_destroy(mg_bases *b) {
 }
 MG_API size_t mg_bases_device_bytes(const mg_bases *b) { return b ? b->bs->bytes : 0; }
 
-MG_API int mg_msm_launch(const mg_bases *b, const uint64_t *d_scalars, size_t n, int scalars_mont, int window_bits,
+MG_API int mg_msm_launch(const mg_bases *b, const uint64_t *d_scalars, size_t n, int scalar_flags, int window_bits,
                          mg_msm_job **job) {
     MG_TRY
     if (!b || !d_scalars || !job || n == 0) return MG_ERROR_INVALID_ARGUMENT;
     MsmWorkspace *ws = b->eng->ws_acquire();
     if (!ws) return MG_ERROR_HIP;
-    int rc = b->eng->msm_launch(b->bs, (const u32 *)d_scalars, n, scalars_mont != 0, window_bits, ws);
+    int rc = b->eng->msm_launch(b->bs, (const u32 *)d_scalars, n, (scalar_flags & MG_SCALARS_MONT) != 0, window_bits, ws, 1, 0,
+                                (scalar_flags & MG_SCALARS_SPARSE) != 0);
     if (rc) {
         hipStreamSynchronize(ws->stream);
         b->eng->ws_release(ws);

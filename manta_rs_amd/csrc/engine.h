@@ -68,6 +68,7 @@ struct BaseSet {
 // Per-call scratch for one MSM (device + pinned host staging). Pooled per engine.
 struct MsmWorkspace {
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, buckets, pkeys[2], ppts[2], redA, redS, misc;
+    DevBuf count; // number of (key, value) pairs the digit kernel produced (zero digits are compacted away)
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
@@ -112,8 +113,11 @@ class GroupEngine {
     // batch > 1: `batch` independent scalar vectors (vector q starts scalar_stride_words u32 after vector
     // q-1) against the SAME bases in one pass of the pipeline -- every (vector, window) pair is its own
     // bucket segment, so the kernels run once over batch x the entries (a batch of proofs of one circuit).
+    // sparse: the scalars are expected to have many zero digits (a witness: 40 % zeros, 25 % ones) -- the digit
+    // kernel then compacts the zero digits away before the sort (two passes over the digits and one atomic per
+    // wavefront: ~3 % slower on uniform scalars, up to 18 % faster on witness-like ones).
     virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
-                           MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0) = 0;
+                           MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) = 0;
     // Waits for the stream, folds the staged partial points on the host. out = `batch` XYZZ host points.
     // already_synced: the caller has synchronised with the work itself (hipGraph replay of a whole proof)
     virtual int msm_finish(MsmWorkspace *ws, HostPoint *out, bool already_synced = false) = 0;
@@ -160,7 +164,9 @@ GroupEngine *get_engine(int curve, int group); // cached singleton per (curve, g
 
 // radix sort of (key,val) pairs, keys < 2^end_bit (sort.hip; hipCUB device-wide radix sort)
 size_t sort_pairs_temp_bytes(size_t n);
+// d_count (optional): the number of pairs actually present, on the device (n is then the capacity)
+bool sort_pairs_takes_device_count(int end_bit);
 int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_out, size_t n, int end_bit,
-               void *tmp, size_t tmp_bytes, hipStream_t s);
+               void *tmp, size_t tmp_bytes, hipStream_t s, const u32 *d_count = nullptr);
 
 } // namespace mg

@@ -42,65 +42,93 @@ MG_DEV u32 limb_at(const u32 (&s)[8], int i) { // dynamic index without scratch
     for (int j = 0; j < 8; ++j) r = (i == j) ? s[j] : r;
     return r;
 }
+// One lane per (stored base, scalar vector of the batch): W signed c-bit digits -> (bucket key, base index | sign)
+// pairs. Zero digits produce NO pair: real witnesses are 40 % zeros and 25 % ones, so two thirds of all digits
+// vanish here instead of being carried through the sort. The surviving pairs are appended to the arrays in
+// wave-sized, window-major groups (one atomicAdd on `count` per wavefront, positions by ballot/popcount: the
+// order is irrelevant, the sort follows); every later stage reads the pair count from the device.
+// count == nullptr selects the fixed layout o = w*n + i with an `invalid` key for zero digits (library-sort path).
 template <class FrC>
 __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
                                                      int precomp, u32 tstride, int mont, u32 invalid,
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
                                                      const u32 *__restrict__ map, u32 n_scalars,
-                                                     size_t scalar_stride, u32 seg_keys) {
+                                                     size_t scalar_stride, u32 seg_keys, u32 *__restrict__ count) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    // blockIdx.y = scalar vector of a batch: its own scalars, its own slice of the key/value arrays and its own
-    // range of bucket keys; the bases (and so the values) are shared
+    // blockIdx.y = scalar vector of a batch: its own scalars, its own range of bucket keys; the bases (and so
+    // the values) are shared
     scalars += (size_t)blockIdx.y * scalar_stride;
-    keys += (size_t)blockIdx.y * W * n;
-    vals += (size_t)blockIdx.y * W * n;
     const u32 key0 = blockIdx.y * seg_keys;
-    const u32 src = map ? map[i] : i; // which scalar belongs to stored base i
-    if (src >= n_scalars) {           // the scalar vector is shorter than the base set: zip to the shorter
-        for (int w = 0; w < W; ++w) {
-            keys[(size_t)w * n + i] = invalid;
-            vals[(size_t)w * n + i] = 0;
-        }
-        return;
-    }
-    u32 s[8];
-    {
+    const u32 src = (i < n) ? (map ? map[i] : i) : 0xffffffffu; // which scalar belongs to stored base i
+    const bool have = i < n && src < n_scalars; // the scalar vector may be shorter than the base set: zip
+    u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (have) {
         const uint4 *p = reinterpret_cast<const uint4 *>(scalars + (size_t)src * 8);
         uint4 a = p[0], b = p[1];
         s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b.x, s[5] = b.y, s[6] = b.z, s[7] = b.w;
-    }
-    if (mont) { // ark-ff into_repr on the device
-        Fp<FrC> f;
+        if (mont) { // ark-ff into_repr on the device
+            Fp<FrC> f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f.v[j] = s[j];
-        f = Fp<FrC>::from_mont(f);
+            for (int j = 0; j < 8; ++j) f.v[j] = s[j];
+            f = Fp<FrC>::from_mont(f);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = f.v[j];
+            for (int j = 0; j < 8; ++j) s[j] = f.v[j];
+        }
     }
-    u32 carry = 0;
     const u32 mask = (1u << c) - 1;
-    for (int w = 0; w < W; ++w) {
+    auto digit = [&](int w, u32 &carry, u32 &neg) -> u32 { // signed digit of window w (0 = nothing to add)
         const int start = w * c;
         const int limb = start >> 5, off = start & 31;
         u64 v = limb < 8 ? (u64)limb_at(s, limb) : 0;
         if (limb + 1 < 8) v |= (u64)limb_at(s, limb + 1) << 32;
         u32 d = ((u32)(v >> off) & mask) + carry;
-        u32 neg = 0;
+        neg = 0;
         carry = 0;
         if (d > B) {
             d = (1u << c) - d;
             neg = 1;
             carry = 1;
         }
-        const size_t o = (size_t)w * n + i;
-        if (d == 0) {
-            keys[o] = invalid;
-            vals[o] = 0;
-        } else {
+        return d;
+    };
+    if (!count) { // fixed layout
+        if (i >= n) return;
+        keys += (size_t)blockIdx.y * W * n;
+        vals += (size_t)blockIdx.y * W * n;
+        u32 carry = 0, neg;
+        for (int w = 0; w < W; ++w) {
+            const u32 d = have ? digit(w, carry, neg) : 0;
+            const size_t o = (size_t)w * n + i;
+            keys[o] = d ? key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1)) : invalid;
+            vals[o] = d ? ((precomp ? ((u32)w * tstride + i) : i) | (neg << 31)) : 0;
+        }
+        return;
+    }
+    // pass 1: how many pairs does this wavefront produce
+    const int lane = threadIdx.x & 63;
+    u32 total = 0;
+    {
+        u32 carry = 0, neg;
+        for (int w = 0; w < W; ++w) {
+            const u32 d = have ? digit(w, carry, neg) : 0;
+            total += (u32)__popcll(__ballot(d != 0));
+        }
+    }
+    u32 base = 0;
+    if (lane == 0 && total) base = atomicAdd(count, total);
+    base = __shfl(base, 0, 64);
+    // pass 2: write them, window-major inside the wavefront's slice
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    u32 carry = 0, neg;
+    for (int w = 0; w < W; ++w) {
+        const u32 d = have ? digit(w, carry, neg) : 0;
+        const unsigned long long m = __ballot(d != 0);
+        if (d) {
+            const u32 o = base + (u32)__popcll(m & lt);
             keys[o] = key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1));
             vals[o] = (precomp ? ((u32)w * tstride + i) : i) | (neg << 31);
         }
+        base += (u32)__popcll(m);
     }
 }
 
@@ -113,13 +141,15 @@ template <class F>
 __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
                                                          u32 astride, u32 *__restrict__ buckets,
-                                                         u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T) {
+                                                         u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T,
+                                                         const u32 *__restrict__ count) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    if (count) M = *count; // compacted pairs: lanes past the last pair have nothing to do
     const size_t begin = (size_t)t * L;
     size_t end = begin + L;
     if (end > M) end = M;
-    u32 cur = keys[begin];
+    u32 cur = begin < M ? keys[begin] : invalid;
     if (cur == invalid) {
         pkeys[2 * t] = invalid;
         pkeys[2 * t + 1] = invalid;
@@ -737,7 +767,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
-                   MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0) override {
+                   MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) override {
         if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig || batch == 0 || batch > 65535) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
@@ -766,21 +796,28 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 
         // with precomputed tables the base index is w*stride + i: table w starts bs->n points after w-1
         if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
+        int end_bit = 1;
+        while ((1u << end_bit) <= invalid) ++end_bit;
+        // zero digits are compacted away by the digit kernel; how many pairs remain is known on the device only
+        u32 *d_count = nullptr;
+        if (sparse && sort_pairs_takes_device_count(end_bit)) {
+            if ((rc = ws->count.reserve(256))) return rc;
+            d_count = ws->count.as<u32>();
+            MG_HIP(hipMemsetAsync(d_count, 0, 4, s));
+        }
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256), batch), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalars_mont ? 1 : 0, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
-                           scalar_stride_words, seg_keys);
-        int end_bit = 1;
-        while ((1u << end_bit) <= invalid) ++end_bit;
+                           scalar_stride_words, seg_keys, d_count);
         if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
-                             ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s)))
+                             ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
             return rc;
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
         ws->timed = kernel_timing() && !ws->capturing;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                            ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
-                           ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T);
+                           ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * T;
         int src = 0;

@@ -453,7 +453,8 @@ class ProverImpl : public Prover {
             w->mw[i]->pending = 1;
             return MG_OK;
         }
-        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]);
+        // the z MSMs see witness scalars (mostly 0 / 1 / small): compact their zero digits; h is dense
+        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i], i != 4);
     }
     int enqueue_part_a(ProveWs *w, bool use_graphs) {
         int rc;
@@ -528,7 +529,7 @@ class ProverImpl : public Prover {
         for (int i = 0; ok && i < 5; ++i) {
             w->mw[i]->capturing = true; // no event records inside the capture: the replay path records `done`
             ok = capture_segment(msm_stream(w, i), &w->g_msm[i], [&] {
-                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i]);
+                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i], i != 4);
             });
             w->mw[i]->capturing = false;
             w->mw[i]->pending = 0;

@@ -23,8 +23,12 @@ namespace mg {
 static constexpr int SORT_TILE = 4096; // elements per workgroup: 4 waves x 16 items x 64 lanes
 static constexpr int SORT_ITEMS = 16;
 
+// (`count`: when non-null the number of elements is read from the device -- the MSM's digit kernel compacts
+// away zero digits and only it knows how many pairs are left; the grid is sized for the maximum and tiles
+// beyond the count contribute zero histograms and no elements)
 __global__ __launch_bounds__(256) void radix_hist(const u32 *__restrict__ keys, u32 M, int shift, u32 ntiles,
-                                                  u32 *__restrict__ hist) {
+                                                  u32 *__restrict__ hist, const u32 *__restrict__ count) {
+    if (count) M = *count;
     __shared__ u32 cnt[256];
     cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(256) void radix_scan_totals(u32 *__restrict__ total
 __global__ __launch_bounds__(256) void radix_scatter(const u32 *__restrict__ keys_in, const u32 *__restrict__ vals_in,
                                                      u32 *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 M,
                                                      int shift, u32 ntiles, const u32 *__restrict__ hist,
-                                                     const u32 *__restrict__ totals) {
+                                                     const u32 *__restrict__ totals, const u32 *__restrict__ count) {
+    if (count) M = *count;
     __shared__ u32 wcount[4][256]; // per-wave running digit counts, then per-wave tile-local offsets
     __shared__ u32 gbase[256];     // global position of the tile's first element of each digit, minus its local offset
     __shared__ u32 sk[SORT_TILE], sv[SORT_TILE]; // the tile, locally sorted by digit (stable)
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void radix_scatter(const u32 *__restrict__ key
         }
     }
     __syncthreads();
-    const u32 cnt = (u32)((tile0 + SORT_TILE <= M) ? SORT_TILE : (M - tile0));
+    const u32 cnt = tile0 >= M ? 0u : (u32)((tile0 + SORT_TILE <= M) ? SORT_TILE : (M - tile0));
     for (u32 t = threadIdx.x; t < cnt; t += 256) { // consecutive lanes -> consecutive addresses within a digit run
         const u32 kk = sk[t];
         const u32 pos = gbase[(kk >> shift) & 255u] + t;
@@ -170,10 +175,13 @@ size_t sort_pairs_temp_bytes(size_t n) {
     return cub > mine ? cub : mine;
 }
 
+bool sort_pairs_takes_device_count(int end_bit) { return !(use_cub() || end_bit > 24); }
+
 int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_out, size_t n, int end_bit,
-               void *tmp, size_t tmp_bytes, hipStream_t s) {
+               void *tmp, size_t tmp_bytes, hipStream_t s, const u32 *d_count) {
     if (n == 0) return MG_OK;
-    if (use_cub() || end_bit > 24) {
+    if (!sort_pairs_takes_device_count(end_bit)) {
+        if (d_count) return MG_ERR_ARG; // the library sort needs the count on the host
         MG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
                                                   end_bit, s));
         return MG_OK;
@@ -188,10 +196,10 @@ int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) % 2) == 0;
         u32 *ok = to_out ? keys_out : tk, *ov = to_out ? vals_out : tv;
-        hipLaunchKernelGGL(radix_hist, dim3(ntiles), dim3(256), 0, s, ik, M, 8 * p, ntiles, hist);
+        hipLaunchKernelGGL(radix_hist, dim3(ntiles), dim3(256), 0, s, ik, M, 8 * p, ntiles, hist, d_count);
         hipLaunchKernelGGL(radix_scan_rows, dim3(256), dim3(256), 0, s, hist, ntiles, totals);
         hipLaunchKernelGGL(radix_scan_totals, dim3(1), dim3(256), 0, s, totals);
-        hipLaunchKernelGGL(radix_scatter, dim3(ntiles), dim3(256), 0, s, ik, iv, ok, ov, M, 8 * p, ntiles, hist, totals);
+        hipLaunchKernelGGL(radix_scatter, dim3(ntiles), dim3(256), 0, s, ik, iv, ok, ov, M, 8 * p, ntiles, hist, totals, d_count);
         ik = ok;
         iv = ov;
     }

@@ -130,3 +130,29 @@ def test_msm_full_size_2_20_closed_form(gpu, curve, pre):
     ssum = synth.ints_to_limbs([(a + c) % p for a, c in zip(su, sw)], 4)
     got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(ssum), n).finish()
     assert (got == O.g_add(curve, 1, res["U"][1], res["W"][1])).all()
+
+
+@pytest.mark.parametrize("curve,group", CASES)
+@pytest.mark.parametrize("pre", [0, 9])
+def test_msm_sparse_hint_compacts_zero_digits(gpu, curve, group, pre):
+    """MG_SCALARS_SPARSE: the digit kernel drops zero digits before the sort (what the prover does for the three
+    witness MSMs). Same result as the oracle for witness-like, all-zero, single-nonzero and uniform scalars, with
+    plain bases and precomputed tables, and more bases than scalars."""
+    n = 3000
+    pts = H.random_points(curve, group, n, seed=41)
+    pts[7] = 0
+    b = gpu.Bases(curve, group, pts, precompute_window_bits=pre)
+    cases = {"W": synth.msm_scalars(curve, n, "W", seed=12), "U": synth.msm_scalars(curve, n, "U", seed=13)}
+    z = np.zeros((n, 4), dtype=np.uint64)
+    cases["zero"] = z
+    one = z.copy()
+    one[1234, 0] = 5
+    cases["single"] = one
+    for name, sc in cases.items():
+        d = gpu.DeviceBuffer.from_numpy(sc)
+        got = gpu.VariableBaseMSM.launch(b, d, n, sparse=True).finish()
+        assert (got == O.msm(curve, group, pts, sc, algo=1)).all(), name
+    m = 1777  # fewer scalars than bases: zip to the shorter
+    sc = cases["W"][:m]
+    got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(sc), m, sparse=True).finish()
+    assert (got == O.msm(curve, group, pts[:m], sc, algo=1)).all()
