@@ -29,6 +29,10 @@ static constexpr int SORT_ITEMS = 16;
 __global__ __launch_bounds__(256) void radix_hist(const u32 *__restrict__ keys, u32 M, int shift, u32 ntiles,
                                                   u32 *__restrict__ hist, const u32 *__restrict__ count) {
     if (count) M = *count;
+    if ((size_t)blockIdx.x * SORT_TILE >= M) { // a tile past the last element: an all-zero histogram column
+        hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = 0;
+        return;
+    }
     __shared__ u32 cnt[256];
     cnt[threadIdx.x] = 0;
     __syncthreads();
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void radix_scatter(const u32 *__restrict__ key
                                                      int shift, u32 ntiles, const u32 *__restrict__ hist,
                                                      const u32 *__restrict__ totals, const u32 *__restrict__ count) {
     if (count) M = *count;
+    if ((size_t)blockIdx.x * SORT_TILE >= M) return; // a tile past the last element
     __shared__ u32 wcount[4][256]; // per-wave running digit counts, then per-wave tile-local offsets
     __shared__ u32 gbase[256];     // global position of the tile's first element of each digit, minus its local offset
     __shared__ u32 sk[SORT_TILE], sv[SORT_TILE]; // the tile, locally sorted by digit (stable)
