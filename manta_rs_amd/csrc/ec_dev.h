@@ -240,4 +240,74 @@ template <class F> struct XYZZ {
     }
 };
 
+// ---- cooperative addition: one group addition spread over the FOUR wavefronts of a 256-thread workgroup --------
+// The latency-bound tails of an MSM (bucket reduce, the last merge levels) are chains of dependent additions
+// executed by a single wavefront -- ~30 us per step over Fp2. The 14 field products of an addition form four
+// dependency levels of at most four independent products (add-2008-s):
+//     U1 U2 S1 S2  |  PP RR Z12 Z123  |  PPP Q ZZ3  |  T V ZZZ3
+// so four wavefronts that hold IDENTICAL copies of (acc, o) in their registers each compute one product per level
+// and swap the results through LDS (one barrier per level). All the linear work and the exceptional cases
+// (infinity on either side, P = Q -> doubling, P = -Q) are evaluated redundantly and identically by every wave, so
+// the copies stay bit-identical. `lds` = 2 x 4 x F::N x 64 words (double-buffered exchange area).
+template <class F> struct CoopAdd {
+    static constexpr int SLOT = F::N * 64;
+    static constexpr int LDS_WORDS = 2 * 4 * SLOT;
+    // publish this wave's product, fetch all four
+    static MG_DEV void swap(u32 *buf, int wave, int lane, const F &mine, F (&all)[4]) {
+        mine.store_strided(buf + wave * SLOT + lane, 64);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) all[q] = F::load_strided(buf + q * SLOT + lane, 64);
+    }
+    static MG_DEV void add(XYZZ<F> &acc, const XYZZ<F> &o, u32 *lds, int wave, int lane) {
+        constexpr int BX = F::BX, BY = F::BY, BM = F::BM;
+        const bool o_inf = o.is_inf(), a_inf = acc.is_inf();
+        F mine, r[4];
+        // level 1
+        if (wave == 0) mine = (bv<BX>(acc.x) * bv<BM>(o.zz)).v;        // U1
+        else if (wave == 1) mine = (bv<BX>(o.x) * bv<BM>(acc.zz)).v;   // U2
+        else if (wave == 2) mine = (bv<BY>(acc.y) * bv<BM>(o.zzz)).v;  // S1
+        else mine = (bv<BY>(o.y) * bv<BM>(acc.zzz)).v;                 // S2
+        swap(lds, wave, lane, mine, r);
+        const auto U1 = bv<BM>(r[0]), U2 = bv<BM>(r[1]), S1 = bv<BM>(r[2]), S2 = bv<BM>(r[3]);
+        const auto P = U2 - U1;
+        const auto R = S2 - S1;
+        const bool p0 = b_is_zero(P), r0 = b_is_zero(R);
+        // level 2
+        if (wave == 0) mine = b_sqr(P).v;                                // PP
+        else if (wave == 1) mine = b_sqr(R).v;                           // RR
+        else if (wave == 2) mine = (bv<BM>(acc.zz) * bv<BM>(o.zz)).v;    // Z12
+        else mine = (bv<BM>(acc.zzz) * bv<BM>(o.zzz)).v;                 // Z123
+        swap(lds + 4 * SLOT, wave, lane, mine, r);
+        const auto PP = bv<BM>(r[0]), RR = bv<BM>(r[1]), Z12 = bv<BM>(r[2]), Z123 = bv<BM>(r[3]);
+        // level 3
+        if (wave == 0) mine = (P * PP).v;         // PPP
+        else if (wave == 1) mine = (U1 * PP).v;   // Q
+        else if (wave == 2) mine = (Z12 * PP).v;  // ZZ3
+        else mine = F::zero();
+        swap(lds, wave, lane, mine, r);
+        const auto PPP = bv<BM>(r[0]), Q = bv<BM>(r[1]);
+        const F ZZ3 = r[2];
+        const auto X3 = b_fit<BX>(b_sub2(RR, PPP, Q)); // R^2 - PPP - 2Q
+        // level 4
+        if (wave == 0) mine = (R * (Q - X3)).v;   // T
+        else if (wave == 1) mine = (S1 * PPP).v;  // V
+        else if (wave == 2) mine = (Z123 * PPP).v; // ZZZ3
+        else mine = F::zero();
+        swap(lds + 4 * SLOT, wave, lane, mine, r);
+        const auto Y3 = b_fit<BY>(bv<BM>(r[0]) - bv<BM>(r[1]));
+        XYZZ<F> sum{X3.v, Y3.v, ZZ3, r[2]};
+        // exceptional cases, decided identically in every wave
+        if (o_inf) {
+            sum = acc;
+        } else if (a_inf) {
+            sum = o;
+        } else if (p0) {
+            if (r0) sum = XYZZ<F>::dbl(acc);
+            else sum = XYZZ<F>::inf();
+        }
+        acc = sum;
+    }
+};
+
 } // namespace mg

@@ -266,6 +266,17 @@ template <class C> struct FpR {
 #pragma unroll
         for (int i = 0; i < K; ++i) p[i] = v[i];
     }
+    // limb i at p[i * stride]: LDS exchange areas keep one limb of all 64 lanes together (no bank conflicts)
+    static MG_DEV FpR load_strided(const u32 *p, int stride) {
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = p[i * stride];
+        return r;
+    }
+    MG_DEV void store_strided(u32 *p, int stride) const {
+#pragma unroll
+        for (int i = 0; i < K; ++i) p[i * stride] = v[i];
+    }
     static MG_DEV FpR select(bool c, const FpR &a, const FpR &b) {
         FpR r;
 #pragma unroll
@@ -346,6 +357,13 @@ template <class C> struct Fp2R {
     }
     static MG_DEV Fp2R from_std(const Std &s) { return Fp2R{B::from_std(s.c0), B::from_std(s.c1)}; }
     MG_DEV Std to_std() const { return Std{c0.to_std(), c1.to_std()}; }
+    static MG_DEV Fp2R load_strided(const u32 *p, int stride) {
+        return Fp2R{B::load_strided(p, stride), B::load_strided(p + B::N * stride, stride)};
+    }
+    MG_DEV void store_strided(u32 *p, int stride) const {
+        c0.store_strided(p, stride);
+        c1.store_strided(p + B::N * stride, stride);
+    }
     static MG_DEV Fp2R load(const u32 *p) { return Fp2R{B::load(p), B::load(p + B::N)}; }
     MG_DEV void store(u32 *p) const {
         c0.store(p);

@@ -332,6 +332,53 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
     }
 }
 
+// The same with the additions spread over the four wavefronts of the workgroup (CoopAdd, ec_dev.h): one tile per
+// workgroup, every wave holds the same 64 items. For the few-tile reduces of proof-sized MSMs, where the kernel is
+// nothing but a chain of dependent additions.
+template <class F>
+__global__ __launch_bounds__(256) void tile_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/,
+                                                        u32 item_off, u32 n_items, u32 tiles_per_seg,
+                                                        u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
+    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    const u32 tile_id = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 seg = tile_id / tiles_per_seg, tile = tile_id % tiles_per_seg;
+    const u32 idx = tile * 64 + lane;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (idx < n_items) acc = XYZZ<F>::load(in + ((size_t)seg * seg_stride + item_off + idx) * XYZZ<F>::WORDS);
+    int top = 1;
+    {
+        const u32 left = n_items - tile * 64;
+        const int lim = left < 64 ? (int)left : 64;
+        while (top < lim) top <<= 1;
+    }
+    for (int d = 1; d < top; d <<= 1) { // suffix scan
+        XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+        if (lane + d >= 64) o = XYZZ<F>::inf();
+        CoopAdd<F>::add(acc, o, lds, wave, lane);
+    }
+    constexpr int SW = XYZZ<typename F::Std>::WORDS;
+    if (threadIdx.x == 0) {
+        if (std_out)
+            acc.store_std(outA + (size_t)tile_id * SW);
+        else
+            acc.store(outA + (size_t)tile_id * XYZZ<F>::WORDS);
+    }
+    if (outS) {
+        for (int d = top >> 1; d >= 1; d >>= 1) { // tree sum of the suffix sums
+            XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+            if (lane >= d) o = XYZZ<F>::inf();
+            CoopAdd<F>::add(acc, o, lds, wave, lane);
+        }
+        if (threadIdx.x == 0) {
+            if (std_out)
+                acc.store_std(outS + (size_t)tile_id * SW);
+            else
+                acc.store(outS + (size_t)tile_id * XYZZ<F>::WORDS);
+        }
+    }
+}
+
 // Second (last) reduce level for 2 <= T0 <= 64 tiles per window, ONE launch, two wavefronts per window on
 // different SIMDs: wave 0 turns the tile totals A_t into X = sum_{t>=1} t*A_t (suffix scan + tree sum, only
 // ceil(log2 T0) steps each), wave 1 sums the S_t. The host gets (X, sumS): window sum = sumS + 64*X.
@@ -756,6 +803,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         return p;
     }
 
+    // few tiles = a pure latency chain: spread each addition over the workgroup's four wavefronts
+    static bool coop_tiles(u32 tiles) {
+        static const int lim = [] {
+            const char *e = getenv("MANTA_COOP_TILES");
+            return e ? atoi(e) : 64;
+        }();
+        return (int)tiles <= lim;
+    }
     static u32 merge_g1() {
         static const u32 g = [] {
             const char *e = getenv("MANTA_MERGE_G");
@@ -843,8 +898,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         constexpr int XWM = XW > XW_IO ? XW : XW_IO;
         if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
-            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                               pl.B, 0u, pl.B, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
+            if (coop_tiles(segs))
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, s, ws->buckets.as<u32>(), pl.B, 0u, pl.B, 1u,
+                                   ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
+            else
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                                   pl.B, 0u, pl.B, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             stage_pts = segs;
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
@@ -852,8 +911,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
                 (rc = ws->misc.reserve((size_t)segs * 2 * XW_IO * 4)))
                 return rc;
-            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                               pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
+            if (coop_tiles(segs * T0))
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs * T0), dim3(256), 0, s, ws->buckets.as<u32>(), pl.B, 0u, pl.B,
+                                   T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
+            else
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
+                                   pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
             hipLaunchKernelGGL((reduce_level1<F>), dim3(segs), dim3(128), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(), T0,
                                ws->misc.as<u32>());
             stage_pts = (size_t)segs * 2;
