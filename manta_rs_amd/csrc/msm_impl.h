@@ -286,6 +286,106 @@ __global__ __launch_bounds__(256) void merge_partials(u32 *__restrict__ pkeys, u
     }
 }
 
+// K7b with cooperative additions (CoopAdd, ec_dev.h): one 64-entry-wide "logical wave" per 256-thread workgroup,
+// its four wavefronts hold identical copies of the lanes' state and share every addition. Same contract as
+// merge_partials; used for the levels with few logical waves, which are nothing but dependent additions.
+template <class F>
+__global__ __launch_bounds__(256) void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
+                                                           u32 invalid, int final_level, u32 *__restrict__ buckets,
+                                                           u32 *__restrict__ okeys, u32 *__restrict__ opts) {
+    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    constexpr size_t XW = XYZZ<F>::WORDS;
+    const u32 wave = blockIdx.x; // logical wave
+    const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    const bool writer = pw == 0; // identical data in the four wavefronts: one of them stores
+    const size_t b = ((size_t)wave * 64 + lane) * G;
+    u32 kh = invalid, cur = invalid;
+    bool single = true, live = false;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (b < cnt) {
+        cur = pkeys[b];
+        if (cur != invalid) {
+            kh = cur;
+            acc = XYZZ<F>::load(ppts + b * XW);
+            live = true;
+        }
+    }
+    for (u32 off = 1; off < G; ++off) { // uniform trip count: the additions below contain barriers
+        const size_t j = b + off;
+        const bool have = live && j < cnt;
+        const u32 k = have ? pkeys[j] : invalid;
+        XYZZ<F> p = XYZZ<F>::inf();
+        if (have && k != invalid) p = XYZZ<F>::load(ppts + j * XW);
+        const bool same = have && k == cur;
+        if (have && k != cur) { // a run ended: the first one is parked in slot b, later ones are complete
+            if (writer) acc.store(single ? ppts + b * XW : buckets + (size_t)cur * XW);
+            single = false;
+            cur = k;
+            acc = p;
+            if (k == invalid) live = false;
+        }
+        if (__any(same && !p.is_inf())) {
+            const XYZZ<F> o = same ? p : XYZZ<F>::inf();
+            CoopAdd<F>::add(acc, o, lds, pw, lane);
+        }
+    }
+    const u32 kt = cur;
+    __threadfence_block(); // the parked head runs are re-read by all four wavefronts
+    __syncthreads();
+    // inclusive segmented scan over (kt, acc)
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 nk = __shfl_up(kt, d, 64);
+        const bool take = (lane >= d) && (nk == kt) && (kt != invalid);
+        if (!__any(take)) break;
+        XYZZ<F> o = XYZZ<F>::shfl(acc, lane - d < 0 ? lane : lane - d);
+        if (!take) o = XYZZ<F>::inf();
+        CoopAdd<F>::add(acc, o, lds, pw, lane);
+    }
+    const u32 prev_kt = __shfl_up(kt, 1, 64), next_kh = __shfl_down(kh, 1, 64);
+    const u32 key0 = __shfl(kh, 0, 64);
+    const bool need_in = !single && lane > 0 && prev_kt == kh;
+    const bool any_in = __any(need_in);
+    XYZZ<F> prev = XYZZ<F>::inf();
+    if (any_in) prev = XYZZ<F>::shfl(acc, lane > 0 ? lane - 1 : 0);
+    const bool cont = lane < 63 && next_kh == kt;
+    if (writer && kt != invalid && !cont) {
+        if (final_level) {
+            acc.store(buckets + (size_t)kt * XW);
+        } else if (kt == key0) {
+            okeys[2 * wave] = kt;
+            acc.store(opts + (size_t)(2 * wave) * XW);
+            if (lane == 63) {
+                okeys[2 * wave + 1] = kt;
+                XYZZ<F>::inf().store(opts + (size_t)(2 * wave + 1) * XW);
+            }
+        } else if (lane == 63) {
+            okeys[2 * wave + 1] = kt;
+            acc.store(opts + (size_t)(2 * wave + 1) * XW);
+        } else {
+            acc.store(buckets + (size_t)kt * XW);
+        }
+    }
+    if (writer && !final_level && lane == 63 && kt == invalid) {
+        okeys[2 * wave + 1] = invalid;
+        if (key0 == invalid) okeys[2 * wave] = invalid;
+    }
+    // head runs
+    XYZZ<F> h = XYZZ<F>::inf();
+    if (!single) h = XYZZ<F>::load(ppts + b * XW);
+    if (any_in) {
+        if (!need_in) prev = XYZZ<F>::inf();
+        CoopAdd<F>::add(h, prev, lds, pw, lane);
+    }
+    if (writer && !single) {
+        if (!final_level && kh == key0) {
+            okeys[2 * wave] = kh;
+            h.store(opts + (size_t)(2 * wave) * XW);
+        } else {
+            h.store(buckets + (size_t)kh * XW);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // K8: per-tile weighted sum. For the 64 items X_0..X_63 of a tile (missing items = infinity):
 //   A = sum_j X_j,  S = sum_j (j+1) X_j  -- via suffix scan (acc_j = sum_{i>=j} X_i) then sum of acc_j.
@@ -811,6 +911,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }();
         return (int)tiles <= lim;
     }
+    static u32 coop_waves() { // merge levels with at most this many 64-entry waves use the cooperative kernel
+        static const u32 lim = [] {
+            const char *e = getenv("MANTA_COOP_WAVES");
+            return (u32)(e ? atoi(e) : 256);
+        }();
+        return lim;
+    }
     static u32 merge_g1() {
         static const u32 g = [] {
             const char *e = getenv("MANTA_MERGE_G");
@@ -883,9 +990,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if (cnt <= 512) G = cnt <= 64 ? 1 : cdiv(cnt, 64);
             const u32 waves = cdiv(cdiv(cnt, G), 64);
             const int fin = waves == 1;
-            hipLaunchKernelGGL((merge_partials<F>), dim3(cdiv(waves, 4)), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
-                               ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
-                               ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves);
+            if (waves <= coop_waves())
+                hipLaunchKernelGGL((merge_partials_coop<F>), dim3(waves), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
+                                   ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
+                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>());
+            else
+                hipLaunchKernelGGL((merge_partials<F>), dim3(cdiv(waves, 4)), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
+                                   ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
+                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves);
             if (fin) break;
             cnt = 2 * waves;
             src ^= 1;
