@@ -1046,10 +1046,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             u32 *A1 = ws->misc.as<u32>();
             u32 *S1 = A1 + (size_t)segs * T1 * XW_IO;
             u32 *P0 = S1 + (size_t)segs * T1 * XW_IO;
-            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T1, 4)), dim3(256), 0, s,
-                               ws->redA.as<u32>(), T0, 1u, T0 - 1, T1, segs * T1, A1, S1, 1);
-            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * nP, 4)), dim3(256), 0, s,
-                               ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr, 1);
+            if (coop_tiles(segs * T1))
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs * T1), dim3(256), 0, s, ws->redA.as<u32>(), T0, 1u, T0 - 1, T1,
+                                   A1, S1, 1);
+            else
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T1, 4)), dim3(256), 0, s,
+                                   ws->redA.as<u32>(), T0, 1u, T0 - 1, T1, segs * T1, A1, S1, 1);
+            if (coop_tiles(segs * nP))
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs * nP), dim3(256), 0, s, ws->redS.as<u32>(), T0, 0u, T0, nP, P0,
+                                   (u32 *)nullptr, 1);
+            else
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * nP, 4)), dim3(256), 0, s,
+                                   ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr, 1);
             stage_pts = (size_t)segs * (2 * T1 + nP);
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
