@@ -272,9 +272,11 @@ class ProverImpl : public Prover {
             h_bs_ = h_bs_wide_ = nullptr;
             // The h MSM is the one with dense, uniform scalars -- half of all the mixed additions of a proof at
             // c = 8. Wider windows halve them, but lengthen its bucket reduce: measured on PrivateTransfer,
-            // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32) but 2-5 % slower
-            // single proofs. The table is small (80 MB), so single proofs keep c = 8 and batches get their own.
+            // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32); for single proofs the
+            // reduce chain matters more (with the cooperative reduce: c_h = 8/10/12 -> 839 / 859 / 862 proofs/s).
+            // The tables are small (80 MB), so single proofs and batches each get their own width.
             int ch = pre_c_for(D), ch_wide = ch;
+            if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
             if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
             if ((rc = g1_->bases_create(perm.data(), D, false, ch, &h_bs_))) return rc;
