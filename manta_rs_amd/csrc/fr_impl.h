@@ -169,6 +169,30 @@ __global__ __launch_bounds__(256) void spmv_kernel(const u32 *__restrict__ row_p
     acc.store(out + (size_t)i * 8);
 }
 
+// the same for three matrices at once (blockIdx.z): A z, B z, C z of the witness map
+struct Csr3 {
+    const u32 *row_ptr[3], *col[3], *val[3];
+    u32 *out[3];
+};
+template <class FrC>
+__global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, size_t z_stride, size_t out_stride) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int t = blockIdx.z;
+    const u32 *__restrict__ row_ptr = M.row_ptr[t], *__restrict__ col = M.col[t], *__restrict__ val = M.val[t];
+    z += (size_t)blockIdx.y * z_stride; // batch member
+    u32 *__restrict__ out = M.out[t] + (size_t)blockIdx.y * out_stride;
+    typedef Fp<FrC> F;
+    F acc = F::zero();
+    const F one = F::one();
+    for (u32 k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+        F c = F::load(val + (size_t)k * 8);
+        F x = F::load(z + (size_t)col[k] * 8);
+        acc = F::add(acc, c == one ? x : F::mul(x, c));
+    }
+    acc.store(out + (size_t)i * 8);
+}
+
 template <class FrC>
 __global__ __launch_bounds__(256) void qap_pointwise_kernel(u32 *__restrict__ a, const u32 *__restrict__ b,
                                                             const u32 *__restrict__ c, const u32 *__restrict__ zinv,
@@ -358,6 +382,15 @@ template <class FrC> class FrEngineT : public FrEngine {
         if (m == 0) return MG_OK;
         hipLaunchKernelGGL((spmv_kernel<FrC>), dim3((u32)((m + 255) / 256), batch), dim3(256), 0, s, M.row_ptr, M.col, M.val,
                            d_z, d_out, (u32)m, z_stride, out_stride);
+        MG_HIP(hipGetLastError());
+        return MG_OK;
+    }
+    int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m,
+              hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0) override {
+        if (m == 0) return MG_OK;
+        Csr3 M{{A.row_ptr, B.row_ptr, C.row_ptr}, {A.col, B.col, C.col}, {A.val, B.val, C.val}, {d_a, d_b, d_c}};
+        hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((m + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m,
+                           z_stride, out_stride);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }

@@ -42,7 +42,7 @@ namespace {
 // slower). The launch streams are high-priority pooled streams: see stream_pool_get() for the runtime defect
 // that makes this necessary for multi-branch graphs.
 struct ProveWs {
-    DevBuf z, a, b, c;
+    DevBuf z, a; // a holds the three work vectors a | b | c back to back (one allocation, one memset)
     hipStream_t stream = nullptr;             // witness map (and the launch stream of the main graph); the G1 MSMs join back into it
     hipStream_t side[2] = {nullptr, nullptr}; // [0]: the G2 MSM (the longest chain); [1]: a, b_g1, l in MANTA_PROVE_STREAMS=3 mode
     hipEvent_t z_ready = nullptr, h_ready = nullptr, fork = nullptr;
@@ -79,8 +79,6 @@ struct ProveWs {
             }
         z.release();
         a.release();
-        b.release();
-        c.release();
         if (h_z) hipHostFree(h_z);
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
@@ -347,9 +345,7 @@ class ProverImpl : public Prover {
     int reserve_witness_map(ProveWs *w) {
         const size_t D = (size_t)1 << log_d_, k = w->k;
         int rc;
-        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(k * D * 32)) || (rc = w->b.reserve(k * D * 32)) ||
-            (rc = w->c.reserve(k * D * 32)))
-            return rc;
+        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(3 * k * D * 32))) return rc;
         return MG_OK;
     }
     // everything after the upload of z, on w->stream (this is what the witness-map graph captures)
@@ -357,14 +353,10 @@ class ProverImpl : public Prover {
         const size_t D = (size_t)1 << log_d_, k = w->k;
         int rc;
         hipStream_t s = w->stream;
-        MG_HIP(hipMemsetAsync(w->a.p, 0, k * D * 32, s));
-        MG_HIP(hipMemsetAsync(w->b.p, 0, k * D * 32, s));
-        MG_HIP(hipMemsetAsync(w->c.p, 0, k * D * 32, s));
-        u32 *a = w->a.as<u32>(), *b = w->b.as<u32>(), *c = w->c.as<u32>(), *zz = w->z.as<u32>();
+        MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * 32, s));
+        u32 *a = w->a.as<u32>(), *b = a + k * D * 8, *c = b + k * D * 8, *zz = w->z.as<u32>();
         const size_t zs = (size_t)V_ * 8, ds = D * 8;
-        if ((rc = fr_->spmv(A_, zz, a, m_, s, (u32)k, zs, ds)) || (rc = fr_->spmv(B_, zz, b, m_, s, (u32)k, zs, ds)) ||
-            (rc = fr_->spmv(C_, zz, c, m_, s, (u32)k, zs, ds)))
-            return rc;
+        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, s, (u32)k, zs, ds))) return rc;
         // input-consistency rows: a[m + j] = z_j for j < P (mpc.rs:299-312)
         MG_HIP(hipMemcpy2DAsync(a + (size_t)m_ * 8, D * 32, zz, V_ * 32, P_ * 32, k, hipMemcpyDeviceToDevice, s));
         // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
