@@ -511,6 +511,39 @@ __global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0,
     if (lane == 0) acc.store_std(out_std + ((size_t)seg * 2 + wave) * SW);
 }
 
+// reduce_level1 with cooperative additions: two 256-thread workgroups per window (blockIdx.x & 1: 0 = the X part,
+// 1 = the sum of the S_t), each spreading its additions over its four wavefronts.
+template <class F>
+__global__ __launch_bounds__(256) void reduce_level1_coop(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
+                                                          u32 *__restrict__ out_std) {
+    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    constexpr int XW = XYZZ<F>::WORDS;
+    constexpr int SW = XYZZ<typename F::Std>::WORDS;
+    const u32 seg = blockIdx.x >> 1;
+    const int part = blockIdx.x & 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int top = 1;
+    while (top < (int)T0) top <<= 1;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (part == 0) { // X = sum_{t>=1} t*A_t  =  sum_{j>=1} (sum_{t>=j} A_t)
+        if (lane >= 1 && lane < (int)T0) acc = XYZZ<F>::load(A0 + ((size_t)seg * T0 + lane) * XW);
+        for (int d = 1; d < top; d <<= 1) {
+            XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+            if (lane + d >= 64) o = XYZZ<F>::inf();
+            CoopAdd<F>::add(acc, o, lds, wave, lane);
+        }
+        if (lane == 0) acc = XYZZ<F>::inf(); // lane 0's suffix (the total) carries weight 0
+    } else {
+        if (lane < (int)T0) acc = XYZZ<F>::load(S0 + ((size_t)seg * T0 + lane) * XW);
+    }
+    for (int d = top >> 1; d >= 1; d >>= 1) {
+        XYZZ<F> o = XYZZ<F>::shfl(acc, lane + d > 63 ? lane : lane + d);
+        if (lane >= d) o = XYZZ<F>::inf();
+        CoopAdd<F>::add(acc, o, lds, wave, lane);
+    }
+    if (threadIdx.x == 0) acc.store_std(out_std + ((size_t)seg * 2 + part) * SW);
+}
+
 // arkworks-format affine bases -> internal representation (identity copy when the two coincide)
 template <class F>
 __global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out,
@@ -1029,8 +1062,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             else
                 hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
                                    pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
-            hipLaunchKernelGGL((reduce_level1<F>), dim3(segs), dim3(128), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(), T0,
-                               ws->misc.as<u32>());
+            if (coop_tiles(segs * 2))
+                hipLaunchKernelGGL((reduce_level1_coop<F>), dim3(segs * 2), dim3(256), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(),
+                                   T0, ws->misc.as<u32>());
+            else
+                hipLaunchKernelGGL((reduce_level1<F>), dim3(segs), dim3(128), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(), T0,
+                                   ws->misc.as<u32>());
             stage_pts = (size_t)segs * 2;
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
