@@ -947,17 +947,22 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     static u32 coop_waves() { // merge levels with at most this many 64-entry waves use the cooperative kernel
         static const u32 lim = [] {
             const char *e = getenv("MANTA_COOP_WAVES");
-            return (u32)(e ? atoi(e) : 256);
+            return (u32)(e ? atoi(e) : 512);
         }();
         return lim;
     }
-    static u32 merge_g1() {
+    // entries folded serially per lane in the first merge level. Large MSMs: 4 (throughput). Proof-sized MSMs: 16 --
+    // the level then has few enough logical waves (<= coop_waves()) for the cooperative kernel, whose additions
+    // cost a third: 15 cooperative serial steps + the scan beat 3 plain steps + the scan and shrink the next level
+    // (PrivateTransfer: G = 4 / 8 / 16 / 32 -> 865 / 927 / 955 / 832 proofs/s).
+    static u32 merge_g1(size_t M) {
         static const u32 g = [] {
             const char *e = getenv("MANTA_MERGE_G");
             const int v = e ? atoi(e) : 0;
-            return (u32)(v >= 1 && v <= 64 ? v : 4);
+            return (u32)(v >= 1 && v <= 64 ? v : 0);
         }();
-        return g;
+        if (g) return g;
+        return M < ((size_t)8 << 20) ? 16u : 4u;
     }
 
     // ---------------------------------------------------------------- launch
@@ -1019,7 +1024,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         for (int level = 0;; ++level) {
             // entries folded serially per lane: the first level is throughput-bound (as many entries as
             // accumulate lanes x 2), later ones are pure latency; <= 512 entries finish in one wave
-            u32 G = level == 0 ? merge_g1() : 2;
+            u32 G = level == 0 ? merge_g1(M) : 2;
             if (cnt <= 512) G = cnt <= 64 ? 1 : cdiv(cnt, 64);
             const u32 waves = cdiv(cdiv(cnt, G), 64);
             const int fin = waves == 1;
