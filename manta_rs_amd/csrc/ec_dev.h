@@ -248,16 +248,20 @@ template <class F> struct XYZZ {
 // so four wavefronts that hold IDENTICAL copies of (acc, o) in their registers each compute one product per level
 // and swap the results through LDS (one barrier per level). All the linear work and the exceptional cases
 // (infinity on either side, P = Q -> doubling, P = -Q) are evaluated redundantly and identically by every wave, so
-// the copies stay bit-identical. `lds` = 2 x 4 x F::N x 64 words (double-buffered exchange area).
+// the copies stay bit-identical. `lds` = 2 x 4 exchange slots of F::XWORDS words (double-buffered).
 template <class F> struct CoopAdd {
-    static constexpr int SLOT = F::N * 64;
-    static constexpr int LDS_WORDS = 2 * 4 * SLOT;
-    // publish this wave's product, fetch all four
+    static constexpr int SLOT = F::XWORDS;
+    // two exchange areas used alternately (one barrier per level) while they fit 48 KB; the largest field (Fp2 over
+    // BLS12-381: 8 KB per slot) uses one area and a second barrier per level instead
+    static constexpr bool DOUBLE = 2 * 4 * SLOT * 4 <= 49152;
+    static constexpr int LDS_WORDS = (DOUBLE ? 2 : 1) * 4 * SLOT;
+    // publish this wave's product, fetch all four (16-byte LDS accesses)
     static MG_DEV void swap(u32 *buf, int wave, int lane, const F &mine, F (&all)[4]) {
-        mine.store_strided(buf + wave * SLOT + lane, 64);
+        mine.store_x(buf + wave * SLOT, lane);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) all[q] = F::load_strided(buf + q * SLOT + lane, 64);
+        for (int q = 0; q < 4; ++q) all[q] = F::load_x(buf + q * SLOT, lane);
+        if (!DOUBLE) __syncthreads();
     }
     static MG_DEV void add(XYZZ<F> &acc, const XYZZ<F> &o, u32 *lds, int wave, int lane) {
         constexpr int BX = F::BX, BY = F::BY, BM = F::BM;
@@ -278,7 +282,7 @@ template <class F> struct CoopAdd {
         else if (wave == 1) mine = b_sqr(R).v;                           // RR
         else if (wave == 2) mine = (bv<BM>(acc.zz) * bv<BM>(o.zz)).v;    // Z12
         else mine = (bv<BM>(acc.zzz) * bv<BM>(o.zzz)).v;                 // Z123
-        swap(lds + 4 * SLOT, wave, lane, mine, r);
+        swap(lds + (DOUBLE ? 4 * SLOT : 0), wave, lane, mine, r);
         const auto PP = bv<BM>(r[0]), RR = bv<BM>(r[1]), Z12 = bv<BM>(r[2]), Z123 = bv<BM>(r[3]);
         // level 3
         if (wave == 0) mine = (P * PP).v;         // PPP
@@ -294,7 +298,7 @@ template <class F> struct CoopAdd {
         else if (wave == 1) mine = (S1 * PPP).v;  // V
         else if (wave == 2) mine = (Z123 * PPP).v; // ZZZ3
         else mine = F::zero();
-        swap(lds + 4 * SLOT, wave, lane, mine, r);
+        swap(lds + (DOUBLE ? 4 * SLOT : 0), wave, lane, mine, r);
         const auto Y3 = b_fit<BY>(bv<BM>(r[0]) - bv<BM>(r[1]));
         XYZZ<F> sum{X3.v, Y3.v, ZZ3, r[2]};
         // exceptional cases, decided identically in every wave

@@ -277,6 +277,33 @@ template <class C> struct FpR {
 #pragma unroll
         for (int i = 0; i < K; ++i) p[i * stride] = v[i];
     }
+    // LDS exchange format of the cooperative addition: quads of limbs, one 16-byte access per lane and quad
+    // (quad q of lane l at word (q*64 + l)*4): a 9-limb element is 3 ds_*_b128 instead of 9 ds_*_b32
+    static constexpr int XQ = (K + 3) / 4;         // quads per element
+    static constexpr int XWORDS = XQ * 64 * 4;     // words of one exchange slot (64 lanes)
+    MG_DEV void store_x(u32 *slot, int lane) const {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            uint4 t;
+            t.x = v[4 * q];
+            t.y = 4 * q + 1 < K ? v[4 * q + 1] : 0u;
+            t.z = 4 * q + 2 < K ? v[4 * q + 2] : 0u;
+            t.w = 4 * q + 3 < K ? v[4 * q + 3] : 0u;
+            *reinterpret_cast<uint4 *>(slot + ((size_t)q * 64 + lane) * 4) = t;
+        }
+    }
+    static MG_DEV FpR load_x(const u32 *slot, int lane) {
+        FpR r;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(slot + ((size_t)q * 64 + lane) * 4);
+            r.v[4 * q] = t.x;
+            if (4 * q + 1 < K) r.v[4 * q + 1] = t.y;
+            if (4 * q + 2 < K) r.v[4 * q + 2] = t.z;
+            if (4 * q + 3 < K) r.v[4 * q + 3] = t.w;
+        }
+        return r;
+    }
     static MG_DEV FpR select(bool c, const FpR &a, const FpR &b) {
         FpR r;
 #pragma unroll
@@ -357,6 +384,12 @@ template <class C> struct Fp2R {
     }
     static MG_DEV Fp2R from_std(const Std &s) { return Fp2R{B::from_std(s.c0), B::from_std(s.c1)}; }
     MG_DEV Std to_std() const { return Std{c0.to_std(), c1.to_std()}; }
+    static constexpr int XWORDS = 2 * B::XWORDS;
+    MG_DEV void store_x(u32 *slot, int lane) const {
+        c0.store_x(slot, lane);
+        c1.store_x(slot + B::XWORDS, lane);
+    }
+    static MG_DEV Fp2R load_x(const u32 *slot, int lane) { return Fp2R{B::load_x(slot, lane), B::load_x(slot + B::XWORDS, lane)}; }
     static MG_DEV Fp2R load_strided(const u32 *p, int stride) {
         return Fp2R{B::load_strided(p, stride), B::load_strided(p + B::N * stride, stride)};
     }

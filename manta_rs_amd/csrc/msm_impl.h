@@ -293,7 +293,7 @@ template <class F>
 __global__ __launch_bounds__(256) void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                            u32 invalid, int final_level, u32 *__restrict__ buckets,
                                                            u32 *__restrict__ okeys, u32 *__restrict__ opts) {
-    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x; // logical wave
     const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
@@ -439,7 +439,7 @@ template <class F>
 __global__ __launch_bounds__(256) void tile_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                         u32 item_off, u32 n_items, u32 tiles_per_seg,
                                                         u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
-    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     const u32 tile_id = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 seg = tile_id / tiles_per_seg, tile = tile_id % tiles_per_seg;
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0,
 template <class F>
 __global__ __launch_bounds__(256) void reduce_level1_coop(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
                                                           u32 *__restrict__ out_std) {
-    __shared__ u32 lds[CoopAdd<F>::LDS_WORDS];
+    __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr int XW = XYZZ<F>::WORDS;
     constexpr int SW = XYZZ<typename F::Std>::WORDS;
     const u32 seg = blockIdx.x >> 1;
