@@ -17,9 +17,13 @@
  *     byte-identical to `proof_as_bytes` (manta-crypto/src/arkworks/groth16.rs:186-195)
  *   - every function returns 0 on success; any non-zero maps to the reference's opaque unit `Error`
  *     (groth16.rs:50-60). No exceptions, no abort. mg_strerror()/mg_last_error() give detail.
- *   - one process per GPU; objects belong to the HIP device current at creation. All entry points are
- *     re-entrant; `mg_groth16_prove` may be called concurrently on one context (the reference's
- *     `prove` takes `&ProvingContext`, groth16.rs:589-596).
+ *   - objects belong to the HIP device current at creation (or to the devices of the list a `_sharded`
+ *     constructor was given) and remember it: calls on them may come from any thread, whatever that
+ *     thread's current device. One process per GPU (torch.distributed / RCCL between them) and one process
+ *     driving several GPUs (the `_sharded` entry points) are both supported.
+ *   - all entry points are re-entrant; `mg_groth16_prove` may be called concurrently on one context (the
+ *     reference's `prove` takes `&ProvingContext`, groth16.rs:589-596). `mg_ctx_set_r1cs` is the one mutator:
+ *     it waits for the proofs in flight on the context, and proofs that start later see the new circuit.
  *   - the library never retains host pointers after a call returns.
  */
 #ifndef MANTAGPU_H
@@ -77,6 +81,13 @@ float mg_last_accumulate_ms(void);
  * windows then share one bucket set and no doubling chain remains); 0 = plain bases. */
 int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, int on_device,
                     int precompute_window_bits, mg_bases **out);
+/* The same vector range-sharded over a list of devices ("MSM shards by scalar/base
+ * range across the GPUs of one node"): shard g = points [n*g/G, n*(g+1)/G) on devices[g], host pointer only. A
+ * device may appear more than once (functional testing of the multi-GPU path on one GPU). */
+int mg_bases_create_sharded(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, const int *devices,
+                            int n_devices, int precompute_window_bits, mg_bases **out);
+int mg_bases_num_shards(const mg_bases *bases);
+int mg_bases_shard(const mg_bases *bases, int shard, int *device, size_t *lo, size_t *hi);
 void mg_bases_destroy(mg_bases *bases);
 size_t mg_bases_device_bytes(const mg_bases *bases);
 /* Host-to-host convenience: result = sum_i scalars[i] * bases[i], i < n <= len(bases).
@@ -90,7 +101,12 @@ int mg_msm(const mg_bases *bases, const uint64_t *scalars_canonical, size_t n, u
 #define MG_SCALARS_SPARSE 2
 int mg_msm_launch(const mg_bases *bases, const uint64_t *d_scalars, size_t n, int scalar_flags, int window_bits,
                   mg_msm_job **job);
-int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine_mont); /* waits, folds, frees the job */
+/* Sharded bases: d_scalars_per_shard[g] points at the scalars of shard g's range, resident on shard g's device.
+ * One Pippenger pass per device, all in flight at once; the per-device partial points are the only data exchanged
+ * and mg_msm_finish adds them. (mg_msm, the host-to-host call, accepts sharded bases too and uploads the slices.) */
+int mg_msm_launch_sharded(const mg_bases *bases, const uint64_t *const *d_scalars_per_shard, int scalar_flags,
+                          int window_bits, mg_msm_job **job);
+int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine_mont); /* waits, folds, adds the shards' partial points, frees the job */
 /* sum of the registered points themselves (multi-GPU partial-point reduction, tests) */
 int mg_points_sum(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, uint64_t *out_affine_mont);
 /* [k_i] * base for n canonical scalars in HBM -> n affine points in HBM (fixed-base batch multiply:
@@ -165,11 +181,21 @@ int mg_groth16_setup(mg_curve_t curve, const mg_csr *a, const mg_csr *b, const m
 
 /* Uploads and re-lays the proving key once (lifetime = the Rust ProvingContext). */
 int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
+/* The proving key range-sharded over a list of devices (BASELINE configs[3]: "PrivateTransfer full proof, MSM
+ * sharded across 8 GPUs"): device g holds the g-th contiguous slice of every query with its window tables. A proof
+ * uploads the assignment to every device, each recomputes the witness map (cheaper than broadcasting h, SURVEY.md
+ * 8(e)) and runs its five partial MSMs; the 5 x G partial points are added on the host by the same code that folds
+ * the single-GPU results. Proof bytes are identical to the single-device context's. devices may repeat. */
+int mg_ctx_create_sharded(mg_curve_t curve, const mg_pk_view *pk, const int *devices, int n_devices, mg_ctx **out);
+int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, size_t len, const int *devices,
+                                     int n_devices, mg_ctx **out);
 /* Same, from the key's wire format: arkworks 0.3 `ProvingKey::serialize_unchecked` bytes (uncompressed points,
  * no curve checks) exactly as `ProvingContext::decode` reads them (manta-crypto/src/arkworks/groth16.rs:268-288)
  * and `generate_parameters` / manta-parameters ship them (data/pay/proving/ *.lfs). */
 int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out);
-/* Once per circuit shape: the matrices of `cs.to_matrices()` (identical for every proof of a shape). */
+/* Once per circuit shape: the matrices of `cs.to_matrices()` (identical for every proof of a shape). Validated
+ * in full before anything changes (row_ptr monotone from 0 to nnz, column indices < V); a rejected call leaves
+ * the context as it was. */
 int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t num_constraints);
 /* One proof. z = instance || witness (V x 4 u64 Montgomery), r, s = the two blinding scalars drawn by
  * the shim with the reference's own RNG in create_random_proof's order (Montgomery).
@@ -186,6 +212,9 @@ int mg_groth16_prove_batch(const mg_ctx *ctx, uint64_t k, const uint64_t *z_mont
 /* h = R1CStoQAP::witness_map(z): D x 4 u64 Montgomery coefficients (tests / parity) */
 int mg_witness_map(const mg_ctx *ctx, const uint64_t *z_mont, uint64_t *h_out_mont);
 uint64_t mg_ctx_domain_size(const mg_ctx *ctx);
+uint64_t mg_ctx_num_variables(const mg_ctx *ctx); /* V: the length every assignment must have */
+uint64_t mg_ctx_num_inputs(const mg_ctx *ctx);    /* P */
+int mg_ctx_num_shards(const mg_ctx *ctx);
 void mg_ctx_destroy(mg_ctx *ctx);
 
 #ifdef __cplusplus

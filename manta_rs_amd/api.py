@@ -42,6 +42,8 @@ def _load():
     lib.mg_last_error.restype = ctypes.c_char_p
     lib.mg_bases_device_bytes.restype = ctypes.c_size_t
     lib.mg_ctx_domain_size.restype = ctypes.c_uint64
+    lib.mg_ctx_num_variables.restype = ctypes.c_uint64
+    lib.mg_ctx_num_inputs.restype = ctypes.c_uint64
     lib.mg_last_accumulate_ms.restype = ctypes.c_float
     return lib
 
@@ -55,7 +57,9 @@ EXPORTS = [
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_host_alloc", "mg_host_free", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_ec_elementwise", "mg_point_serialize", "mg_ntt",
     "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
-    "mg_ctx_destroy",
+    "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
+    "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
+    "mg_ctx_num_shards",
 ]
 
 
@@ -170,10 +174,19 @@ class Bases:
     """A static vector of curve points resident in HBM (the `bases: &[G::Affine]` argument of
     `VariableBaseMSM::multi_scalar_mul`, made persistent because proving-key queries never change)."""
 
-    def __init__(self, curve, group, points, precompute_window_bits=0, on_device=False):
+    def __init__(self, curve, group, points, precompute_window_bits=0, on_device=False, devices=None):
+        """devices: a list of HIP device indices -> the vector is range-sharded over them (`mg_bases_create_sharded`;
+        a device may repeat); None -> one shard on the current device."""
         self.curve, self.group = curve, group
         h = _vp()
-        if on_device:
+        if devices is not None:
+            pts = _u64(points)
+            assert pts.ndim == 2 and pts.shape[1] == affine_limbs(curve, group), pts.shape
+            self.n = pts.shape[0]
+            dv = (ctypes.c_int * len(devices))(*devices)
+            _chk(LIB.mg_bases_create_sharded(curve, group, _p(pts), _sz(self.n), dv, len(devices),
+                                             int(precompute_window_bits), ctypes.byref(h)), "mg_bases_create_sharded")
+        elif on_device:
             ptr, n = points
             _chk(LIB.mg_bases_create(curve, group, ptr, _sz(n), 1, int(precompute_window_bits), ctypes.byref(h)),
                  "mg_bases_create")
@@ -188,6 +201,15 @@ class Bases:
 
     def device_bytes(self):
         return LIB.mg_bases_device_bytes(self.handle)
+
+    def shards(self):
+        """[(device, lo, hi)] of the range shards."""
+        out = []
+        for g in range(LIB.mg_bases_num_shards(self.handle)):
+            dev, lo, hi = ctypes.c_int(0), _sz(0), _sz(0)
+            _chk(LIB.mg_bases_shard(self.handle, g, ctypes.byref(dev), ctypes.byref(lo), ctypes.byref(hi)), "mg_bases_shard")
+            out.append((dev.value, lo.value, hi.value))
+        return out
 
     def close(self):
         if self.handle is not None:
@@ -233,6 +255,16 @@ class VariableBaseMSM:
         _chk(LIB.mg_msm_launch(bases.handle, ptr, _sz(n), int(bool(scalars_mont)) | (2 if sparse else 0), int(window_bits),
                                ctypes.byref(h)),
              "mg_msm_launch")
+        return MsmJob(bases, h)
+
+    @staticmethod
+    def launch_sharded(bases: Bases, d_scalars_per_shard, scalars_mont=False, window_bits=0, sparse=False) -> MsmJob:
+        """Sharded bases, scalars already resident: one DeviceBuffer / pointer per shard, on that shard's device."""
+        ptrs = [d.ptr if isinstance(d, DeviceBuffer) else d for d in d_scalars_per_shard]
+        arr = (_vp * len(ptrs))(*ptrs)
+        h = _vp()
+        _chk(LIB.mg_msm_launch_sharded(bases.handle, arr, int(bool(scalars_mont)) | (2 if sparse else 0), int(window_bits),
+                                       ctypes.byref(h)), "mg_msm_launch_sharded")
         return MsmJob(bases, h)
 
 
@@ -370,31 +402,63 @@ class ProvingContext:
     """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
     device-resident proving key; created once, shared by every proof of the shape."""
 
-    def __init__(self, curve, pk):
+    def __init__(self, curve, pk, devices=None):
         """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
-        b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P."""
+        b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P.
+        devices: list of HIP device indices -> every MSM of a proof is range-sharded over them
+        (`mg_ctx_create_sharded`); None -> the current device."""
         self.curve = curve
         self._keep = [_u64(getattr(pk, k)) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2",
                                                      "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
         v = _PkView(pk.V, pk.P, self._keep[8].shape[0], *[_p(a) for a in self._keep])
         h = _vp()
-        _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")
+        if devices is None:
+            _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")
+        else:
+            dv = (ctypes.c_int * len(devices))(*devices)
+            _chk(LIB.mg_ctx_create_sharded(curve, ctypes.byref(v), dv, len(devices), ctypes.byref(h)), "mg_ctx_create_sharded")
         self._keep = None  # the library copied everything
         self.handle = h
-        self._shape = None
+        self._r1cs_ref = None
 
     @classmethod
-    def decode(cls, curve, data: bytes):
+    def decode(cls, curve, data: bytes, devices=None):
         """Mirror of `impl Decode for ProvingContext` (groth16.rs:268-288): arkworks `deserialize_unchecked`
         bytes of the ProvingKey -- the format of manta-parameters' proving-key files."""
         self = cls.__new__(cls)
         self.curve = curve
         self._keep = None
-        self._shape = None
+        self._r1cs_ref = None
         h = _vp()
-        _chk(LIB.mg_ctx_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_ctx_create_from_bytes")
+        if devices is None:
+            _chk(LIB.mg_ctx_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_ctx_create_from_bytes")
+        else:
+            dv = (ctypes.c_int * len(devices))(*devices)
+            _chk(LIB.mg_ctx_create_from_bytes_sharded(curve, bytes(data), _sz(len(data)), dv, len(devices), ctypes.byref(h)),
+                 "mg_ctx_create_from_bytes_sharded")
         self.handle = h
         return self
+
+    @property
+    def num_variables(self):
+        """V: the number of Fr elements every assignment must have (from the C context, so the decode() path knows it too)."""
+        return int(LIB.mg_ctx_num_variables(self.handle))
+
+    @property
+    def num_inputs(self):
+        return int(LIB.mg_ctx_num_inputs(self.handle))
+
+    @property
+    def num_shards(self):
+        return int(LIB.mg_ctx_num_shards(self.handle))
+
+    def _check_assignment(self, z, k=1):
+        """The C side copies k*V*32 bytes from the buffer: a short array must never reach it."""
+        z = np.ascontiguousarray(z, dtype=np.uint64)
+        want = k * self.num_variables * 4
+        if z.size != want:
+            raise ValueError(f"assignment holds {z.size} u64 words, the context's circuit needs {want} ({k} x V = {self.num_variables} x 4)")
+        return z
 
     def set_r1cs(self, r1cs: R1CS):
         ms = []
@@ -405,7 +469,8 @@ class ProvingContext:
             ms.append((rp, col, val, _Csr(_p(rp), _p(col), _p(val), len(col))))
         _chk(LIB.mg_ctx_set_r1cs(self.handle, ctypes.byref(ms[0][3]), ctypes.byref(ms[1][3]), ctypes.byref(ms[2][3]),
                                  ctypes.c_uint64(r1cs.num_constraints)), "mg_ctx_set_r1cs")
-        self._shape = (r1cs.num_constraints, r1cs.num_instance)
+        import weakref
+        self._r1cs_ref = weakref.ref(r1cs)  # the uploaded matrices belong to exactly this R1CS object
 
     @property
     def domain_size(self):
@@ -413,7 +478,8 @@ class ProvingContext:
 
     def witness_map(self, z):
         h = np.zeros((self.domain_size, 4), dtype=np.uint64)
-        _chk(LIB.mg_witness_map(self.handle, _p(_u64(z)), _p(h)), "mg_witness_map")
+        z = self._check_assignment(z)
+        _chk(LIB.mg_witness_map(self.handle, _p(z), _p(h)), "mg_witness_map")
         return h
 
     def close(self):
@@ -439,7 +505,9 @@ class Groth16:
         """`rng` supplies the two blinding scalars exactly where ark-groth16's create_random_proof draws
         them: r = Fr::rand(rng); s = Fr::rand(rng) -- `rng()` must return one Montgomery Fr element
         (4 x u64) per call. Returns the arkworks canonical compressed proof bytes."""
-        if context._shape != (compiler.num_constraints, compiler.num_instance):
+        # the matrices on the device are those of the R1CS object last uploaded: another object -- even one with the
+        # same (m, P) -- is another circuit and is uploaded afresh
+        if context._r1cs_ref is None or context._r1cs_ref() is not compiler:
             context.set_r1cs(compiler)
         r = _u64(rng())
         s = _u64(rng())
@@ -448,7 +516,11 @@ class Groth16:
     @staticmethod
     def prove_with_randomness(context: ProvingContext, z, r, s) -> bytes:
         out = ctypes.create_string_buffer(PROOF_BYTES[context.curve])
-        _chk(LIB.mg_groth16_prove(context.handle, _p(_u64(z)), _p(_u64(r)), _p(_u64(s)), out), "mg_groth16_prove")
+        z = context._check_assignment(z)
+        r, s = _u64(r).reshape(-1), _u64(s).reshape(-1)
+        if r.size != 4 or s.size != 4:
+            raise ValueError("r and s are one Fr element (4 x u64) each")
+        _chk(LIB.mg_groth16_prove(context.handle, _p(z), _p(r), _p(s), out), "mg_groth16_prove")
         return out.raw
 
     @staticmethod
@@ -460,8 +532,9 @@ class Groth16:
         rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(-1, 4)
         ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
         k = rs.shape[0]
-        if ss.shape[0] != k or zs.size % k or zs.size == 0:
+        if ss.shape[0] != k or k == 0:
             raise ValueError("prove_batch: zs, rs, ss must describe the same number of proofs")
+        zs = context._check_assignment(zs, k)
         n = PROOF_BYTES[context.curve]
         out = ctypes.create_string_buffer(n * k)
         _chk(LIB.mg_groth16_prove_batch(context.handle, ctypes.c_uint64(k), _p(zs), _p(rs), _p(ss), out),

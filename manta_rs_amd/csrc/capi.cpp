@@ -8,13 +8,32 @@
 
 using namespace mg;
 
-struct mg_bases {
+// A registered base vector: one shard per device of the list it was created over (a plain mg_bases_create gives one
+// shard on the current device). Shard g owns the contiguous range [lo, hi) of the points.
+struct BasesShard {
     GroupEngine *eng;
     BaseSet *bs;
+    int device;
+    size_t lo, hi;
 };
-struct mg_msm_job {
+struct mg_bases {
+    std::vector<BasesShard> sh;
+    size_t n = 0;
+};
+struct JobShard {
     GroupEngine *eng;
     MsmWorkspace *ws;
+    int device;
+    void *d_tmp; // scalars uploaded by the host-to-host convenience call (freed at finish)
+};
+struct mg_msm_job {
+    std::vector<JobShard> sh;
+};
+// restores the caller's current device when a call that visits other devices returns
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { hipGetDevice(&prev); }
+    ~DeviceGuard() { hipSetDevice(prev); }
 };
 
 #define MG_API extern "C" __attribute__((visibility("default")))
@@ -23,7 +42,6 @@ struct mg_msm_job {
     }                                                                                                             \
     catch (const std::bad_alloc &) { return MG_ERROR_OUT_OF_MEMORY; }                                             \
     catch (...) { return MG_ERROR_STATE; }
-
 MG_API int mg_init(int device) {
     MG_TRY
     MG_HIP(hipSetDevice(device));
@@ -86,75 +104,189 @@ MG_API int mg_set_kernel_timing(int on) {
 MG_API float mg_last_accumulate_ms(void) { return last_accumulate_ms(); }
 
 // ---------------------------------------------------------------------------------------------- MSM
+static void bases_free(mg_bases *b) {
+    DeviceGuard guard;
+    for (BasesShard &s : b->sh) {
+        hipSetDevice(s.device);
+        if (s.bs) s.eng->bases_destroy(s.bs);
+    }
+    delete b;
+}
+static int bases_create_on(mg_curve_t curve, int group, const uint64_t *affine, size_t n, int on_device, int pre_c,
+                           const int *devices, int n_devices, mg_bases **out) {
+    if (!out || !affine || n == 0 || pre_c < 0 || pre_c > 24 || n_devices < 1 || n_devices > 64 || (size_t)n_devices > n)
+        return MG_ERROR_INVALID_ARGUMENT;
+    if (on_device && n_devices != 1) return MG_ERROR_INVALID_ARGUMENT; // a device pointer belongs to one device
+    int count = 0;
+    MG_HIP(hipGetDeviceCount(&count));
+    DeviceGuard guard;
+    mg_bases *b = new mg_bases();
+    b->n = n;
+    for (int g = 0; g < n_devices; ++g) {
+        const int dev = devices ? devices[g] : guard.prev;
+        if (dev < 0 || dev >= count || dev >= MAX_DEVICES) {
+            bases_free(b);
+            return MG_ERROR_INVALID_ARGUMENT;
+        }
+        hipError_t he = hipSetDevice(dev);
+        GroupEngine *e = he == hipSuccess ? get_engine((int)curve, group) : nullptr;
+        if (!e) {
+            bases_free(b);
+            return he == hipSuccess ? MG_ERROR_INVALID_ARGUMENT : MG_ERROR_HIP;
+        }
+        const size_t lo = n * (size_t)g / n_devices, hi = n * (size_t)(g + 1) / n_devices;
+        BaseSet *bs = nullptr;
+        int rc = e->bases_create((const u32 *)affine + lo * (size_t)e->affine_words(), hi - lo, on_device != 0, pre_c, &bs);
+        if (rc) {
+            bases_free(b);
+            return rc;
+        }
+        b->sh.push_back(BasesShard{e, bs, dev, lo, hi});
+    }
+    *out = b;
+    return MG_SUCCESS;
+}
 MG_API int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine, size_t n, int on_device,
                            int precompute_window_bits, mg_bases **out) {
     MG_TRY
-    if (!out || !affine || n == 0 || precompute_window_bits < 0 || precompute_window_bits > 24)
-        return MG_ERROR_INVALID_ARGUMENT;
-    GroupEngine *e = get_engine((int)curve, group);
-    if (!e) return MG_ERROR_INVALID_ARGUMENT;
-    BaseSet *bs = nullptr;
-    int rc = e->bases_create((const u32 *)affine, n, on_device != 0, precompute_window_bits, &bs);
-    if (rc) return rc;
-    *out = new mg_bases{e, bs};
-    return MG_SUCCESS;
+    return bases_create_on(curve, group, affine, n, on_device, precompute_window_bits, nullptr, 1, out);
+    MG_CATCH
+}
+MG_API int mg_bases_create_sharded(mg_curve_t curve, int group, const uint64_t *affine, size_t n, const int *devices,
+                                   int n_devices, int precompute_window_bits, mg_bases **out) {
+    MG_TRY
+    if (!devices) return MG_ERROR_INVALID_ARGUMENT;
+    return bases_create_on(curve, group, affine, n, 0, precompute_window_bits, devices, n_devices, out);
     MG_CATCH
 }
 MG_API void mg_bases_destroy(mg_bases *b) {
-    if (!b) return;
-    b->eng->bases_destroy(b->bs);
-    delete b;
+    if (b) bases_free(b);
 }
-MG_API size_t mg_bases_device_bytes(const mg_bases *b) { return b ? b->bs->bytes : 0; }
+MG_API size_t mg_bases_device_bytes(const mg_bases *b) {
+    size_t t = 0;
+    if (b)
+        for (const BasesShard &s : b->sh) t += s.bs->bytes;
+    return t;
+}
+MG_API int mg_bases_num_shards(const mg_bases *b) { return b ? (int)b->sh.size() : 0; }
+MG_API int mg_bases_shard(const mg_bases *b, int shard, int *device, size_t *lo, size_t *hi) {
+    if (!b || shard < 0 || (size_t)shard >= b->sh.size()) return MG_ERROR_INVALID_ARGUMENT;
+    if (device) *device = b->sh[(size_t)shard].device;
+    if (lo) *lo = b->sh[(size_t)shard].lo;
+    if (hi) *hi = b->sh[(size_t)shard].hi;
+    return MG_SUCCESS;
+}
 
+static void job_abandon(mg_msm_job *job) {
+    DeviceGuard guard;
+    for (JobShard &j : job->sh) {
+        hipSetDevice(j.device);
+        hipStreamSynchronize(j.ws->stream);
+        j.ws->pending = 0;
+        j.eng->ws_release(j.ws);
+        if (j.d_tmp) hipFree(j.d_tmp);
+    }
+    delete job;
+}
+// one launch per shard; d_scalars[g] = the scalars of shard g's range, resident on shard g's device (n_g of them,
+// n_g <= hi - lo); host_scalars != nullptr instead uploads the slices first
+static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, const uint64_t *host_scalars, size_t n_total,
+                         int scalar_flags, int window_bits, mg_msm_job **out) {
+    DeviceGuard guard;
+    mg_msm_job *job = new mg_msm_job();
+    for (size_t g = 0; g < b->sh.size(); ++g) {
+        const BasesShard &s = b->sh[g];
+        if (n_total <= s.lo) break; // multi_scalar_mul zips to the shorter side: later shards have no scalars
+        const size_t n = (n_total < s.hi ? n_total : s.hi) - s.lo;
+        void *d_tmp = nullptr;
+        const u32 *d_sc = d_scalars ? (const u32 *)d_scalars[g] : nullptr;
+        int rc = MG_SUCCESS;
+        hipError_t he = hipSetDevice(s.device);
+        if (he == hipSuccess && host_scalars) {
+            he = hipMalloc(&d_tmp, n * 32);
+            if (he == hipSuccess) he = hipMemcpy(d_tmp, host_scalars + s.lo * 4, n * 32, hipMemcpyHostToDevice);
+            d_sc = (const u32 *)d_tmp;
+        }
+        if (he != hipSuccess) {
+            set_last_hip_error(he, "sharded MSM launch", __FILE__, __LINE__);
+            rc = he == hipErrorOutOfMemory ? MG_ERROR_OUT_OF_MEMORY : MG_ERROR_HIP;
+        } else if (!d_sc) {
+            rc = MG_ERROR_INVALID_ARGUMENT;
+        }
+        MsmWorkspace *ws = rc ? nullptr : s.eng->ws_acquire();
+        if (!rc && !ws) rc = MG_ERROR_HIP;
+        if (ws) {
+            job->sh.push_back(JobShard{s.eng, ws, s.device, d_tmp});
+            rc = s.eng->msm_launch(s.bs, d_sc, n, (scalar_flags & MG_SCALARS_MONT) != 0, window_bits, ws, 1, 0,
+                                   (scalar_flags & MG_SCALARS_SPARSE) != 0);
+        } else if (d_tmp) {
+            hipFree(d_tmp);
+        }
+        if (rc) {
+            job_abandon(job);
+            return rc;
+        }
+    }
+    *out = job;
+    return MG_SUCCESS;
+}
 MG_API int mg_msm_launch(const mg_bases *b, const uint64_t *d_scalars, size_t n, int scalar_flags, int window_bits,
                          mg_msm_job **job) {
     MG_TRY
-    if (!b || !d_scalars || !job || n == 0) return MG_ERROR_INVALID_ARGUMENT;
-    MsmWorkspace *ws = b->eng->ws_acquire();
-    if (!ws) return MG_ERROR_HIP;
-    int rc = b->eng->msm_launch(b->bs, (const u32 *)d_scalars, n, (scalar_flags & MG_SCALARS_MONT) != 0, window_bits, ws, 1, 0,
-                                (scalar_flags & MG_SCALARS_SPARSE) != 0);
-    if (rc) {
-        hipStreamSynchronize(ws->stream);
-        b->eng->ws_release(ws);
-        return rc;
-    }
-    *job = new mg_msm_job{b->eng, ws};
-    return MG_SUCCESS;
+    if (!b || !d_scalars || !job || n == 0 || b->sh.size() != 1) return MG_ERROR_INVALID_ARGUMENT;
+    if (n > b->n) return MG_ERROR_INVALID_ARGUMENT;
+    const uint64_t *one[1] = {d_scalars};
+    return launch_shards(b, one, nullptr, n, scalar_flags, window_bits, job);
     MG_CATCH
 }
+MG_API int mg_msm_launch_sharded(const mg_bases *b, const uint64_t *const *d_scalars_per_shard, int scalar_flags,
+                                 int window_bits, mg_msm_job **job) {
+    MG_TRY
+    if (!b || !d_scalars_per_shard || !job) return MG_ERROR_INVALID_ARGUMENT;
+    for (size_t g = 0; g < b->sh.size(); ++g)
+        if (!d_scalars_per_shard[g]) return MG_ERROR_INVALID_ARGUMENT;
+    return launch_shards(b, d_scalars_per_shard, nullptr, b->n, scalar_flags, window_bits, job);
+    MG_CATCH
+}
+// waits for every shard, folds its staged points, and adds the partial results: the exchange step of the
+// sharded MSM (the per-device partial points arrive through pinned host staging and are summed here)
 MG_API int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine) {
     MG_TRY
     if (!job) return MG_ERROR_INVALID_ARGUMENT;
-    HostPoint hp;
-    int rc = job->eng->msm_finish(job->ws, &hp);
-    if (!rc && out_affine) job->eng->hp_to_affine(&hp, (u32 *)out_affine);
-    job->eng->ws_release(job->ws);
+    DeviceGuard guard;
+    int rc = MG_SUCCESS;
+    HostPoint total, hp;
+    GroupEngine *e0 = job->sh.empty() ? nullptr : job->sh[0].eng;
+    if (e0) e0->hp_set_inf(&total);
+    for (JobShard &j : job->sh) {
+        hipSetDevice(j.device);
+        int rc2 = j.eng->msm_finish(j.ws, &hp);
+        if (rc2) {
+            hipStreamSynchronize(j.ws->stream);
+            j.ws->pending = 0;
+        } else {
+            e0->hp_add(&total, &hp);
+        }
+        if (!rc) rc = rc2;
+        j.eng->ws_release(j.ws);
+        if (j.d_tmp) hipFree(j.d_tmp);
+    }
+    if (!rc && out_affine && e0) e0->hp_to_affine(&total, (u32 *)out_affine);
     delete job;
     return rc;
     MG_CATCH
 }
 MG_API int mg_msm(const mg_bases *b, const uint64_t *scalars, size_t n, uint64_t *out_affine) {
     MG_TRY
-    if (!b || !scalars || !out_affine) return MG_ERROR_INVALID_ARGUMENT;
-    if (n > b->bs->n) n = b->bs->n; // multi_scalar_mul zips to the shorter of the two
+    if (!b || !scalars || !out_affine || b->sh.empty()) return MG_ERROR_INVALID_ARGUMENT;
+    if (n > b->n) n = b->n; // multi_scalar_mul zips to the shorter of the two
     if (n == 0) {
-        std::memset(out_affine, 0, (size_t)b->eng->affine_words() * 4);
+        std::memset(out_affine, 0, (size_t)b->sh[0].eng->affine_words() * 4);
         return MG_SUCCESS;
     }
-    void *d = nullptr;
-    MG_HIP(hipMalloc(&d, n * 32));
-    hipError_t e = hipMemcpy(d, scalars, n * 32, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        hipFree(d);
-        set_last_hip_error(e, "hipMemcpy(scalars)", __FILE__, __LINE__);
-        return MG_ERROR_HIP;
-    }
     mg_msm_job *job = nullptr;
-    int rc = mg_msm_launch(b, (const uint64_t *)d, n, 0, 0, &job);
+    int rc = launch_shards(b, nullptr, scalars, n, 0, 0, &job);
     if (!rc) rc = mg_msm_finish(job, out_affine);
-    hipFree(d);
     return rc;
     MG_CATCH
 }
@@ -241,6 +373,27 @@ MG_API int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out) {
     return MG_SUCCESS;
     MG_CATCH
 }
+MG_API int mg_ctx_create_sharded(mg_curve_t curve, const mg_pk_view *pk, const int *devices, int n_devices, mg_ctx **out) {
+    MG_TRY
+    if (!pk || !out || !devices) return MG_ERROR_INVALID_ARGUMENT;
+    Prover *p = nullptr;
+    int rc = prover_create_sharded((int)curve, pk, devices, n_devices, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, size_t len, const int *devices,
+                                            int n_devices, mg_ctx **out) {
+    MG_TRY
+    if (!bytes || !out || !devices || n_devices < 1) return MG_ERROR_INVALID_ARGUMENT;
+    Prover *p = nullptr;
+    int rc = prover_create_from_bytes((int)curve, bytes, len, &p, devices, n_devices);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
 MG_API int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out) {
     MG_TRY
     if (!bytes || !out) return MG_ERROR_INVALID_ARGUMENT;
@@ -285,6 +438,9 @@ MG_API int mg_witness_map(const mg_ctx *ctx, const uint64_t *z, uint64_t *h_out)
     MG_CATCH
 }
 MG_API uint64_t mg_ctx_domain_size(const mg_ctx *ctx) { return ctx ? ctx->p->domain_size() : 0; }
+MG_API uint64_t mg_ctx_num_variables(const mg_ctx *ctx) { return ctx ? ctx->p->n_vars() : 0; }
+MG_API uint64_t mg_ctx_num_inputs(const mg_ctx *ctx) { return ctx ? ctx->p->n_inputs() : 0; }
+MG_API int mg_ctx_num_shards(const mg_ctx *ctx) { return ctx ? (int)ctx->p->n_shards() : 0; }
 MG_API void mg_ctx_destroy(mg_ctx *ctx) {
     if (!ctx) return;
     delete ctx->p;

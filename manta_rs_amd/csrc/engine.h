@@ -31,6 +31,8 @@ bool kernel_timing();
 void set_last_accumulate_ms(float ms);
 float last_accumulate_ms();
 // process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)
+constexpr int MAX_DEVICES = 16;
+int current_device(); // hipGetDevice, clamped to the engine tables
 hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 const char *last_error_string();
@@ -57,6 +59,7 @@ struct MsmPlan {
 // A static set of bases resident in HBM (a proving-key query, or a caller-registered vector).
 struct BaseSet {
     int curve = 0, group = 1;
+    int device = 0;       // the HIP device the points live on
     size_t n = 0;         // points stored (after dropping infinity entries when compacted)
     size_t n_orig = 0;    // logical length: scalars are indexed 0 .. n_orig-1
     u32 *d_map = nullptr; // compacted sets: stored point i belongs to scalar d_map[i]; nullptr = identity
@@ -82,6 +85,7 @@ struct MsmWorkspace {
     MsmPlan plan;
     u32 T1 = 0, nP = 0, batch = 1;
     int pending = 0;
+    int device = 0;
     ~MsmWorkspace();
 };
 
@@ -150,6 +154,8 @@ class GroupEngine {
 
     MsmWorkspace *ws_acquire();
     void ws_release(MsmWorkspace *);
+
+    static constexpr size_t MAX_IDLE_WS = 24;
 
   protected:
     std::mutex ws_mu_;

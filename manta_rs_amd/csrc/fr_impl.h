@@ -455,7 +455,10 @@ template <class FrC> class FrEngineT : public FrEngine {
         std::vector<HF> *acc[3] = {&av, &bv, &cv};
         for (int t = 0; t < 3; ++t) {
             const mg_csr *M = Ms[t];
-            if (!M || !M->row_ptr || (M->nnz && (!M->col || !M->val)) || M->row_ptr[m] != M->nnz) return MG_ERR_ARG;
+            if (!M || !M->row_ptr || (M->nnz && (!M->col || !M->val)) || M->row_ptr[0] != 0 || M->row_ptr[m] != M->nnz)
+                return MG_ERR_ARG;
+            for (u64 i = 0; i < m; ++i) // the loop below walks row_ptr[i] .. row_ptr[i+1] on the host: monotone or rejected
+                if (M->row_ptr[i] > M->row_ptr[i + 1]) return MG_ERR_ARG;
             for (u64 i = 0; i < m; ++i)
                 for (u64 k = M->row_ptr[i]; k < M->row_ptr[i + 1]; ++k) {
                     if (M->col[k] >= V) return MG_ERR_ARG;

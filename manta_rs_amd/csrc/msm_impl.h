@@ -819,6 +819,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         BaseSet *bs = new BaseSet();
         bs->curve = CURVE_ID;
         bs->group = GROUP;
+        bs->device = current_device();
         bs->n = n;
         bs->n_orig = n_in;
         if (!map.empty()) {

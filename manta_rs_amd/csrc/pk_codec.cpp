@@ -82,7 +82,7 @@ template <class C> bool read_vec(Reader &r, int deg, std::vector<uint64_t> &out,
     return true;
 }
 
-template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, Prover **out) {
+template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices, int n_devices) {
     typedef typename Curve::Fq C;
     typedef host::HFp<C> HF;
     Reader r{bytes, len};
@@ -110,15 +110,15 @@ template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, P
     v.b_g2_query = b2.data();
     v.h_query = h.data();
     v.l_query = l.data();
-    return prover_create(curve, &v, out);
+    return devices && n_devices > 0 ? prover_create_sharded(curve, &v, devices, n_devices, out) : prover_create(curve, &v, out);
 }
 
 } // namespace
 
-int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out) {
+int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices, int n_devices) {
     if (!bytes || !out) return MG_ERR_ARG;
-    if (curve == 0) return decode<Bn254>(curve, bytes, len, out);
-    if (curve == 1) return decode<Bls381>(curve, bytes, len, out);
+    if (curve == 0) return decode<Bn254>(curve, bytes, len, out, devices, n_devices);
+    if (curve == 1) return decode<Bls381>(curve, bytes, len, out, devices, n_devices);
     return MG_ERR_ARG;
 }
 

@@ -17,17 +17,19 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 namespace mg {
 
-FrEngine *get_ntt_engine(int curve) {
+FrEngine *get_ntt_engine(int curve) { // one per (device, curve): twiddle and scale tables are device memory
     static std::mutex mu;
-    static FrEngine *tab[2] = {nullptr, nullptr};
+    static FrEngine *tab[MAX_DEVICES][2] = {};
     if (curve < 0 || curve > 1) return nullptr;
+    const int dev = current_device();
     std::lock_guard<std::mutex> g(mu);
-    if (!tab[curve]) tab[curve] = curve == 0 ? make_fr_engine_bn254() : make_fr_engine_bls381();
-    return tab[curve];
+    if (!tab[dev][curve]) tab[dev][curve] = curve == 0 ? make_fr_engine_bn254() : make_fr_engine_bls381();
+    return tab[dev][curve];
 }
 
 namespace {
@@ -56,6 +58,8 @@ struct ProveWs {
     hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
     bool graphs_ready = false;
     u32 k = 1; // proofs per pass (the slot's buffers and its captured graph are sized for exactly this batch)
+    int device = 0;
+    u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
     int eager_runs = 0;
     bool no_graph = false;
     void drop_graphs() {
@@ -71,6 +75,9 @@ struct ProveWs {
         graphs_ready = false;
     }
     ~ProveWs() {
+        int prev = 0;
+        hipGetDevice(&prev);
+        hipSetDevice(device);
         drop_graphs();
         for (int i = 0; i < 5; ++i)
             if (mw[i]) {
@@ -86,6 +93,7 @@ struct ProveWs {
         stream_pool_put(stream); // never destroyed: see stream_pool_get()
         stream_pool_put(side[0]);
         stream_pool_put(side[1]);
+        hipSetDevice(prev);
     }
 };
 
@@ -117,6 +125,9 @@ static bool graphs_enabled() { return graph_mode() != GRAPH_OFF; }
 class ProverImpl : public Prover {
   public:
     int curve_ = 0;
+    int dev_ = 0;                      // the HIP device this (shard of the) context lives on
+    u32 shard_ = 0, n_shards_ = 1;     // range shard g of G: every MSM of a proof covers the g-th contiguous slice of its query
+    std::vector<ProverImpl *> peers_;  // shard 0 only: shards 1 .. G-1 (owned); a pass runs on all of them, shard 0 assembles
     FrEngine *fr_ = nullptr;
     GroupEngine *g1_ = nullptr, *g2_ = nullptr;
     u64 V_ = 0, P_ = 0, h_len_ = 0, m_ = 0;
@@ -133,9 +144,18 @@ class ProverImpl : public Prover {
     DevCsr A_, B_, C_;
     std::vector<u32> h_query_host_; // kept until the domain size is known (set_r1cs), then re-laid
     std::mutex mu_;
+    // proofs hold it shared for the length of a pass, set_r1cs exclusively: replacing the circuit waits for the passes in
+    // flight and no pass ever sees a half-replaced one (mantagpu.h: prove is re-entrant on one context)
+    mutable std::shared_mutex shape_mu_;
+    u64 gen_ = 0; // bumped by every set_r1cs; a slot remembers the generation it was sized and captured for
     std::map<u32, std::vector<ProveWs *>> ws_free_; // idle proof slots, by batch size
+    size_t idle_slots_ = 0;
+    u64 lru_tick_ = 0;
+    static constexpr size_t MAX_IDLE_SLOTS = 6; // per context: beyond it the least recently used idle slot is destroyed
 
     ~ProverImpl() override {
+        for (ProverImpl *q : peers_) delete q;
+        hipSetDevice(dev_);
         // (h_bs_ is created by set_r1cs)
         if (a_bs_) g1_->bases_destroy(a_bs_);
         if (b1_bs_) g1_->bases_destroy(b1_bs_);
@@ -176,8 +196,16 @@ class ProverImpl : public Prover {
         return 16;
     }
 
-    int init(int curve, const mg_pk_view *pk) {
+    // contiguous slice of an n-entry query owned by this shard
+    size_t shard_lo(size_t n) const { return n * shard_ / n_shards_; }
+    size_t shard_hi(size_t n) const { return n * (shard_ + 1) / n_shards_; }
+
+    int init(int curve, const mg_pk_view *pk, int device, u32 shard = 0, u32 n_shards = 1) {
         curve_ = curve;
+        dev_ = device;
+        shard_ = shard;
+        n_shards_ = n_shards;
+        MG_HIP(hipSetDevice(dev_));
         fr_ = get_ntt_engine(curve);
         g1_ = get_engine(curve, 1);
         g2_ = get_engine(curve, 2);
@@ -207,22 +235,27 @@ class ProverImpl : public Prover {
         delta1_tab_ = g1_->hp_table_create(&delta_g1_);
         delta2_tab_ = g2_->hp_table_create(&delta_g2_);
         int rc;
+        if (n_shards_ > 1 && (V_ - P_ < n_shards_ || V_ - 1 < n_shards_)) return MG_ERR_ARG; // every shard owns >= 1 entry
+        // this shard's slices of the z queries (entries 1 .. V-1 of a / b_g1 / b_g2) and of the l query
+        const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
+        const u32 *aq = (const u32 *)pk->a_query + (1 + zlo) * w1, *b1q = (const u32 *)pk->b_g1_query + (1 + zlo) * w1;
+        const u32 *b2q = (const u32 *)pk->b_g2_query + (1 + zlo) * w2, *lq = (const u32 *)pk->l_query + llo * w1;
         const int c_z = pre_c_for(V_ - 1);
-        if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, c_z, &a_bs_, true))) return rc;
-        if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, c_z, &b1_bs_, true))) return rc;
+        if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
+        if ((rc = g1_->bases_create(b1q, zn, false, c_z, &b1_bs_, true))) return rc;
         // The G2 MSM is the latency-critical chain of a single proof: 6-bit windows (32 buckets: one tile, no second
         // reduce level) shorten it by four dependent additions (measured +4 % proofs/s); the extra windows only
         // add parallel mixed additions.
         const bool small = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
         const int c_g2 = small ? 6 : c_z;
-        if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, c_g2, &b2_bs_, true))) return rc;
-        if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
+        if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
+        if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
         if (small) { // batched passes are throughput-bound: 10-bit windows = 20 % fewer mixed additions (+7 % measured)
             const int cw = 10;
-            if ((rc = g1_->bases_create((const u32 *)pk->a_query + w1, V_ - 1, false, cw, &a_bs_wide_, true))) return rc;
-            if ((rc = g1_->bases_create((const u32 *)pk->b_g1_query + w1, V_ - 1, false, cw, &b1_bs_wide_, true))) return rc;
-            if ((rc = g2_->bases_create((const u32 *)pk->b_g2_query + w2, V_ - 1, false, cw, &b2_bs_wide_, true))) return rc;
-            if ((rc = g1_->bases_create((const u32 *)pk->l_query, V_ - P_, false, cw, &l_bs_wide_, true))) return rc;
+            if ((rc = g1_->bases_create(aq, zn, false, cw, &a_bs_wide_, true))) return rc;
+            if ((rc = g1_->bases_create(b1q, zn, false, cw, &b1_bs_wide_, true))) return rc;
+            if ((rc = g2_->bases_create(b2q, zn, false, cw, &b2_bs_wide_, true))) return rc;
+            if ((rc = g1_->bases_create(lq, ln, false, cw, &l_bs_wide_, true))) return rc;
         }
         // h_query is stored in the bit-reversed order the witness map leaves h in; that order depends on
         // the domain size, known once the R1CS arrives (set_r1cs)
@@ -230,12 +263,19 @@ class ProverImpl : public Prover {
         return MG_OK;
     }
 
-    static int upload_csr(const mg_csr *src, u64 m, u64 n_vars, DevCsr &dst) {
-        if (!src->row_ptr || (src->nnz && (!src->col || !src->val))) return MG_ERR_ARG;
-        if (src->row_ptr[m] != src->nnz) return MG_ERR_ARG;
+    // Structural checks of one matrix as it arrives over the ABI (O(m + nnz) on the host): the device kernels loop
+    // k = row_ptr[i] .. row_ptr[i+1] and gather z[col[k]] without further checks, so nothing malformed may pass here.
+    static int validate_csr(const mg_csr *src, u64 m, u64 n_vars) {
+        if (!src || !src->row_ptr || (src->nnz && (!src->col || !src->val))) return MG_ERR_ARG;
+        if (src->nnz >= ((u64)1 << 32)) return MG_ERR_ARG;
+        if (src->row_ptr[0] != 0 || src->row_ptr[m] != src->nnz) return MG_ERR_ARG;
+        for (u64 i = 0; i < m; ++i)
+            if (src->row_ptr[i] > src->row_ptr[i + 1]) return MG_ERR_ARG; // monotone => every entry <= row_ptr[m] = nnz
         for (u64 k = 0; k < src->nnz; ++k)
             if (src->col[k] >= n_vars) return MG_ERR_ARG;
-        free_csr(dst);
+        return MG_OK;
+    }
+    static int upload_csr(const mg_csr *src, u64 m, DevCsr &dst) { // dst is empty on entry; freed by the caller on failure
         dst.nnz = src->nnz;
         MG_HIP(hipMalloc((void **)&dst.row_ptr, (m + 1) * 4));
         MG_HIP(hipMalloc((void **)&dst.col, (src->nnz ? src->nnz : 1) * 4));
@@ -248,26 +288,49 @@ class ProverImpl : public Prover {
         return MG_OK;
     }
 
+    // Replaces the circuit. All-or-nothing: the three matrices are validated, then uploaded into temporaries, the
+    // h-query tables for a new domain size are built, and only when everything has succeeded is the context
+    // switched over (a failure leaves the previous circuit, if any, fully usable). Exclusive against proofs in
+    // flight on other threads (shape_mu_): it waits for them, and they never see a half-replaced circuit.
     int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) override {
-        std::lock_guard<std::mutex> g(mu_);
+        int rc = MG_OK, prev = 0;
+        MG_HIP(hipGetDevice(&prev));
+        for (ProverImpl *q : peers_)
+            if ((rc = q->set_r1cs_shard(a, b, c, m))) break;
+        if (!rc) rc = set_r1cs_shard(a, b, c, m);
+        hipSetDevice(prev);
+        return rc;
+    }
+    u64 n_vars() const override { return V_; }
+    u64 n_inputs() const override { return P_; }
+    u32 n_shards() const override { return n_shards_; }
+    int set_r1cs_shard(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) {
+        MG_HIP(hipSetDevice(dev_));
         if (m == 0 || m + P_ > ((u64)1 << 32)) return MG_ERR_ARG;
         unsigned lg = 0;
         while (((u64)1 << lg) < m + P_) ++lg; // GeneralEvaluationDomain::new(m + P) -> next power of two
         if ((int)lg > fr_->two_adicity()) return MG_ERR_DOMAIN;
         int rc;
-        if ((rc = upload_csr(a, m, V_, A_)) || (rc = upload_csr(b, m, V_, B_)) || (rc = upload_csr(c, m, V_, C_)))
+        if ((rc = validate_csr(a, m, V_)) || (rc = validate_csr(b, m, V_)) || (rc = validate_csr(c, m, V_))) return rc;
+        std::unique_lock<std::shared_mutex> shape_lock(shape_mu_);
+        DevCsr nA, nB, nC;
+        if ((rc = upload_csr(a, m, nA)) || (rc = upload_csr(b, m, nB)) || (rc = upload_csr(c, m, nC))) {
+            free_csr(nA), free_csr(nB), free_csr(nC);
             return rc;
-        if (!h_bs_ || lg != log_d_) { // (re)build the h-query base set for this domain
+        }
+        BaseSet *nh = nullptr, *nh_wide = nullptr;
+        const bool new_domain = !h_bs_ || lg != log_d_;
+        if (new_domain) { // (re)build the h-query base set for this domain
             const size_t D = (size_t)1 << lg, w1 = (size_t)g1_->affine_words();
-            std::vector<u32> perm(D * w1, 0u); // entries beyond len(h_query) stay infinity: h[D-1] = 0 anyway
-            for (size_t p = 0; p < D; ++p) {
+            // this shard's slice [h_lo, h_hi) of the bit-reversed positions; entries beyond len(h_query) stay
+            // infinity: h[D-1] = 0 anyway
+            const size_t lo = shard_lo(D), hi = shard_hi(D);
+            std::vector<u32> perm((hi - lo) * w1, 0u);
+            for (size_t p = lo; p < hi; ++p) {
                 size_t src = 0;
-                for (unsigned b = 0; b < lg; ++b) src |= ((p >> b) & 1) << (lg - 1 - b);
-                if (src < h_len_) std::memcpy(&perm[p * w1], &h_query_host_[src * w1], w1 * 4);
+                for (unsigned bb = 0; bb < lg; ++bb) src |= ((p >> bb) & 1) << (lg - 1 - bb);
+                if (src < h_len_) std::memcpy(&perm[(p - lo) * w1], &h_query_host_[src * w1], w1 * 4);
             }
-            if (h_bs_) g1_->bases_destroy(h_bs_);
-            if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
-            h_bs_ = h_bs_wide_ = nullptr;
             // The h MSM is the one with dense, uniform scalars -- half of all the mixed additions of a proof at
             // c = 8. Wider windows halve them, but lengthen its bucket reduce: measured on PrivateTransfer,
             // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32); for single proofs the
@@ -277,13 +340,31 @@ class ProverImpl : public Prover {
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
             if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
-            if ((rc = g1_->bases_create(perm.data(), D, false, ch, &h_bs_))) return rc;
-            if (ch_wide != ch && (rc = g1_->bases_create(perm.data(), D, false, ch_wide, &h_bs_wide_))) return rc;
+            rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &nh);
+            if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &nh_wide);
+            if (rc) {
+                if (nh) g1_->bases_destroy(nh);
+                if (nh_wide) g1_->bases_destroy(nh_wide);
+                free_csr(nA), free_csr(nB), free_csr(nC);
+                return rc;
+            }
         }
-        // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them
+        // ---- commit
+        std::lock_guard<std::mutex> g(mu_);
+        free_csr(A_), free_csr(B_), free_csr(C_);
+        A_ = nA, B_ = nB, C_ = nC;
+        if (new_domain) {
+            if (h_bs_) g1_->bases_destroy(h_bs_);
+            if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
+            h_bs_ = nh, h_bs_wide_ = nh_wide;
+        }
+        // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them (slots of
+        // another generation that are still in flight cannot exist -- the exclusive lock waited for them)
         for (auto &kv : ws_free_)
             for (ProveWs *w : kv.second) delete w;
         ws_free_.clear();
+        idle_slots_ = 0;
+        ++gen_;
         m_ = m;
         log_d_ = lg;
         have_r1cs_ = true;
@@ -291,17 +372,23 @@ class ProverImpl : public Prover {
     }
 
     ProveWs *ws_acquire(u32 k = 1) {
+        u64 gen;
         {
             std::lock_guard<std::mutex> g(mu_);
+            gen = gen_;
             auto it = ws_free_.find(k);
-            if (it != ws_free_.end() && !it->second.empty()) {
+            while (it != ws_free_.end() && !it->second.empty()) {
                 ProveWs *w = it->second.back();
                 it->second.pop_back();
-                return w;
+                --idle_slots_;
+                if (w->gen == gen_) return w;
+                delete w; // sized / captured for a previous circuit
             }
         }
         ProveWs *w = new ProveWs();
         w->k = k;
+        w->gen = gen;
+        w->device = dev_;
         if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
             !(w->side[1] = stream_pool_get()) || hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
@@ -335,9 +422,34 @@ class ProverImpl : public Prover {
         }
         return w;
     }
+    // Idle slots are cached per exact batch size (their buffers and graphs are sized for it) but the cache is
+    // bounded: a slot of an outdated circuit generation is destroyed, and beyond MAX_IDLE_SLOTS the least recently
+    // used idle slot goes -- its MSM workspaces return to the engine pool, which is bounded too (runtime.cpp), so a
+    // service that varies k or creates and drops contexts does not accumulate HBM.
     void ws_release(ProveWs *w) {
-        std::lock_guard<std::mutex> g(mu_);
-        ws_free_[w->k].push_back(w);
+        std::vector<ProveWs *> doomed;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (w->gen != gen_) {
+                doomed.push_back(w);
+            } else {
+                w->last_use = ++lru_tick_;
+                ws_free_[w->k].push_back(w);
+                ++idle_slots_;
+                while (idle_slots_ > MAX_IDLE_SLOTS) {
+                    std::vector<ProveWs *> *from = nullptr;
+                    size_t at = 0;
+                    for (auto &kv : ws_free_)
+                        for (size_t i = 0; i < kv.second.size(); ++i)
+                            if (!from || kv.second[i]->last_use < (*from)[at]->last_use) from = &kv.second, at = i;
+                    if (!from) break;
+                    doomed.push_back((*from)[at]);
+                    from->erase(from->begin() + (long)at);
+                    --idle_slots_;
+                }
+            }
+        }
+        for (ProveWs *d : doomed) delete d;
     }
 
     // Witness map for the slot's w->k assignments (stored back to back, like the three work vectors: member q of
@@ -384,6 +496,8 @@ class ProverImpl : public Prover {
     }
 
     int witness_map_host(const uint64_t *z, uint64_t *h_out) override {
+        MG_HIP(hipSetDevice(dev_));
+        std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
         if (!have_r1cs_) return MG_ERR_STATE;
         ProveWs *w = ws_acquire();
         if (!w) return MG_ERR_HIP;
@@ -422,11 +536,15 @@ class ProverImpl : public Prover {
         // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
         // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
         const bool wide = w->k >= 4;
+        // a range shard multiplies its contiguous slice of every query by the matching slice of the scalars
+        const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
+        const size_t hlo = shard_lo(D), hn = shard_hi(D) - hlo;
+        const u32 *sz = dz + (1 + zlo) * 8;
         return MsmArgs{{wide && a_bs_wide_ ? a_bs_wide_ : a_bs_, wide && b1_bs_wide_ ? b1_bs_wide_ : b1_bs_,
                         wide && b2_bs_wide_ ? b2_bs_wide_ : b2_bs_, wide && l_bs_wide_ ? l_bs_wide_ : l_bs_,
                         wide && h_bs_wide_ ? h_bs_wide_ : h_bs_},
-                       {dz + 8, dz + 8, dz + 8, dz + (size_t)P_ * 8, w->a.as<u32>()},
-                       {(size_t)V_ - 1, (size_t)V_ - 1, (size_t)V_ - 1, (size_t)(V_ - P_), D},
+                       {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * 8},
+                       {zn, zn, zn, ln, hn},
                        {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * 8}};
     }
     static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
@@ -546,11 +664,20 @@ class ProverImpl : public Prover {
     // flight, to assemble one half on the host while the GPU works on the other, was measured and gains nothing:
     // the smaller passes lose what the overlap wins. Two calling threads with a batch each do overlap.)
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
-        if (!have_r1cs_) return MG_ERR_STATE;
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
+        // shared against set_r1cs on every shard for the length of the pass
+        std::vector<std::shared_lock<std::shared_mutex>> locks;
+        locks.emplace_back(shape_mu_);
+        for (ProverImpl *q : peers_) locks.emplace_back(q->shape_mu_);
+        if (!have_r1cs_) return MG_ERR_STATE;
+        // every shard gets the whole assignment (1.1 MB for PrivateTransfer) and recomputes the witness map -- cheaper
+        // than broadcasting h -- then multiplies its slices; shard 0 launches last and assembles
+        std::vector<Pass> pp(peers_.size());
+        int rc = MG_OK;
+        for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
-        const int rc = launch_pass(p, (u32)k64, z, r, s, proofs_out);
-        return finish_pass(p, rc);
+        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out);
+        return finish_pass(p, rc, &pp);
     }
 
     struct Pass {
@@ -571,6 +698,7 @@ class ProverImpl : public Prover {
 
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
     int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out) {
+        MG_HIP(hipSetDevice(dev_));
         p.k = k, p.r = r, p.s = s, p.out = out;
         ProveWs *w = p.w = ws_acquire(k);
         if (!w) return MG_ERR_HIP;
@@ -607,9 +735,49 @@ class ProverImpl : public Prover {
     }
 
     // host side of a pass: blinding terms while the GPU works, wait, fold the MSM results, assemble and encode
-    int finish_pass(Pass &p, int rc) {
+    // wait for one part of a pass on this shard and fold its MSMs: res[i * k + q] = MSM i of proof q
+    int collect_part(Pass &p, bool part_a, HostPoint *res) {
         ProveWs *w = p.w;
-        if (!w) return rc ? rc : MG_ERR_HIP;
+        if (!w) return MG_ERR_HIP;
+        int rc = MG_OK;
+        hipSetDevice(dev_);
+        hipError_t e = hipStreamSynchronize(part_a ? w->stream : msm_stream(w, 2));
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "prove: hipStreamSynchronize", __FILE__, __LINE__);
+            rc = MG_ERR_HIP;
+        }
+        for (int i = 0; i < 5; ++i) {
+            if (in_part_a(i) != part_a) continue;
+            if (w->mw[i]->pending) {
+                int rc2 = w->me[i]->msm_finish(w->mw[i], res + (size_t)i * p.k, true);
+                if (!rc) rc = rc2;
+            } else {
+                hipStreamSynchronize(msm_stream(w, i));
+                if (!rc) rc = MG_ERR_STATE;
+            }
+        }
+        return rc;
+    }
+    void abandon_pass(Pass &p) { // a pass that will not be assembled: drain its streams, return the slot
+        if (!p.w) return;
+        hipSetDevice(dev_);
+        hipStreamSynchronize(p.w->stream);
+        for (int i = 0; i < 5; ++i) {
+            hipStreamSynchronize(msm_stream(p.w, i));
+            p.w->mw[i]->pending = 0;
+        }
+        ws_release(p.w);
+        p.w = nullptr;
+    }
+
+    int finish_pass(Pass &p, int rc, std::vector<Pass> *peer_passes = nullptr) {
+        ProveWs *w = p.w;
+        if (!w || rc) {
+            if (peer_passes)
+                for (size_t g = 0; g < peers_.size(); ++g) peers_[g]->abandon_pass((*peer_passes)[g]);
+            if (w) abandon_pass(p);
+            return rc ? rc : MG_ERR_HIP;
+        }
         const u32 k = p.k;
         const uint64_t *r = p.r, *s = p.s;
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
@@ -633,22 +801,22 @@ class ProverImpl : public Prover {
                 g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
             }
         }
-        std::vector<HostPoint> res((size_t)5 * k); // res[i * k + q]: MSM i of proof q
-        auto collect = [&](hipStream_t s, bool part_a) { // wait for one part and fold its MSMs
-            hipError_t e = hipStreamSynchronize(s);
-            if (e != hipSuccess && !rc) {
-                set_last_hip_error(e, "prove: hipStreamSynchronize", __FILE__, __LINE__);
-                rc = MG_ERR_HIP;
-            }
-            for (int i = 0; i < 5; ++i) {
-                if (in_part_a(i) != part_a) continue;
-                if (w->mw[i]->pending) {
-                    int rc2 = w->me[i]->msm_finish(w->mw[i], &res[(size_t)i * k], true);
+        std::vector<HostPoint> res((size_t)5 * k), tmp; // res[i * k + q]: MSM i of proof q
+        auto collect = [&](hipStream_t, bool part_a) { // wait for one part on every shard and fold its MSMs
+            int rc2 = collect_part(p, part_a, res.data());
+            if (!rc) rc = rc2;
+            if (peer_passes && !peers_.empty()) { // the exchange step of the sharded path: partial points are summed here
+                tmp.resize((size_t)5 * k);
+                for (size_t g = 0; g < peers_.size(); ++g) {
+                    rc2 = peers_[g]->collect_part((*peer_passes)[g], part_a, tmp.data());
                     if (!rc) rc = rc2;
-                } else {
-                    hipStreamSynchronize(msm_stream(w, i));
-                    if (!rc) rc = MG_ERR_STATE;
+                    for (int i = 0; i < 5 && !rc2; ++i) {
+                        if (in_part_a(i) != part_a) continue;
+                        GroupEngine *ge = i == 2 ? g2_ : g1_;
+                        for (u32 q = 0; q < k; ++q) ge->hp_add(&res[(size_t)i * k + q], &tmp[(size_t)i * k + q]);
+                    }
                 }
+                hipSetDevice(dev_);
             }
         };
         const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
@@ -684,6 +852,12 @@ class ProverImpl : public Prover {
         collect(msm_stream(w, 2), false);
         ws_release(w);
         p.w = nullptr;
+        if (peer_passes)
+            for (size_t g = 0; g < peers_.size(); ++g) {
+                Pass &pg = (*peer_passes)[g];
+                if (pg.w) peers_[g]->ws_release(pg.w);
+                pg.w = nullptr;
+            }
         if (rc) return rc;
         for (u32 q = 0; q < k; ++q) {
             HostPoint g2_b = res[2 * (size_t)k + q];
@@ -698,13 +872,34 @@ class ProverImpl : public Prover {
 } // namespace
 
 int prover_create(int curve, const mg_pk_view *pk, Prover **out) {
-    ProverImpl *p = new ProverImpl();
-    int rc = p->init(curve, pk);
+    int dev = 0;
+    MG_HIP(hipGetDevice(&dev));
+    return prover_create_sharded(curve, pk, &dev, 1, out);
+}
+
+// One context over a list of devices: shard g owns the g-th contiguous slice of every query on devices[g] (a
+// device may be listed more than once -- two shards then share it, which is how the path is tested on a 1-GPU
+// box). Shard 0 is the object handed back; it owns the others.
+int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out) {
+    if (!pk || !devices || n_devices < 1 || n_devices > 64 || !out) return MG_ERR_ARG;
+    int count = 0, prev = 0;
+    MG_HIP(hipGetDeviceCount(&count));
+    MG_HIP(hipGetDevice(&prev));
+    for (int g = 0; g < n_devices; ++g)
+        if (devices[g] < 0 || devices[g] >= count) return MG_ERR_ARG;
+    ProverImpl *p0 = new ProverImpl();
+    int rc = MG_OK;
+    for (int g = n_devices - 1; g >= 0 && !rc; --g) { // shard 0 last: it ends up the current device's context
+        ProverImpl *p = g == 0 ? p0 : new ProverImpl();
+        if (g) p0->peers_.insert(p0->peers_.begin(), p);
+        rc = p->init(curve, pk, devices[g], (u32)g, (u32)n_devices);
+    }
+    hipSetDevice(prev);
     if (rc) {
-        delete p;
+        delete p0;
         return rc;
     }
-    *out = p;
+    *out = p0;
     return MG_OK;
 }
 

@@ -59,10 +59,16 @@ class Prover {
     virtual int prove_batch(u64 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) = 0;
     virtual int witness_map_host(const uint64_t *z, uint64_t *h_out) = 0;
     virtual u64 domain_size() const = 0;
+    virtual u64 n_vars() const = 0;
+    virtual u64 n_inputs() const = 0;
+    virtual u32 n_shards() const = 0;
 };
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);
+// every MSM of a proof range-sharded over the listed devices; devices may repeat
+int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out);
 // arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
-int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out);
+int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices = nullptr,
+                             int n_devices = 0);
 // Groth16 key generation from explicit toxic waste and group generators (setup.cpp)
 int groth16_setup(int curve, const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, u64 n_vars, u64 n_inputs,
                   const u64 *toxic5, const u64 *g1_gen, const u64 *g2_gen, const mg_pk_out *out);

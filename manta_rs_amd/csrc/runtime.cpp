@@ -3,6 +3,7 @@
 #include "engine.h"
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 
 namespace mg {
@@ -56,13 +57,21 @@ void DevBuf::release() {
 // streams are normal-priority; a high-priority launch stream lives in the other hardware-queue pool and can
 // never alias them.
 static std::mutex g_stream_mu;
-static std::vector<hipStream_t> g_stream_pool;
+static std::vector<hipStream_t> g_stream_pools[MAX_DEVICES]; // a stream belongs to the device it was created on
+static std::map<hipStream_t, int> g_stream_dev;
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) return 0;
+    return d;
+}
 hipStream_t stream_pool_get() {
+    const int dev = current_device();
     {
         std::lock_guard<std::mutex> g(g_stream_mu);
-        if (!g_stream_pool.empty()) {
-            hipStream_t s = g_stream_pool.back();
-            g_stream_pool.pop_back();
+        std::vector<hipStream_t> &pool = g_stream_pools[dev];
+        if (!pool.empty()) {
+            hipStream_t s = pool.back();
+            pool.pop_back();
             return s;
         }
     }
@@ -70,12 +79,15 @@ hipStream_t stream_pool_get() {
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return nullptr;
     if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    g_stream_dev[s] = dev;
     return s;
 }
 void stream_pool_put(hipStream_t s) {
     if (!s) return;
     std::lock_guard<std::mutex> g(g_stream_mu);
-    g_stream_pool.push_back(s);
+    auto it = g_stream_dev.find(s);
+    g_stream_pools[it == g_stream_dev.end() ? 0 : it->second].push_back(s);
 }
 
 MsmWorkspace::~MsmWorkspace() {
@@ -99,6 +111,7 @@ MsmWorkspace *GroupEngine::ws_acquire() {
         }
     }
     MsmWorkspace *w = new MsmWorkspace();
+    w->device = current_device();
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&w->t0) != hipSuccess || hipEventCreate(&w->t1) != hipSuccess) {
@@ -107,18 +120,33 @@ MsmWorkspace *GroupEngine::ws_acquire() {
     }
     return w;
 }
+// The idle pool is bounded: beyond MAX_IDLE_WS a released workspace is destroyed (its grow-only buffers are
+// freed), so HBM held for past MSM sizes / dropped contexts does not accumulate.
 void GroupEngine::ws_release(MsmWorkspace *w) {
     if (!w) return;
-    std::lock_guard<std::mutex> g(ws_mu_);
-    ws_free_.push_back(w);
+    {
+        std::lock_guard<std::mutex> g(ws_mu_);
+        if (ws_free_.size() < MAX_IDLE_WS) {
+            ws_free_.push_back(w);
+            return;
+        }
+    }
+    int prev = 0;
+    hipGetDevice(&prev);
+    hipSetDevice(w->device);
+    delete w;
+    hipSetDevice(prev);
 }
 
+// one engine per (device, curve, group): an engine's workspaces, streams and tables live on the device that was
+// current when it was first asked for
 GroupEngine *get_engine(int curve, int group) {
     static std::mutex mu;
-    static GroupEngine *tab[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    static GroupEngine *tab[MAX_DEVICES][2][2] = {};
     if (curve < 0 || curve > 1 || group < 1 || group > 2) return nullptr;
+    const int dev = current_device();
     std::lock_guard<std::mutex> g(mu);
-    GroupEngine *&e = tab[curve][group - 1];
+    GroupEngine *&e = tab[dev][curve][group - 1];
     if (!e) {
         if (curve == 0)
             e = group == 1 ? make_engine_bn254_g1() : make_engine_bn254_g2();

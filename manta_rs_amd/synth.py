@@ -217,36 +217,51 @@ def make_circuit(curve: int, m: int, V: int, P: int, seed: int = 0x4D414E5441_00
                    to_mont(z, p, 4))
 
 
+class Reassigner:
+    """Further satisfying assignments of one circuit (same matrices): fresh instance values, fresh boolean
+    witnesses, every gate output recomputed from its defining row -- distinct proofs of one ProvingContext. The
+    matrices are parsed once, so a batch of hundreds of assignments of a PrivateTransfer-sized circuit costs
+    ~0.1 s each."""
+
+    def __init__(self, c: Circuit):
+        self.c = c
+        p = FR_MODULUS[c.curve]
+        Rinv = pow(1 << 256, -1, p)
+
+        def rows(M):
+            vals = [v * Rinv % p for v in limbs_to_ints(M.val)] if len(M.col) else []
+            col = M.col.tolist()
+            rp = M.row_ptr.tolist()
+            return [[(col[k], vals[k]) for k in range(rp[i], rp[i + 1])] for i in range(c.m)]
+
+        self.A, self.B, self.C = rows(c.A), rows(c.B), rows(c.C)
+
+    def assign(self, seed: int) -> Circuit:
+        c, A, B, C = self.c, self.A, self.B, self.C
+        p = FR_MODULUS[c.curve]
+        rng = XorShift(seed)
+        z = [0] * c.V
+        z[0] = 1
+        for j in range(1, c.P):
+            z[j] = rng.field(p)
+        nw = c.V - c.P
+        for k in range(min(nw, c.m)):
+            v = c.P + k
+            if not C[k]:  # boolean witness: v * (1 - v) = 0
+                z[v] = rng.below(2)
+            else:         # gate with output v: (sum A)(sum B) = z[v]
+                sa = sum(cf * z[i] for i, cf in A[k]) % p
+                sb = sum(cf * z[i] for i, cf in B[k]) % p
+                assert C[k] == [(v, 1)]
+                z[v] = sa * sb % p
+        for k in range(c.m, nw):
+            z[c.P + k] = rng.field(p)
+        return dataclasses.replace(c, z_int=z, z=to_mont(z, p, 4))
+
+
 def reassign(c: Circuit, seed: int) -> Circuit:
-    """Another satisfying assignment of the same circuit (same matrices): fresh instance values, fresh boolean
-    witnesses, every gate output recomputed from its defining row -- distinct proofs of one ProvingContext."""
-    p = FR_MODULUS[c.curve]
-    rng = XorShift(seed)
-    Rinv = pow(1 << 256, -1, p)
-
-    def rows(M):
-        vals = [v * Rinv % p for v in limbs_to_ints(M.val)] if len(M.col) else []
-        return [[(int(M.col[k]), vals[k]) for k in range(M.row_ptr[i], M.row_ptr[i + 1])] for i in range(c.m)]
-
-    A, B, C = rows(c.A), rows(c.B), rows(c.C)
-    z = [0] * c.V
-    z[0] = 1
-    for j in range(1, c.P):
-        z[j] = rng.field(p)
-    nw = c.V - c.P
-    for k in range(min(nw, c.m)):
-        v = c.P + k
-        if not C[k]:  # boolean witness: v * (1 - v) = 0
-            z[v] = rng.below(2)
-        else:         # gate with output v: (sum A)(sum B) = z[v]
-            sa = sum(cf * z[i] for i, cf in A[k]) % p
-            sb = sum(cf * z[i] for i, cf in B[k]) % p
-            assert C[k] == [(v, 1)]
-            z[v] = sa * sb % p
-    for k in range(c.m, nw):
-        z[c.P + k] = rng.field(p)
-    out = dataclasses.replace(c, z_int=z, z=to_mont(z, p, 4))
-    return out
+    """One more satisfying assignment of the same circuit (see Reassigner)."""
+    return Reassigner(c).assign(seed)
 
 
 def make_shape(curve: int, name: str, seed: int = 0x4D414E5441_0001) -> Circuit:
