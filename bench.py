@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X Groth16 hot path.
 
-Metric (BASELINE.json): "G1 MSM Mscalar/s at 2^20" on configs[1] = "2^20 BLS12-381 G1 variable-base
-MSM, synthetic scalars/bases, 1 MI355X". A step = one full MSM (digits -> sort -> bucket accumulate ->
-merge -> bucket reduce -> host fold to one affine point) over n = 2^20 scalars that are already
-resident in HBM, against bases registered (resident, with their 2^(c w) multiples) before timing.
+BASELINE.json's metric has two halves and the default line carries both:
+
+  "G1 MSM Mscalar/s at 2^20"  (the line's `metric` / `value`; configs[1] = "2^20 BLS12-381 G1 variable-base MSM,
+      synthetic scalars/bases, 1 MI355X"). A step = one full MSM (digits -> sort -> bucket accumulate -> merge ->
+      bucket reduce -> host fold to one affine point) over n = 2^20 scalars already resident in HBM, against bases
+      registered (resident, with their 2^(c w) multiples) before timing.
+  "Groth16 proofs/sec (manta-pay PrivateTransfer)"  (the line's `proofs` object): whole proofs of the shape-exact
+      PrivateTransfer circuit (BN254, D = 2^16, V = 35 175, P = 27) through mg_groth16_prove / _prove_batch --
+      sequential latency, two host threads on one context, and batches of 32 -- with its own cpu_baseline.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-N > 1 (weak scaling): the global MSM has N * 2^20 terms, sharded by contiguous base/scalar range, one
-process per GPU; every step ends with an RCCL all_gather of the N partial points (96 B each, xGMI) and
-the local N-term sum -- SURVEY.md section 8(e). value = N * 2^20 * K / t with t the max over ranks.
+N > 1 (weak scaling, the line's `value`): the global MSM has N * 2^20 terms, sharded by contiguous base/scalar range,
+one process per GPU; every step ends with an RCCL all_gather of the N partial points (96 B each, xGMI) and the local
+N-term sum (manta_rs_amd/distributed.py) -- SURVEY.md section 8(e). value = N * 2^20 * K / t, t = max over ranks. The
+same run also measures STRONG scaling (`strong_scaling`: a fixed 2^20-term and a fixed 35 174-term MSM split N ways)
+and the proofs half as replicas (no collective).
 
-One JSON line on rank 0. `roofline` is for the dominant kernel (bucket accumulate), timed live with HIP
-events on its own stream; `cpu_baseline` is the arkworks-algorithm CPU restatement (oracle/, 1 thread
-like the reference) on a bounded prefix of the same inputs.
+`roofline` is for the dominant kernel (bucket accumulate), timed live with HIP events on the stream it runs on;
+`cpu_baseline` is the arkworks-algorithm CPU restatement (oracle/) on the GPU box's host: 1 thread (what the
+reference ships) and all cores (arkworks' `parallel` decomposition), on the same inputs.
 """
 import argparse
 import json
 import os
+import shutil
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,140 +37,203 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-LOG_N = int(os.environ.get("MANTA_BENCH_LOGN", "20"))  # 20 = the BASELINE config; smaller n only for scaling studies
+LOG_N = int(os.environ.get("MANTA_BENCH_LOGN", "20"))  # 20 = the BASELINE config; smaller n only for studies
 CURVE = 1  # BLS12-381
 WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
 DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
 ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+# v_mad_u64_u32 per mixed addition in the 14 x 28-bit representation: 8 products x 406 + 2 squarings x 315
+MADS_PER_MIXED_ADD = 8 * 406 + 2 * 315
+PEAK_TMAD_S = 1024 * 64 / 4.2 * 2.4e9 / 1e12  # 1024 SIMDs x 64 lanes / 4.2 cycles (profiles/r01_ubench2_mad_u64_u32.txt) x 2.4 GHz
 
 BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
           0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+S0, S1 = 0x243F6A8885A308D313198A2E03707344, 0x9E3779B97F4A7C15F39CC0605CEDC835
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["msm", "prove"], default="msm",
-                    help="msm = BASELINE configs[1] (default, the headline line); prove = whole Groth16 proofs of a "
-                         "manta-pay circuit shape (configs[0]/[3]/[4] shapes, BN254)")
-    ap.add_argument("--shape", default="private_transfer", choices=["to_private", "to_public", "private_transfer"])
-    ap.add_argument("--threads", type=int, default=2, help="prove workload: host threads issuing proofs concurrently")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="prove workload: proofs per mg_groth16_prove_batch call (a step is still ONE proof)")
-    args = ap.parse_args()
-    if args.workload == "prove":
-        return prove_main(args)
+def host_info():
+    """CPU model / thread count of the box the CPU baselines run on, and whether the real reference could be timed
+    here (it needs cargo plus an offline registry holding the ark-* 0.3 crates)."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    cargo = shutil.which("cargo")
+    reg = os.path.isdir(os.path.expanduser("~/.cargo/registry"))
+    return {"cpu_model": model, "hardware_concurrency": os.cpu_count(),
+            "cargo": {"cargo_on_path": cargo, "cargo_registry_present": reg,
+                      "reference_timed": False,
+                      "note": "no Rust toolchain / offline ark-* registry on this box: the CPU baseline is the C restatement of "
+                              "the arkworks 0.3 algorithms (oracle/), not `cargo bench -p manta-benchmark`" if not (cargo and reg)
+                      else "cargo and a registry exist: `cargo bench -p manta-benchmark --bench private_transfer` could be run by hand"}}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
-    import torch
-    import torch.distributed as dist
-    from manta_rs_amd import api, synth
+class Env:
+    """Process-per-GPU plumbing: device, process group, barrier, max-over-ranks."""
 
-    dev = _device_index(local_rank)
-    backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")  # "gloo": single-GPU functional check of the N>1 path
-    torch.cuda.set_device(dev)
-    api.init(dev)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from manta_rs_amd import api
+        self.torch, self.dist, self.api = torch, dist, api
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, f"WORLD_SIZE={self.world} but --gpus {args.gpus}"
+        # MANTA_BENCH_DEVICE pins every rank to one device (functional test of the multi-process path on a 1-GPU box)
+        self.dev = int(os.environ.get("MANTA_BENCH_DEVICE", self.local_rank))
+        self.backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(self.dev)
+        api.init(self.dev)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev))
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
 
-    n = 1 << LOG_N
-    p = synth.FR_MODULUS[CURVE]
-    q = synth.FQ_MODULUS[CURVE]
-    G = synth.to_mont(list(BLS_G1), q, 6).reshape(-1)
+    def barrier(self):
+        self.api.synchronize()
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
-    # ---- synthetic inputs (untimed). Bases: arithmetic progression P_i = [s0 + i*s1]G over the GLOBAL
-    # index range, built on the GPU by the library's fixed-base batch multiply; rank r owns [r*n, (r+1)*n).
-    s0, s1 = 0x243F6A8885A308D313198A2E03707344, 0x9E3779B97F4A7C15F39CC0605CEDC835
-    base_idx = np.arange(rank * n, (rank + 1) * n, dtype=object)
-    ks = [(s0 + int(i) * s1) % p for i in base_idx]
-    d_ks = api.DeviceBuffer.from_numpy(synth.ints_to_limbs(ks, 4))
-    d_pts = api.fixed_base_mul(CURVE, 1, G, d_ks, n)
-    bases = api.Bases(CURVE, 1, (d_pts.ptr, n), precompute_window_bits=WINDOW_BITS, on_device=True)
-    scalars = synth.msm_scalars(CURVE, n, "U", seed=0x4D414E54 + rank)  # uniform: the h-query MSM's case
-    d_sc = api.DeviceBuffer.from_numpy(scalars)
-    api.synchronize()
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    acc_ms = []
+    def sum_ints_mod(self, v, p):
+        if self.world == 1:
+            return v % p
+        parts = [None] * self.world
+        self.dist.all_gather_object(parts, v)
+        return sum(parts) % p
 
-    def gather_sum(local_pt):
-        if world == 1:
-            return local_pt
-        t = torch.from_numpy(local_pt.view(np.int64))
-        if backend == "nccl":
-            t = t.cuda()
-        outs = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)  # RCCL over xGMI: 96 B per rank
-        pts = torch.stack(outs).cpu().numpy().view(np.uint64)
-        return api.points_sum(CURVE, 1, pts)
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
 
-    def barrier():
+
+class MsmInstance:
+    """One range shard of an n_total-term BLS12-381 G1 MSM: bases P_i = [S0 + i S1]G for i in this rank's range (built
+    on the GPU by the library's fixed-base multiply), uniform scalars, both resident in HBM. The closed form
+    sum_i k_i (S0 + i S1) mod r gives the expected global point from one scalar multiplication."""
+
+    def __init__(self, env, n_total, window_bits, seed):
+        from manta_rs_amd import api, synth, distributed
+        self.env, self.api = env, api
+        p, q = synth.FR_MODULUS[CURVE], synth.FQ_MODULUS[CURVE]
+        self.p = p
+        self.G = synth.to_mont(list(BLS_G1), q, 6).reshape(-1)
+        lo, hi = distributed.shard_range(n_total, env.rank, env.world)
+        self.n = hi - lo
+        self.ks = [(S0 + i * S1) % p for i in range(lo, hi)]
+        d_ks = api.DeviceBuffer.from_numpy(synth.ints_to_limbs(self.ks, 4))
+        self.d_pts = api.fixed_base_mul(CURVE, 1, self.G, d_ks, self.n)
+        self.bases = api.Bases(CURVE, 1, (self.d_pts.ptr, self.n), precompute_window_bits=window_bits, on_device=True)
+        self.scalars = synth.msm_scalars(CURVE, self.n, "U", seed=seed + env.rank)  # uniform: the h-query MSM's case
+        self.d_sc = api.DeviceBuffer.from_numpy(self.scalars)
+        self.msm = distributed.ShardedMSM(self.bases)
+        self.synth = synth
         api.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    def run(steps):
-        """DEPTH MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i
-        (bucket reduce, host fold, partial-point exchange) overlaps the accumulate kernel of step i+1."""
-        res = None
-        pending = []
+    def expected(self):
+        part = sum(k * b for k, b in zip(self.synth.limbs_to_ints(self.scalars), self.ks))
+        t = self.env.sum_ints_mod(part, self.p)
+        d_one = self.api.DeviceBuffer.from_numpy(self.synth.ints_to_limbs([t], 4))
+        return self.api.fixed_base_mul(CURVE, 1, self.G, d_one, 1).to_numpy()
+
+    def run(self, steps, depth, acc_ms=None):
+        """`depth` MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i (bucket reduce,
+        host fold, partial-point exchange) overlaps the accumulate kernel of step i+1. depth = 1: latency mode."""
+        res, pending = None, []
 
         def finish_one():
-            pt = pending.pop(0).finish()
-            acc_ms.append(api.last_accumulate_ms())  # HIP events around the accumulate kernel, on its own stream
-            return gather_sum(pt)
+            out = pending.pop(0).finish()  # local fold + all_gather of the partial points + N-term sum
+            if acc_ms is not None:
+                acc_ms.append(self.api.last_accumulate_ms())  # HIP events around the accumulate kernel, on its stream
+            return out
         for _ in range(steps):
-            pending.append(api.VariableBaseMSM.launch(bases, d_sc, n))
-            if len(pending) == DEPTH:
+            pending.append(self.msm.launch(self.d_sc, self.n))
+            if len(pending) == depth:
                 res = finish_one()
         while pending:
             res = finish_one()
         return res
 
-    # ---- correctness gate before any timing counts: closed form sum_i k_i (s0 + i s1) mod r, one scalar mult
-    result = run(1)
-    sc_int = synth.limbs_to_ints(scalars)
-    part = sum(k * b for k, b in zip(sc_int, ks)) % p
-    if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, part)
-        part = sum(parts) % p
-    d_one = api.DeviceBuffer.from_numpy(synth.ints_to_limbs([part], 4))
-    expect = api.fixed_base_mul(CURVE, 1, G, d_one, 1).to_numpy()
-    assert (result == expect).all(), "MSM result does not match the closed-form expectation"
+    def timed(self, steps, depth, warmup=2, kernel_timing=False):
+        """-> (seconds for `steps` steps: max over ranks, list of accumulate-kernel durations in ms)"""
+        env = self.env
+        self.run(warmup, depth)
+        acc = []
+        if kernel_timing:
+            self.api.set_kernel_timing(True)
+        env.barrier()
+        t0 = time.perf_counter()
+        self.run(steps, depth, acc if kernel_timing else None)
+        env.barrier()
+        dt = time.perf_counter() - t0
+        if kernel_timing:
+            self.api.set_kernel_timing(False)
+        return env.max_over_ranks(dt), acc
 
-    run(args.warmup)
-    api.set_kernel_timing(True)  # two hipEventRecord per MSM: the dominant kernel is timed live, in the timed region
-    barrier()
-    acc_ms.clear()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    api.set_kernel_timing(False)
-    timed_acc_ms = list(acc_ms)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    # ---- roofline of the dominant kernel from the HIP-event durations collected in the timed region (rank 0)
+def msm_bench(args, env):
+    n = 1 << LOG_N
+    inst = MsmInstance(env, env.world * n, WINDOW_BITS, seed=0x4D414E54)
+    # ---- correctness gate before any timing counts
+    result = inst.run(1, 1)
+    assert (result == inst.expected()).all(), "MSM result does not match the closed-form expectation"
+
+    dt, acc_pipe = inst.timed(args.steps, DEPTH, warmup=args.warmup, kernel_timing=True)
+    line = {
+        "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(env.world * n * args.steps / dt / 1e6, 3),
+        "unit": "Mscalar/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+    }
+    # ---- latency mode (one MSM at a time: nothing hides the merge / reduce / host-fold tail) doubles as the
+    # stand-alone measurement of the dominant kernel: with one MSM in flight the HIP-event span IS the kernel's duration
+    lat_steps = max(5, min(args.steps, 10))
+    dt_lat, acc_alone = inst.timed(lat_steps, 1, warmup=2, kernel_timing=True)
+    # ---- plain bases: what `VariableBaseMSM::multi_scalar_mul(bases, scalars)` literally takes (no precomputed tables)
+    plain = None
+    if env.world == 1 and not args.quick:
+        from manta_rs_amd import api, distributed
+        pb = api.Bases(CURVE, 1, (inst.d_pts.ptr, inst.n), precompute_window_bits=0, on_device=True)
+        keep = inst.bases, inst.msm
+        inst.bases, inst.msm = pb, distributed.ShardedMSM(pb)
+        assert (inst.run(1, 1) == result).all()
+        dt_p1, _ = inst.timed(lat_steps, 1)
+        dt_p3, _ = inst.timed(lat_steps, DEPTH)
+        plain = {"latency_mode_Mscalar_s": round(n * lat_steps / dt_p1 / 1e6, 2), "pipelined_Mscalar_s": round(n * lat_steps / dt_p3 / 1e6, 2),
+                 "bases_hbm_bytes": pb.device_bytes()}
+        inst.bases, inst.msm = keep
+        pb.close()
+    line["config"] = {
+        "workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
+        "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS, "msms_in_flight": DEPTH,
+        "precomputed_base_multiples": True, "bases_hbm_bytes": inst.bases.device_bytes(),
+        "note": "headline = pipelined (%d MSMs in flight) against bases with precomputed 2^(16w) multiples (a full 2^20 "
+                "BLS12-381 key needs 5 such tables, ~10 GB of the 288 GB)" % DEPTH,
+        "latency_mode": {"Mscalar_s": round(env.world * n * lat_steps / dt_lat / 1e6, 2), "ms_per_msm": round(dt_lat / lat_steps * 1e3, 4)},
+        "plain_bases": plain,
+        "sharding": "contiguous base/scalar ranges, all_gather of partial points (RCCL) + N-term host sum" if env.world > 1 else "none"}
+
     roofline = cpu = None
-    if rank == 0:
-        k_ms = float(np.mean(timed_acc_ms))  # average launch duration over the K timed steps (MSMs overlap: DEPTH in flight)
-        achieved = n * ALGO_BYTES_PER_SCALAR / (k_ms * 1e-3) / 1e9
+    if env.rank == 0:
+        k_alone = float(np.mean(acc_alone))
+        k_pipe = float(np.mean(acc_pipe))
+        algo = n * ALGO_BYTES_PER_SCALAR
+        achieved = algo / (k_alone * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
         if os.path.exists(pmc):
@@ -169,99 +241,101 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        mads = None
+        if LOG_N == 20 and WINDOW_BITS == 16:  # ~15.06 mixed adds per scalar (16 signed 16-bit windows, top one nearly empty)
+            m = n * 15.06 * MADS_PER_MIXED_ADD
+            mads = {"mads_per_launch": int(m), "achieved_Tmad_s": round(m / (k_alone * 1e-3) / 1e12, 2),
+                    "peak_Tmad_s": round(PEAK_TMAD_S, 2), "frac": round(m / (k_alone * 1e-3) / 1e12 / PEAK_TMAD_S, 3)}
         roofline = {"bound": "hbm", "kernel": "accumulate_chunks<FpR<Bls381Fq>>", "achieved": round(achieved, 2),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                    "traffic": traffic, "kernel_ms": round(k_ms, 4),
-                    "algorithmic_bytes_per_launch": n * ALGO_BYTES_PER_SCALAR,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "kernel_ms": round(k_alone, 4),
+                    "kernel_ms_how": "HIP events on the kernel's own stream, averaged over the %d latency-mode steps of this run "
+                                     "(one MSM in flight, so the span is the launch duration; rocprofv3 --kernel-trace of "
+                                     "MANTA_BENCH_DEPTH=1 runs agrees: profiles/)" % lat_steps,
+                    "kernel_ms_pipelined_span": round(k_pipe, 4),
+                    "kernel_ms_pipelined_note": "same events inside the timed region: with %d MSMs in flight the span also holds "
+                                                "time queued behind / shared with the neighbours' kernels, so it exceeds ms_per_step" % DEPTH,
+                    "algorithmic_bytes_per_launch": algo,
                     "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); int_mad gives the bound that governs",
-                    # v_mad_u64_u32 per launch: ~15.06 mixed adds per scalar (16 signed 16-bit windows, top one nearly
-                    # empty) x (8 mul x 406 + 2 sqr x 315) mads; peak = 1024 SIMDs x 64 lanes / 4.2 cycles (measured issue
-                    # rate, profiles/r01_ubench2_mad_u64_u32.txt) x 2.4 GHz
-                    "int_mad": {"mads_per_launch": int(n * 15.06 * 3878), "achieved_Tmad_s": round(n * 15.06 * 3878 / (k_ms * 1e-3) / 1e12, 2),
-                                "peak_Tmad_s": round(1024 * 64 / 4.2 * 2.4e9 / 1e12, 2),
-                                "frac": round(n * 15.06 * 3878 / (k_ms * 1e-3) / (1024 * 64 / 4.2 * 2.4e9), 3)} if LOG_N == 20 and WINDOW_BITS == 16 else None}
-        if not args.no_cpu_baseline and world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as O  # the checker, here only as the timed CPU baseline
-            ns = min(n, 1 << 20)  # one whole 2^20 MSM: ~15 s of CPU work on one thread
-            host_pts = d_pts.to_numpy(shape=(n, 12))[:ns].copy()
-            tcpu, out = O.time_msm(CURVE, 1, host_pts, scalars[:ns])
-            if ns == n:  # and a free parity check: the CPU restatement's point equals the GPU's
-                assert (np.asarray(out).reshape(-1) == np.asarray(result).reshape(-1)).all(), "CPU and GPU MSM results differ"
-            cpu = {"value": round(ns / tcpu / 1e6, 5), "unit": "Mscalar/s", "cores": 1, "kind": "port",
-                   "sample": f"{'the same' if ns == n else 'first'} {ns} bases/scalars of the workload, arkworks-0.3 Pippenger restatement, "
-                             f"{tcpu:.1f} s on 1 thread (the reference ships arkworks without `parallel`)"}
-
-    if rank == 0:
-        total = world * n * args.steps
-        line = {
-            "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(total / dt / 1e6, 3), "unit": "Mscalar/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
-                       "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS,
-                       "precomputed_base_multiples": True, "bases_hbm_bytes": bases.device_bytes(),
-                       "sharding": "contiguous base/scalar ranges, all_gather of partial points" if world > 1 else "none"},
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+                    "int_mad": mads}
+        if not args.no_cpu_baseline and env.world == 1:
+            cpu = msm_cpu_baseline(inst, result, n)
+    line["roofline"], line["cpu_baseline"] = roofline, cpu
+    return line, inst
 
 
-def _device_index(local_rank):
-    """LOCAL_RANK, unless MANTA_BENCH_DEVICE pins every rank to one device (functional test of the
-    multi-process path on a 1-GPU box)."""
-    return int(os.environ.get("MANTA_BENCH_DEVICE", local_rank))
+def msm_cpu_baseline(inst, result, n):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker, here only as the timed CPU baseline
+    host_pts = inst.d_pts.to_numpy(shape=(n, 12))
+    O.set_threads(1)
+    t1, out = O.time_msm(CURVE, 1, host_pts, inst.scalars)  # one whole 2^20 MSM: ~12 s on one thread
+    assert (np.asarray(out).reshape(-1) == np.asarray(result).reshape(-1)).all(), "CPU and GPU MSM results differ"
+    cores = O.set_threads(0)
+    ta, out = O.time_msm(CURVE, 1, host_pts, inst.scalars)
+    O.set_threads(1)
+    assert (np.asarray(out).reshape(-1) == np.asarray(result).reshape(-1)).all()
+    return {"value": round(n / t1 / 1e6, 5), "unit": "Mscalar/s", "cores": 1, "kind": "port",
+            "sample": f"the same {n} bases/scalars as the GPU workload, arkworks-0.3 Pippenger restatement (window rule, "
+                      f"bucket method, Horner), {t1:.1f} s on 1 thread (the reference ships arkworks without `parallel`); "
+                      "result point equals the GPU's",
+            "all_cores": {"value": round(n / ta / 1e6, 5), "cores": cores, "seconds": round(ta, 2),
+                          "how": "one task per Pippenger window, the decomposition of arkworks' `parallel` feature (17 windows at "
+                                 "2^20: at most 17-way)"},
+            **host_info()}
 
 
-def prove_main(args):
-    """Whole proofs of a shape-exact synthetic manta-pay circuit (BN254, the curve manta-pay uses).
-    A step = one `Groth16::prove` call: H2D of z, witness map (3 SpMV, 7 NTT), 5 MSMs, host assembly, 128 proof
-    bytes out. `--threads` host threads share ONE ProvingContext (the reference's signer does the same,
-    manta-pay/src/simulation/mod.rs:75-79); replicas across GPUs need no collective."""
-    import threading
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus
-    import torch
-    import torch.distributed as dist
-    from manta_rs_amd import api, synth, keygen
-    dev = _device_index(local_rank)
-    backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(dev)
-    api.init(dev)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    curve = synth.BN254
-    p = synth.FR_MODULUS[curve]
-    t0 = time.perf_counter()
-    c = synth.make_shape(curve, args.shape)
-    rng = synth.XorShift(0x4D414E5441_0002)
-    toxic = [rng.field(p) for _ in range(5)]
-    pk = keygen.generate(c, toxic)
-    ctx = api.ProvingContext(curve, pk)
-    r1cs = api.R1CS.from_circuit(c)
-    ctx.set_r1cs(r1cs)
-    setup_s = time.perf_counter() - t0
-    nrs = max(args.steps, args.warmup, 1)
-    rs = synth.to_mont([rng.field(p) for _ in range(2 * nrs)], p, 4).reshape(nrs, 2, 4)
-    first = api.Groth16.prove_with_randomness(ctx, c.z, rs[0][0], rs[0][1])
+def strong_scaling(args, env):
+    """1/2/4/8-GPU times for a FIXED n = 2^20 and a fixed n = 35 174 (the PrivateTransfer witness MSM),
+    split into N contiguous ranges -- expected near-linear at 2^20, flat or worse at 35 k (launch-latency-bound)."""
+    out = {}
+    for name, n_total, c in (("n_2^20", 1 << 20, 16), ("n_35174", 35174, 8)):
+        inst = MsmInstance(env, n_total, c, seed=0x5354524F)
+        got = inst.run(1, 1)
+        assert (got == inst.expected()).all(), "strong-scaling MSM does not match the closed form"
+        steps = max(5, min(args.steps, 20))
+        dt1, _ = inst.timed(steps, 1)
+        dt3, _ = inst.timed(steps, DEPTH)
+        out[name] = {"n_total": n_total, "n_per_gpu": inst.n, "window_bits": c,
+                     "ms_per_msm_latency_mode": round(dt1 / steps * 1e3, 4), "ms_per_msm_pipelined": round(dt3 / steps * 1e3, 4),
+                     "Mscalar_s_pipelined": round(n_total * steps / dt3 / 1e6, 3)}
+        inst.bases.close()
+    return out
 
-    K = max(1, args.batch)
-    # the assignment lives in page-locked memory (mg_host_alloc), as a host integration would keep it: the
-    # library then DMAs it from there instead of staging a copy first
-    z1_pin = api.PinnedArray.like(c.z)
-    z1 = z1_pin.array
-    zK_pin = api.PinnedArray.like(np.stack([c.z] * K)) if K > 1 else None
-    zK = zK_pin.array if K > 1 else None
 
-    def run(steps, threads):
+# ---------------------------------------------------------------------------------------------------- proofs
+class ProveSetup:
+    def __init__(self, shape):
+        from manta_rs_amd import api, synth, keygen
+        self.api, self.synth, self.shape = api, synth, shape
+        curve = self.curve = synth.BN254
+        p = self.p = synth.FR_MODULUS[curve]
+        t0 = time.perf_counter()
+        self.c = synth.make_shape(curve, shape)
+        self.rng = synth.XorShift(0x4D414E5441_0002)
+        toxic = [self.rng.field(p) for _ in range(5)]
+        self.pk = keygen.generate(self.c, toxic)
+        self.ctx = api.ProvingContext(curve, self.pk)
+        self.ctx.set_r1cs(api.R1CS.from_circuit(self.c))
+        self.setup_s = time.perf_counter() - t0
+        self.nrs = 64
+        self.rs = synth.to_mont([self.rng.field(p) for _ in range(2 * self.nrs)], p, 4).reshape(self.nrs, 2, 4)
+        # the assignment lives in page-locked memory (mg_host_alloc), as a host integration would keep it: the library
+        # then DMAs it from there instead of staging a copy first
+        self.z1_pin = api.PinnedArray.like(self.c.z)
+        self.zK = {}
+
+    def zk(self, K):
+        if K not in self.zK:
+            self.zK[K] = self.api.PinnedArray.like(np.stack([self.c.z] * K))
+        return self.zK[K].array
+
+    def run(self, steps, threads, K):
+        """`steps` proofs, `threads` host threads sharing ONE ProvingContext (the reference's signer does the same,
+        manta-pay/src/simulation/mod.rs:75-79), K proofs per call (K = 1: mg_groth16_prove)."""
+        api, rs, nrs, ctx = self.api, self.rs, self.nrs, self.ctx
+        z1 = self.z1_pin.array
+        zK = self.zk(K) if K > 1 else None
         idx = iter(range(0, steps, K))
         lock = threading.Lock()
         out = [None] * steps
@@ -274,77 +348,126 @@ def prove_main(args):
                     return
                 if K == 1:
                     out[i] = api.Groth16.prove_with_randomness(ctx, z1, rs[i % nrs][0], rs[i % nrs][1])
-                else:  # one pass of the GPU pipeline for proofs i .. i+K-1 (the last batch wraps around)
+                else:  # one pass of the GPU pipeline for proofs i .. i+K-1
                     sel = [(i + q) % nrs for q in range(K)]
                     got = api.Groth16.prove_batch(ctx, zK, rs[sel, 0], rs[sel, 1])
                     for q in range(min(K, steps - i)):
                         out[i + q] = got[q]
-        ts = [threading.Thread(target=worker) for _ in range(threads)]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+        if threads == 1:
+            worker()
+        else:
+            ts = [threading.Thread(target=worker) for _ in range(threads)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
         return out
 
-    def barrier():
-        api.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    def timed(self, env, steps, threads, K):
+        self.run(max(4 * K * threads, 8), threads, K)  # slots capture their graphs on the 3rd call
+        env.barrier()
+        t0 = time.perf_counter()
+        proofs = self.run(steps, threads, K)
+        env.barrier()
+        return env.max_over_ranks(time.perf_counter() - t0), proofs
 
-    run(args.warmup if K == 1 else max(args.warmup, 4 * K * args.threads), args.threads)  # slots capture their graphs on the 3rd call
-    # sequential latency (one proof at a time)
-    nlat = min(5, args.steps)
-    for i in range(4):  # whichever slot serves a lone caller has captured its graphs after three passes
-        api.Groth16.prove_with_randomness(ctx, z1, rs[i % nrs][0], rs[i % nrs][1])
-    t0 = time.perf_counter()
-    for i in range(nlat):
-        api.Groth16.prove_with_randomness(ctx, z1, rs[i][0], rs[i][1])
-    lat_ms = (time.perf_counter() - t0) / nlat * 1e3
-    barrier()
-    t0 = time.perf_counter()
-    proofs = run(args.steps, args.threads)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    assert proofs[0] == first
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_lib as O  # checker, here as the timed CPU baseline (and a free byte-parity check)
-        ncpu = min(8, args.steps, len(proofs))  # ~10 s of CPU work on one thread for PrivateTransfer
-        t1 = time.perf_counter()
-        want = [O.groth16_prove(c, pk, rs[i % nrs][0], rs[i % nrs][1], msm_algo=1) for i in range(ncpu)]
-        tcpu = time.perf_counter() - t1
-        for i in range(ncpu):
-            assert want[i] == proofs[i], "GPU proof bytes differ from the CPU restatement"
-        ok = O.groth16_verify(curve, pk, c.z[1:c.P], first)
-        assert ok == 1, "proof does not satisfy the pairing equation"
-        cpu = {"value": round(ncpu / tcpu, 4), "unit": "proofs/s", "cores": 1, "kind": "port",
-               "sample": f"{ncpu} proofs of the same circuit/key/witness (the timed run's first {ncpu} (r, s) pairs), "
-                         f"arkworks-0.3 algorithm restatement, {tcpu:.2f} s on 1 thread; bytes equal the GPU proofs; "
-                         "proof pairing-verified"}
-    if rank == 0:
-        D, V, P = synth.SHAPES[args.shape]
-        algo_bytes = 7 * 64 * D + 32 * V + 32 * D + 64 * (3 * V - P + D) + 128 * V
-        line = {"metric": f"Groth16 proofs/sec (manta-pay {args.shape} shape)", "value": round(world * args.steps / dt, 3),
-                "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                "config": {"workload": f"Groth16 prove, shape-exact synthetic {args.shape} circuit (D={D}, V={V}, P={P}), BN254",
-                           "host_threads": args.threads, "proofs_per_call": K, "assignment_memory": "page-locked (mg_host_alloc)", "sequential_latency_ms": round(lat_ms, 3),
-                           "setup_s": round(setup_s, 2)},
-                "roofline": {"bound": "hbm", "achieved": round(algo_bytes * args.steps / dt / 1e9, 3), "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": round(algo_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBPS, 6),
-                             "traffic": None, "algorithmic_bytes_per_proof": algo_bytes,
-                             "note": "whole-proof algorithmic bytes (SURVEY.md 8(d), SpMV term excluded); integer-multiply and latency bound"},
-                "cpu_baseline": cpu}
+
+def prove_cpu_baseline(ps, proofs, ncpu=8):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # checker, here as the timed CPU baseline (and a free byte-parity check)
+    c, pk, rs, nrs = ps.c, ps.pk, ps.rs, ps.nrs
+    O.set_threads(1)
+    t1 = time.perf_counter()
+    want = [O.groth16_prove(c, pk, rs[i % nrs][0], rs[i % nrs][1], msm_algo=1) for i in range(ncpu)]
+    t1 = time.perf_counter() - t1
+    for i in range(ncpu):
+        assert want[i] == proofs[i], "GPU proof bytes differ from the CPU restatement"
+    assert O.groth16_verify(ps.curve, pk, c.z[1:c.P], proofs[0]) == 1, "proof does not satisfy the pairing equation"
+    cores = O.set_threads(0)
+    ta = time.perf_counter()
+    again = [O.groth16_prove(c, pk, rs[i % nrs][0], rs[i % nrs][1], msm_algo=1) for i in range(ncpu)]
+    ta = time.perf_counter() - ta
+    O.set_threads(1)
+    assert again == want
+    return {"value": round(ncpu / t1, 4), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"{ncpu} proofs of the same circuit/key/witness (the timed run's first {ncpu} (r, s) pairs), arkworks-0.3 "
+                      f"algorithm restatement (7-FFT witness map, 5 Pippenger MSMs), {t1:.2f} s on 1 thread; bytes equal the GPU "
+                      "proofs; proof pairing-verified",
+            "all_cores": {"value": round(ncpu / ta, 4), "cores": cores, "seconds": round(ta, 2),
+                          "how": "arkworks-`parallel` decomposition: one task per MSM window, chunk-parallel FFT stages and element loops"},
+            **host_info()}
+
+
+def prove_bench(args, env, shape="private_transfer", full=True):
+    """The proofs/s half of the metric. full: sequential / 2 threads / batch 32 (N = 1); else only the batched stream."""
+    ps = ProveSetup(shape)
+    D, V, P = ps.synth.SHAPES[shape]
+    first = ps.api.Groth16.prove_with_randomness(ps.ctx, ps.c.z, ps.rs[0][0], ps.rs[0][1])
+    res = {"metric": f"Groth16 proofs/sec (manta-pay {shape} shape)", "unit": "proofs/s", "dtype": "u32", "data": "synthetic",
+           "workload": f"Groth16 prove, shape-exact synthetic {shape} circuit (D={D}, V={V}, P={P}), BN254, valid key, "
+                       "assignment in page-locked memory; a step = one proof incl. H2D of z and the 128 proof bytes out",
+           "setup_s": round(ps.setup_s, 2)}
+    proofs = None
+    if full:
+        n1 = max(20, min(100, args.steps * 5))
+        dt, proofs = ps.timed(env, n1, 1, 1)
+        assert proofs[0] == first
+        res["sequential"] = {"proofs_per_s": round(env.world * n1 / dt, 2), "ms_per_proof": round(dt / n1 * 1e3, 4), "host_threads": 1, "proofs_per_call": 1}
+        n2 = 3 * n1
+        dt, _ = ps.timed(env, n2, 2, 1)
+        res["two_threads"] = {"proofs_per_s": round(env.world * n2 / dt, 2), "host_threads": 2, "proofs_per_call": 1}
+    K = 32
+    nb = 256 * (2 if full else 1)  # configs[4]: batches of 256 proofs streamed through per-GPU pipelines
+    dt, pb = ps.timed(env, nb, 2, K)
+    assert pb[0] == first
+    res["batched"] = {"proofs_per_s": round(env.world * nb / dt, 2), "host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,
+                      "ms_per_proof": round(dt / nb * 1e3, 4)}
+    res["value"] = res["batched"]["proofs_per_s"]
+    res["n_gpus"] = env.world
+    res["scaling"] = "weak (replicas: every GPU proves its own stream, no collective)"
+    algo_bytes = 7 * 64 * D + 32 * V + 32 * D + 64 * (3 * V - P + D) + 128 * V
+    res["roofline"] = {"bound": "hbm", "achieved": round(algo_bytes * res["value"] / 1e9, 3), "peak": HBM_PEAK_GBPS * env.world, "unit": "GB/s",
+                       "frac": round(algo_bytes * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6), "traffic": None,
+                       "algorithmic_bytes_per_proof": algo_bytes,
+                       "note": "whole-proof algorithmic bytes (SURVEY.md 8(d), SpMV term excluded); integer-multiply and latency bound"}
+    if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = prove_cpu_baseline(ps, proofs if proofs else pb)
+        b = res["cpu_baseline"]
+        res["speedup_vs_cpu_1_thread"] = {k: round(res[k]["proofs_per_s"] / b["value"], 1) for k in ("sequential", "two_threads", "batched") if k in res}
+        res["speedup_vs_cpu_all_cores"] = {k: round(res[k]["proofs_per_s"] / b["all_cores"]["value"], 1) for k in ("sequential", "two_threads", "batched") if k in res}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="MSM headline only: skip plain-bases, strong-scaling and proofs legs")
+    ap.add_argument("--workload", choices=["both", "msm", "prove"], default="both",
+                    help="both (default) = the MSM line with the proofs half inside it; msm = configs[1] only; prove = a "
+                         "proofs/s line of its own for --shape")
+    ap.add_argument("--shape", default="private_transfer", choices=["to_private", "to_public", "private_transfer"])
+    args = ap.parse_args()
+    env = Env(args)
+    if args.workload == "prove":
+        res = prove_bench(args, env, args.shape, full=env.world == 1)
+        if env.rank == 0:
+            line = {"metric": res["metric"], "value": res["value"], "unit": "proofs/s", "n_gpus": env.world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": res["batched"]["ms_per_proof"], "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": res["workload"]},
+                    "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"), "proofs": res}
+            print(json.dumps(line), flush=True)
+        env.close()
+        return
+    line, inst = msm_bench(args, env)
+    if args.workload == "both" and not args.quick:
+        if env.world > 1:
+            line["strong_scaling"] = strong_scaling(args, env)
+        inst.bases.close()
+        line["proofs"] = prove_bench(args, env, "private_transfer", full=env.world == 1)
+    if env.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    env.close()
 
 
 if __name__ == "__main__":

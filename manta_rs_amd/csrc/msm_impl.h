@@ -186,6 +186,40 @@ __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__
     }
 }
 
+// Calibration twin of accumulate_chunks (tools/gather_calibration.py, MANTA_ACC_GATHER_ONLY=1; never on the product
+// path): the same lanes walk the same sorted (key, value) stream and gather the same base records, but instead of
+// the mixed addition every loaded word is XORed into a register. Its duration is the memory side of the accumulate
+// kernel alone -- how long the random 128 B gathers from the window tables take when no field arithmetic competes --
+// and its PMC FETCH_SIZE calibrates the counter for this access pattern.
+template <class F>
+__global__ __launch_bounds__(256) void gather_only_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
+                                                          u32 astride, u32 *__restrict__ pkeys, u32 T,
+                                                          const u32 *__restrict__ count) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    if (count) M = *count;
+    const size_t begin = (size_t)t * L;
+    size_t end = begin + L;
+    if (end > M) end = M;
+    u32 x = 0;
+    for (size_t j = begin; j < end; ++j) {
+        const u32 k = keys[j];
+        if (k == invalid) break;
+        const u32 v = vals[j];
+        const uint4 *p = reinterpret_cast<const uint4 *>(bases + (size_t)(v & 0x7fffffffu) * astride);
+#pragma unroll
+        for (int q = 0; q < (int)(Affine<F>::WORDS + 3) / 4; ++q) {
+            const uint4 w = p[q];
+            x ^= w.x ^ w.y ^ w.z ^ w.w;
+        }
+        x ^= k;
+    }
+    pkeys[2 * t] = invalid; // no partials: the later stages see an empty list
+    pkeys[2 * t + 1] = invalid;
+    if (x == 0x9e3779b9u) pkeys[2 * t] = invalid - 1; // keep the loads alive
+}
+
 // --------------------------------------------------------------------------------------------
 // K7b: merge of partials. The partial array is a key-sorted sequence of (key, point) entries, two per
 // producer (head run, tail run; a producer whose whole range was one run emits (key, sum), (key, inf)).
@@ -1016,6 +1050,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
         ws->timed = kernel_timing() && !ws->capturing;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
+        static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration runs only (wrong results)
+        if (gather_only)
+            hipLaunchKernelGGL((gather_only_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+                               ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->pkeys[0].as<u32>(), T,
+                               (const u32 *)d_count);
+        else
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                            ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                            ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count);

@@ -23,6 +23,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define API __attribute__((visibility("default")))
 
@@ -327,6 +330,7 @@ API int mo_point_deserialize(int curve, int group, int compressed, const unsigne
  * ark-ec 0.3.0 msm/variable_base.rs VariableBaseMSM::multi_scalar_mul, restated from SURVEY.md App. B.2.
  * Called 4x over G1 and 1x over G2 per proof by ark-groth16's create_proof (reached from
  * manta-crypto/src/arkworks/groth16.rs:597). Single-threaded like the reference. */
+static int g_threads = 1; /* mo_set_threads: 1 = what the reference ships; > 1 = arkworks-`parallel`-style decomposition */
 static unsigned ark_log2(size_t x) { /* ark_std::log2: ceil(log2 x) */
     if (x <= 1) return 0;
     unsigned l = 0;
@@ -349,11 +353,14 @@ static void msm_arkworks(const curve_t *C, const u64 *bases, const u64 *scalars,
     const unsigned c = n < 32 ? 3 : (ark_log2(n) * 69 / 100) + 2;
     const unsigned num_bits = (unsigned)C->Fr->bits;
     const size_t nb = ((size_t)1 << c) - 1;
-    u64 *buckets = (u64 *)malloc(8 * (size_t)PJ * nb);
     unsigned nwin = (num_bits + c - 1) / c;
     u64 *wsums = (u64 *)malloc(8 * (size_t)PJ * nwin);
-    unsigned wi = 0;
-    for (unsigned w_start = 0; w_start < num_bits; w_start += c, ++wi) {
+    /* g_threads > 1: one task per window, exactly the decomposition of arkworks' `parallel` feature
+     * (`cfg_into_iter!(window_starts)` in variable_base.rs); g_threads == 1: the loop the reference ships (F3) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1)
+    for (unsigned wi = 0; wi < nwin; ++wi) {
+        const unsigned w_start = wi * c;
+        u64 *buckets = (u64 *)malloc(8 * (size_t)PJ * nb);
         u64 res[3 * MO_MAXE];
         jac_set_inf(C, res);
         for (size_t b = 0; b < nb; ++b) jac_set_inf(C, buckets + b * PJ);
@@ -374,6 +381,7 @@ static void msm_arkworks(const curve_t *C, const u64 *bases, const u64 *scalars,
             jac_add(C, res, res, running);
         }
         jac_copy(C, wsums + (size_t)wi * PJ, res);
+        free(buckets);
     }
     u64 total[3 * MO_MAXE];
     jac_set_inf(C, total);
@@ -382,7 +390,6 @@ static void msm_arkworks(const curve_t *C, const u64 *bases, const u64 *scalars,
         for (unsigned k = 0; k < c; ++k) jac_double(C, total, total);
     }
     jac_add(C, outJ, total, wsums);
-    free(buckets);
     free(wsums);
 }
 static void msm_naive(const curve_t *C, const u64 *bases, const u64 *scalars, size_t n, u64 *outJ) {
@@ -441,6 +448,31 @@ static void ntt_core(const fp_t *F, u64 *a, unsigned log_n, const u64 *root) {
         u64 wm[4];
         fp_copy(F, wm, root);
         for (unsigned k = s; k < log_n; ++k) fp_sqr(F, wm, wm); /* root^(n/m) */
+        if (g_threads > 1 && n >= 4096) { /* chunk-parallel butterflies (ark-poly's parallel FFT splits likewise) */
+            const size_t CH = 2048, total = n / 2, nch = (total + CH - 1) / CH;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+            for (size_t ch = 0; ch < nch; ++ch) {
+                size_t t0 = ch * CH, t1 = t0 + CH < total ? t0 + CH : total;
+                while (t0 < t1) {
+                    const size_t blk = t0 / half, j0 = t0 % half;
+                    size_t j1 = half;
+                    if (blk * half + j1 > t1) j1 = t1 - blk * half;
+                    u64 w[4], e[4] = {(u64)j0, 0, 0, 0};
+                    fp_pow(F, w, wm, e, 4);
+                    const size_t k = blk * m;
+                    for (size_t j = j0; j < j1; ++j) {
+                        u64 t[4], u[4];
+                        fp_mul(F, t, w, a + 4 * (k + j + half));
+                        fp_copy(F, u, a + 4 * (k + j));
+                        fp_add(F, a + 4 * (k + j), u, t);
+                        fp_sub(F, a + 4 * (k + j + half), u, t);
+                        fp_mul(F, w, w, wm);
+                    }
+                    t0 = blk * half + j1;
+                }
+            }
+            continue;
+        }
         for (size_t k = 0; k < n; k += m) {
             u64 w[4];
             fp_set_one(F, w);
@@ -525,6 +557,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     if ((int)lg > FR_TWO_ADICITY[curve]) return -1;
     const size_t D = (size_t)1 << lg;
     u64 *a = (u64 *)calloc(D, 32), *b = (u64 *)calloc(D, 32), *c = (u64 *)calloc(D, 32);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < m; ++i) {
         csr_row_dot(F, A, i, z, a + 4 * i);
         csr_row_dot(F, B, i, z, b + 4 * i);
@@ -535,6 +568,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     mo_ntt(curve, b, lg, 1, 0);
     mo_ntt(curve, a, lg, 0, 1);
     mo_ntt(curve, b, lg, 0, 1);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) fp_mul(F, a + 4 * i, a + 4 * i, b + 4 * i);
     mo_ntt(curve, c, lg, 1, 0);
     mo_ntt(curve, c, lg, 0, 1);
@@ -544,6 +578,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     for (unsigned k = 0; k < lg; ++k) fp_sqr(F, gd, gd);
     fp_sub(F, gd, gd, F->one);
     fp_inv(F, zi, gd);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) {
         fp_sub(F, a + 4 * i, a + 4 * i, c + 4 * i);
         fp_mul(F, a + 4 * i, a + 4 * i, zi);
@@ -696,7 +731,9 @@ API int mo_groth16_prove(int curve, const mo_pk *pk, const mo_csr *A, const mo_c
     if (h_out_opt) memcpy(h_out_opt, h, D * 32);
     /* into_repr */
     u64 *zc = (u64 *)malloc(V * 32), *hc = (u64 *)malloc(D * 32);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < V; ++i) fp_to_canonical(F, zc + 4 * i, z + 4 * i);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) fp_to_canonical(F, hc + 4 * i, h + 4 * i);
     void (*msm)(const curve_t *, const u64 *, const u64 *, size_t, u64 *) = msm_algo ? msm_arkworks : msm_naive;
     u64 h_acc[3 * MO_MAXE], l_acc[3 * MO_MAXE], g_a[3 * MO_MAXE], g1_b[3 * MO_MAXE], g2_b[3 * MO_MAXE],
@@ -823,6 +860,26 @@ static double now_s(void) {
     struct timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+/* threads for the timed baselines: 1 (default) = the single-threaded arkworks the reference ships;
+ * n > 1 = the decomposition of arkworks' `parallel` feature (one task per MSM window, chunk-parallel FFT stages and
+ * element loops) on n threads; 0 = all hardware threads. Returns the thread count in effect. */
+API int mo_set_threads(int n) {
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_num_procs();
+    g_threads = n < 1 ? 1 : n;
+#else
+    (void)n;
+    g_threads = 1;
+#endif
+    return g_threads;
+}
+API int mo_hardware_threads(void) {
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
 }
 API double mo_time_msm(int curve, int group, const u64 *bases_aff, const u64 *scalars_canonical, size_t n,
                        u64 *out_aff) {

@@ -114,6 +114,16 @@ def msm(curve, group, bases, scalars, algo=1):
     return out
 
 
+def set_threads(n):
+    """1 = the single-threaded arkworks the reference ships; n > 1 = arkworks-`parallel`-style decomposition; 0 = all
+    hardware threads. Returns the count in effect. Only the timed baselines use more than one."""
+    return LIB.mo_set_threads(int(n))
+
+
+def hardware_threads():
+    return LIB.mo_hardware_threads()
+
+
 def time_msm(curve, group, bases, scalars):
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)

@@ -239,7 +239,7 @@ def test_python_mirror_rejects_short_buffers_and_tracks_the_circuit(gpu):
     curve = 0
     c1 = synth.make_circuit(curve, 300, 260, 4, seed=601)
     c2 = synth.make_circuit(curve, 300, 260, 4, seed=602)  # same m, V, P -- another circuit
-    assert not (c1.A.col == c2.A.col).all()
+    assert c1.A.col.shape != c2.A.col.shape or not (c1.A.col == c2.A.col).all()
     tox = H.toxic(curve, seed=19)
     pk1, pk2 = O.groth16_setup(c1, tox), O.groth16_setup(c2, tox)
     rs = H.rand_fr_mont(curve, 2, seed=93)

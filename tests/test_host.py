@@ -75,26 +75,33 @@ def test_small_synthetic_circuit_is_satisfied_and_deterministic():
 
 
 def test_msm_range_sharding_with_gloo_world2(tmp_path):
-    """N > 1 path of bench.py on CPU: each rank owns a contiguous range, partial points are all_gathered
-    (gloo here, RCCL on the GPUs) and summed with the product's host reduction."""
+    """N > 1 path on CPU through the PRODUCT's exchange (manta_rs_amd/distributed.py: all_gather of the ranks' partial
+    points -- gloo here, RCCL on the GPUs -- and the library's host sum). Without a GPU the per-rank partial MSM is
+    stood in for by the oracle; tests/test_gpu_multi.py runs the same two-rank layout through the GPU MSM."""
     script = tmp_path / "w.py"
     script.write_text(f'''
 import os, sys
 sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
 import numpy as np, torch, torch.distributed as dist
 import oracle_lib as O, helpers as H
-from manta_rs_amd import api, synth
+from manta_rs_amd import api, synth, distributed
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-n = 64
-pts = H.random_points(1, 1, n * world, seed=3)
-sc = synth.msm_scalars(1, n * world, "W", seed=4)
-part = O.msm(1, 1, pts[rank * n:(rank + 1) * n], sc[rank * n:(rank + 1) * n])   # stand-in for the GPU MSM
-t = torch.from_numpy(part.view(np.int64))
-outs = [torch.empty_like(t) for _ in range(world)]
-dist.all_gather(outs, t)
-total = api.points_sum(1, 1, torch.stack(outs).numpy().view(np.uint64))
-assert (total == O.msm(1, 1, pts, sc)).all()
+n = 129                                  # odd: the two ranges differ in length
+pts = H.random_points(1, 1, n, seed=3)
+sc = synth.msm_scalars(1, n, "W", seed=4)
+lo, hi = distributed.shard_range(n, rank, world)
+assert (lo, hi) == ((0, 64) if rank == 0 else (64, 129))
+part = O.msm(1, 1, pts[lo:hi], sc[lo:hi])   # stand-in for this rank's GPU MSM
+ex = distributed.PartialPointExchange(1, 1)
+allp = ex.all_gather(part)
+assert allp.shape == (world, 12) and (allp[rank] == part).all()
+for _ in range(3):                          # buffers are reused across steps
+    total = ex.sum(part)
+    assert (total == O.msm(1, 1, pts, sc)).all()
+# G2 points (192 B) through the same exchange
+p2 = H.random_points(0, 2, world, seed=5)
+assert (distributed.PartialPointExchange(0, 2).sum(p2[rank]) == O.g_sum(0, 2, p2)).all()
 dist.barrier()
 print("rank", rank, "ok")
 ''')
@@ -104,3 +111,14 @@ print("rank", rank, "ok")
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_shard_ranges_tile_the_index_space():
+    from manta_rs_amd import distributed
+    for n in (1, 7, 35174, 1 << 20):
+        for world in (1, 2, 3, 8):
+            if world > n:
+                continue
+            r = [distributed.shard_range(n, g, world) for g in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(r[g][1] == r[g + 1][0] for g in range(world - 1))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
