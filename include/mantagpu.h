@@ -130,6 +130,25 @@ int mg_fixed_base_mul(mg_curve_t curve, int group, const uint64_t *base_affine_m
 #define MG_EC_SUB_MIXED 4
 int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t *a_affine, const uint64_t *b, size_t n,
                       uint64_t *out_affine);
+/* Element-wise prime-field arithmetic on the GPU with the kernels' own device functions: the direct parity surface
+ * for ark-ff 0.3 Fp256 / Fp384 (`ark_ff::Fp256<..>::{add_assign, sub_assign, mul_assign, square, neg, inverse, from_repr,
+ * into_repr}`; re-exported manta-crypto/src/arkworks/mod.rs:25-35).
+ *   field: 0 BN254 Fr, 1 BN254 Fq, 2 BLS12-381 Fr, 3 BLS12-381 Fq;  elements = 4 / 4 / 4 / 6 u64 limbs, Montgomery
+ *          (MG_FIELD_FROM_CANONICAL takes, MG_FIELD_TO_CANONICAL returns, plain integers)
+ *   repr:  0 = the saturated 32-bit-limb Montgomery arithmetic of the NTT / SpMV kernels (ABI format);
+ *          1 = the reduced-radix lazily-reduced arithmetic inside the MSM kernels: a (b) is converted, lazy_a (lazy_b)
+ *              in 0..3 times p is added so that the operation runs on a non-canonical representative, and the result
+ *              comes back canonical. out[i] = a[i] op b[i]; b is ignored by the unary operations. */
+#define MG_FIELD_ADD 0
+#define MG_FIELD_SUB 1
+#define MG_FIELD_MUL 2
+#define MG_FIELD_SQR 3
+#define MG_FIELD_NEG 4
+#define MG_FIELD_FROM_CANONICAL 5
+#define MG_FIELD_TO_CANONICAL 6
+#define MG_FIELD_INV 7
+int mg_field_op(int field, int op, int repr, int lazy_a, int lazy_b, const uint64_t *a, const uint64_t *b, size_t n,
+                uint64_t *out);
 /* arkworks canonical serialisation of one affine point (compressed: 32/48/64/96 B) */
 int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine_mont, int compressed, uint8_t *out);
 

@@ -59,7 +59,7 @@ EXPORTS = [
     "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
-    "mg_ctx_num_shards",
+    "mg_ctx_num_shards", "mg_field_op",
 ]
 
 
@@ -292,6 +292,25 @@ def ec_elementwise(curve, group, op, a, b=None) -> np.ndarray:
     out = np.zeros_like(a)
     bb = _p(_u64(b)) if b is not None else None
     _chk(LIB.mg_ec_elementwise(curve, group, op, _p(a), bb, _sz(n), _p(out)), "mg_ec_elementwise")
+    return out
+
+
+FIELD_IDS = {"bn254_fr": 0, "bn254_fq": 1, "bls381_fr": 2, "bls381_fq": 3}
+FIELD_OPS = {"add": 0, "sub": 1, "mul": 2, "sqr": 3, "neg": 4, "from_canonical": 5, "to_canonical": 6, "inv": 7}
+
+
+def field_op(field, op, a, b=None, repr=0, lazy_a=0, lazy_b=0) -> np.ndarray:
+    """Element-wise field arithmetic on the GPU (`mg_field_op`): a, b = [n, limbs] uint64 Montgomery elements of
+    `field` ("bn254_fr" ...); repr 0 = the saturated Montgomery arithmetic, 1 = the MSM kernels' reduced-radix lazy
+    arithmetic on the representatives a + lazy_a p, b + lazy_b p."""
+    a = _u64(a)
+    nl = 6 if field == "bls381_fq" else 4
+    assert a.ndim == 2 and a.shape[1] == nl, a.shape
+    out = np.zeros_like(a)
+    bb = None if b is None else _u64(b)
+    assert bb is None or bb.shape == a.shape
+    _chk(LIB.mg_field_op(FIELD_IDS[field], FIELD_OPS[op], int(repr), int(lazy_a), int(lazy_b), _p(a), _p(bb), _sz(a.shape[0]),
+                         _p(out)), "mg_field_op")
     return out
 
 

@@ -332,6 +332,16 @@ MG_API int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affin
     MG_CATCH
 }
 
+namespace mg {
+int field_op(int field, int op, int repr, int lazy_a, int lazy_b, const u32 *a, const u32 *b, size_t n, u32 *out);
+}
+MG_API int mg_field_op(int field, int op, int repr, int lazy_a, int lazy_b, const uint64_t *a, const uint64_t *b, size_t n,
+                       uint64_t *out) {
+    MG_TRY
+    return field_op(field, op, repr, lazy_a, lazy_b, (const u32 *)a, (const u32 *)b, n, (u32 *)out);
+    MG_CATCH
+}
+
 // ---------------------------------------------------------------------------------------------- NTT
 MG_API int mg_ntt_device(mg_curve_t curve, uint64_t *d_data, unsigned log_n, int inverse, int coset) {
     MG_TRY
