@@ -65,7 +65,11 @@ def host_info():
         pass
     cargo = shutil.which("cargo")
     reg = os.path.isdir(os.path.expanduser("~/.cargo/registry"))
-    return {"cpu_model": model, "hardware_concurrency": os.cpu_count(),
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
+    return {"cpu_model": model, "hardware_concurrency": os.cpu_count(), "cpus_in_affinity_mask": usable,
             "cargo": {"cargo_on_path": cargo, "cargo_registry_present": reg,
                       "reference_timed": False,
                       "note": "no Rust toolchain / offline ark-* registry on this box: the CPU baseline is the C restatement of "
@@ -271,7 +275,7 @@ def msm_cpu_baseline(inst, result, n):
     O.set_threads(1)
     t1, out = O.time_msm(CURVE, 1, host_pts, inst.scalars)  # one whole 2^20 MSM: ~12 s on one thread
     assert (np.asarray(out).reshape(-1) == np.asarray(result).reshape(-1)).all(), "CPU and GPU MSM results differ"
-    cores = O.set_threads(0)
+    cores = O.set_threads(O.usable_cpus())
     ta, out = O.time_msm(CURVE, 1, host_pts, inst.scalars)
     O.set_threads(1)
     assert (np.asarray(out).reshape(-1) == np.asarray(result).reshape(-1)).all()
@@ -381,7 +385,7 @@ def prove_cpu_baseline(ps, proofs, ncpu=8):
     for i in range(ncpu):
         assert want[i] == proofs[i], "GPU proof bytes differ from the CPU restatement"
     assert O.groth16_verify(ps.curve, pk, c.z[1:c.P], proofs[0]) == 1, "proof does not satisfy the pairing equation"
-    cores = O.set_threads(0)
+    cores = O.set_threads(O.usable_cpus())
     ta = time.perf_counter()
     again = [O.groth16_prove(c, pk, rs[i % nrs][0], rs[i % nrs][1], msm_algo=1) for i in range(ncpu)]
     ta = time.perf_counter() - ta

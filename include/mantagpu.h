@@ -236,6 +236,39 @@ uint64_t mg_ctx_num_inputs(const mg_ctx *ctx);    /* P */
 int mg_ctx_num_shards(const mg_ctx *ctx);
 void mg_ctx_destroy(mg_ctx *ctx);
 
+/* ---- verification: replaces `Groth16::verify` (manta-crypto/src/arkworks/groth16.rs:603-609 -> ark-groth16 0.3
+ *      verify_with_processed_vk) and `VerifyingContext` with its codec (groth16.rs:305-539) -------------------------- */
+typedef struct mg_vk mg_vk; /* device-resident PreparedVerifyingKey */
+/* `VerifyingContext::new(&vk)` = ArkGroth16::process_vk (groth16.rs:323-327): from the key's five components (affine
+ * Montgomery; gamma_abc_g1 = n_inputs points incl. the one for the constant input) everything the prepared key holds is
+ * computed on the GPU -- the G2Prepared line coefficients of -gamma_g2 and -delta_g2 and e(alpha_g1, beta_g2) with
+ * arkworks' final exponentiation. */
+int mg_vk_create(mg_curve_t curve, const uint64_t *alpha_g1, const uint64_t *beta_g2, const uint64_t *gamma_g2,
+                 const uint64_t *delta_g2, const uint64_t *gamma_abc_g1, uint64_t n_inputs, mg_vk **out);
+/* `impl Decode for VerifyingContext` (groth16.rs:498-517): the wire format of manta-parameters' verifying-key files
+ * (vk compressed | e(alpha, beta) | two G2Prepared). Checked like `CanonicalDeserialize::deserialize`: canonical field
+ * encodings, points on the curve and in the prime-order subgroup, no trailing bytes. */
+int mg_vk_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_vk **out);
+/* `impl Encode for VerifyingContext` (groth16.rs:519-533): byte-identical to the reference's file for the same key. */
+size_t mg_vk_encoded_size(const mg_vk *vk);
+int mg_vk_encode(const mg_vk *vk, uint8_t *out);
+int mg_vk_alpha_beta(const mg_vk *vk, uint8_t *out /* 12 Fq elements, 384 / 576 B */);
+uint64_t mg_vk_num_inputs(const mg_vk *vk);
+void mg_vk_destroy(mg_vk *vk);
+/* One proof. inputs = the n_inputs - 1 public inputs (Montgomery Fr, `Input = Vec<E::Fr>`), proof_points = a | b | c
+ * affine Montgomery (the in-memory ark_groth16::Proof<E>; mg_proof_decode gives it from the 128 / 192 proof bytes).
+ * *ok = 1 iff the proof verifies; the return value reports only operational failures. */
+int mg_groth16_verify(const mg_vk *vk, const uint64_t *inputs_mont, const uint64_t *proof_points, int *ok);
+/* k proofs against one key by random linear combination: rand128 = k x 2 u64 non-zero 128-bit coefficients from the
+ * caller's RNG. k + 3 Miller loops (one GPU lane each), two small MSMs and one final exponentiation. *ok = 1 iff ALL
+ * k proofs verify (up to the 2^-128 soundness error of the combination); on 0 fall back to mg_groth16_verify to find
+ * the offender. */
+int mg_groth16_verify_batch(const mg_vk *vk, uint64_t k, const uint64_t *inputs_mont, const uint64_t *proof_points,
+                            const uint64_t *rand128, int *ok);
+/* `Proof::deserialize` (arkworks compressed a | b | c) -> a | b | c affine Montgomery limbs; rejects non-canonical
+ * encodings, points off the curve or outside the subgroup. */
+int mg_proof_decode(mg_curve_t curve, const uint8_t *proof_bytes, uint64_t *points_out);
+
 #ifdef __cplusplus
 }
 #endif

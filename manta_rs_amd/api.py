@@ -45,6 +45,8 @@ def _load():
     lib.mg_ctx_num_variables.restype = ctypes.c_uint64
     lib.mg_ctx_num_inputs.restype = ctypes.c_uint64
     lib.mg_last_accumulate_ms.restype = ctypes.c_float
+    lib.mg_vk_encoded_size.restype = ctypes.c_size_t
+    lib.mg_vk_num_inputs.restype = ctypes.c_uint64
     return lib
 
 
@@ -59,7 +61,8 @@ EXPORTS = [
     "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
     "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
-    "mg_ctx_num_shards", "mg_field_op",
+    "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
+    "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_proof_decode",
 ]
 
 
@@ -559,3 +562,94 @@ class Groth16:
         _chk(LIB.mg_groth16_prove_batch(context.handle, ctypes.c_uint64(k), _p(zs), _p(rs), _p(ss), out),
              "mg_groth16_prove_batch")
         return [out.raw[i * n:(i + 1) * n] for i in range(k)]
+
+
+def proof_decode(curve, proof_bytes) -> np.ndarray:
+    """Mirror of `Proof::deserialize`: arkworks compressed a | b | c -> affine Montgomery limbs (a | b | c), checked."""
+    out = np.zeros(2 * affine_limbs(curve, 1) + affine_limbs(curve, 2), dtype=np.uint64)
+    _chk(LIB.mg_proof_decode(curve, bytes(proof_bytes), _p(out)), "mg_proof_decode")
+    return out
+
+
+class VerifyingContext:
+    """Mirror of groth16::VerifyingContext<E> (manta-crypto/src/arkworks/groth16.rs:305-539): the prepared verifying key,
+    resident on the GPU."""
+
+    def __init__(self, curve, vk):
+        """`VerifyingContext::new(&vk)`: vk = object with alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1 (affine
+        Montgomery limb arrays) -- e.g. a ProvingKey."""
+        self.curve = curve
+        arrs = [_u64(getattr(vk, k)) for k in ("alpha_g1", "beta_g2", "gamma_g2", "delta_g2", "gamma_abc_g1")]
+        h = _vp()
+        _chk(LIB.mg_vk_create(curve, *[_p(a) for a in arrs], ctypes.c_uint64(arrs[4].reshape(-1, affine_limbs(curve, 1)).shape[0]),
+                              ctypes.byref(h)), "mg_vk_create")
+        self.handle = h
+
+    @classmethod
+    def from_proving_context_key(cls, curve, pk):
+        return cls(curve, pk)
+
+    @classmethod
+    def decode(cls, curve, data: bytes):
+        self = cls.__new__(cls)
+        self.curve = curve
+        h = _vp()
+        _chk(LIB.mg_vk_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_vk_create_from_bytes")
+        self.handle = h
+        return self
+
+    def encode(self) -> bytes:
+        out = ctypes.create_string_buffer(LIB.mg_vk_encoded_size(self.handle))
+        _chk(LIB.mg_vk_encode(self.handle, out), "mg_vk_encode")
+        return out.raw
+
+    @property
+    def num_inputs(self):
+        return int(LIB.mg_vk_num_inputs(self.handle))
+
+    def alpha_g1_beta_g2(self) -> bytes:
+        out = ctypes.create_string_buffer(12 * FQ_LIMBS[self.curve] * 8)
+        _chk(LIB.mg_vk_alpha_beta(self.handle, out), "mg_vk_alpha_beta")
+        return out.raw
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            LIB.mg_vk_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _proof_points(curve, proof):
+    return proof_decode(curve, proof) if isinstance(proof, (bytes, bytearray)) else _u64(proof)
+
+
+def groth16_verify(context: VerifyingContext, inputs, proof) -> bool:
+    """Mirror of `Groth16::verify(context, input, proof)` (groth16.rs:603-609): inputs = [P - 1, 4] Montgomery Fr,
+    proof = the proof bytes (decoded and checked first) or its a | b | c limbs."""
+    inp = _u64(inputs).reshape(-1, 4)
+    if inp.shape[0] != context.num_inputs - 1:
+        raise ValueError(f"{inp.shape[0]} public inputs, the key takes {context.num_inputs - 1}")
+    ok = ctypes.c_int(0)
+    pts = _proof_points(context.curve, proof)
+    _chk(LIB.mg_groth16_verify(context.handle, _p(inp), _p(pts), ctypes.byref(ok)), "mg_groth16_verify")
+    return bool(ok.value)
+
+
+def groth16_verify_batch(context: VerifyingContext, inputs, proofs, rand128) -> bool:
+    """k proofs of one key in one pass (`mg_groth16_verify_batch`): inputs [k, P - 1, 4], proofs = k proof byte strings
+    (or [k, limbs] points), rand128 [k, 2] uint64 non-zero coefficients."""
+    k = len(proofs)
+    inp = _u64(inputs).reshape(k, -1, 4)
+    if inp.shape[1] != context.num_inputs - 1:
+        raise ValueError("public-input count does not match the key")
+    pts = np.stack([_proof_points(context.curve, p) for p in proofs])
+    rnd = _u64(rand128).reshape(k, 2)
+    ok = ctypes.c_int(0)
+    _chk(LIB.mg_groth16_verify_batch(context.handle, ctypes.c_uint64(k), _p(inp), _p(_u64(pts)), _p(rnd), ctypes.byref(ok)),
+         "mg_groth16_verify_batch")
+    return bool(ok.value)

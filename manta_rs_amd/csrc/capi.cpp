@@ -2,6 +2,7 @@
 #include "../../include/mantagpu.h"
 #include "engine.h"
 #include "prover.h"
+#include "verify.h"
 #include <cstring>
 #include <new>
 #include <vector>
@@ -455,4 +456,67 @@ MG_API void mg_ctx_destroy(mg_ctx *ctx) {
     if (!ctx) return;
     delete ctx->p;
     delete ctx;
+}
+
+// ---------------------------------------------------------------------------------------------- verification (f-2)
+struct mg_vk {
+    Verifier *v;
+};
+MG_API int mg_vk_create(mg_curve_t curve, const uint64_t *alpha_g1, const uint64_t *beta_g2, const uint64_t *gamma_g2,
+                        const uint64_t *delta_g2, const uint64_t *gamma_abc_g1, uint64_t n_inputs, mg_vk **out) {
+    MG_TRY
+    if (!out) return MG_ERROR_INVALID_ARGUMENT;
+    Verifier *v = nullptr;
+    int rc = verifier_create((int)curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, n_inputs, &v);
+    if (rc) return rc;
+    *out = new mg_vk{v};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_vk_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_vk **out) {
+    MG_TRY
+    if (!out) return MG_ERROR_INVALID_ARGUMENT;
+    Verifier *v = nullptr;
+    int rc = verifier_create_from_bytes((int)curve, bytes, len, &v);
+    if (rc) return rc;
+    *out = new mg_vk{v};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API void mg_vk_destroy(mg_vk *vk) {
+    if (!vk) return;
+    delete vk->v;
+    delete vk;
+}
+MG_API uint64_t mg_vk_num_inputs(const mg_vk *vk) { return vk ? vk->v->n_inputs() : 0; }
+MG_API size_t mg_vk_encoded_size(const mg_vk *vk) { return vk ? vk->v->encoded_size() : 0; }
+MG_API int mg_vk_encode(const mg_vk *vk, uint8_t *out) {
+    MG_TRY
+    if (!vk) return MG_ERROR_INVALID_ARGUMENT;
+    return vk->v->encode(out);
+    MG_CATCH
+}
+MG_API int mg_vk_alpha_beta(const mg_vk *vk, uint8_t *out) {
+    MG_TRY
+    if (!vk) return MG_ERROR_INVALID_ARGUMENT;
+    return vk->v->alpha_beta_bytes(out);
+    MG_CATCH
+}
+MG_API int mg_groth16_verify(const mg_vk *vk, const uint64_t *inputs_mont, const uint64_t *proof_points, int *ok) {
+    MG_TRY
+    if (!vk) return MG_ERROR_INVALID_ARGUMENT;
+    return vk->v->verify(inputs_mont, proof_points, ok);
+    MG_CATCH
+}
+MG_API int mg_groth16_verify_batch(const mg_vk *vk, uint64_t k, const uint64_t *inputs_mont, const uint64_t *proof_points,
+                                   const uint64_t *rand128, int *ok) {
+    MG_TRY
+    if (!vk) return MG_ERROR_INVALID_ARGUMENT;
+    return vk->v->verify_batch(k, inputs_mont, proof_points, rand128, ok);
+    MG_CATCH
+}
+MG_API int mg_proof_decode(mg_curve_t curve, const uint8_t *proof_bytes, uint64_t *points_out) {
+    MG_TRY
+    return proof_decode((int)curve, proof_bytes, points_out);
+    MG_CATCH
 }

@@ -1,0 +1,44 @@
+// Groth16 verification on the MI355X: pairing engine interface + the verifying-key object.
+#pragma once
+#include "../../include/mantagpu.h"
+#include "engine.h"
+
+namespace mg {
+
+class PairingEngine {
+  public:
+    virtual ~PairingEngine() {}
+    virtual int n_coeffs() const = 0;    // line-coefficient triples per prepared G2 point (91 BN254 / 68 BLS12-381)
+    virtual int coeff_words() const = 0; // u32 per triple
+    virtual int f12_words() const = 0;
+    virtual int fq_words() const = 0;
+    // G2Prepared::from for n affine points (host, Montgomery) -> device array n x n_coeffs x coeff_words (hipFree it)
+    virtual int prepare(const u32 *q_affine_host, size_t n, u32 **d_out) = 0;
+    // out = [final_exponentiation] ( prod_i MillerLoop(P_i, prepared_i) ): P host affine G1; d_coeffs[i] device pointers;
+    // skip[i] != 0 leaves pair i out (its G2 point was infinity)
+    virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const unsigned char *skip, size_t n,
+                                bool do_final_exp, u32 *out_f12_host) = 0;
+};
+PairingEngine *make_pairing_engine_bn254();
+PairingEngine *make_pairing_engine_bls381();
+PairingEngine *get_pairing_engine(int curve); // per (device, curve)
+
+class Verifier {
+  public:
+    virtual ~Verifier() {}
+    virtual u64 n_inputs() const = 0;
+    // ark-groth16 verify_proof: inputs = P - 1 public inputs (Montgomery Fr), proof = a | b | c affine Montgomery
+    virtual int verify(const u64 *inputs_mont, const u64 *proof_points, int *ok) = 0;
+    // k proofs at once by random linear combination; rand = k x 2 u64 (128-bit coefficients from the caller's RNG)
+    virtual int verify_batch(u64 k, const u64 *inputs_mont, const u64 *proof_points, const u64 *rand128, int *ok) = 0;
+    virtual size_t encoded_size() const = 0;
+    virtual int encode(uint8_t *out) const = 0;          // VerifyingContext wire format, groth16.rs:337-361
+    virtual int alpha_beta_bytes(uint8_t *out) const = 0; // 12 canonical Fq elements, arkworks order
+};
+int verifier_create(int curve, const u64 *alpha_g1, const u64 *beta_g2, const u64 *gamma_g2, const u64 *delta_g2,
+                    const u64 *gamma_abc_g1, u64 n_inputs, Verifier **out);
+int verifier_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Verifier **out);
+// Proof::deserialize (compressed a | b | c) -> affine Montgomery points; checks canonical encoding, curve and subgroup
+int proof_decode(int curve, const uint8_t *bytes, u64 *points_out);
+
+} // namespace mg

@@ -331,6 +331,13 @@ API int mo_point_deserialize(int curve, int group, int compressed, const unsigne
  * Called 4x over G1 and 1x over G2 per proof by ark-groth16's create_proof (reached from
  * manta-crypto/src/arkworks/groth16.rs:597). Single-threaded like the reference. */
 static int g_threads = 1; /* mo_set_threads: 1 = what the reference ships; > 1 = arkworks-`parallel`-style decomposition */
+/* threads for a parallel region with `units` independent pieces of work: never more threads than pieces (a barrier over
+ * idle threads is pure cost), never more than the configured count */
+static int nt(size_t units) {
+    size_t t = (size_t)g_threads;
+    if (units < t) t = units;
+    return t < 1 ? 1 : (int)t;
+}
 static unsigned ark_log2(size_t x) { /* ark_std::log2: ceil(log2 x) */
     if (x <= 1) return 0;
     unsigned l = 0;
@@ -357,7 +364,7 @@ static void msm_arkworks(const curve_t *C, const u64 *bases, const u64 *scalars,
     u64 *wsums = (u64 *)malloc(8 * (size_t)PJ * nwin);
     /* g_threads > 1: one task per window, exactly the decomposition of arkworks' `parallel` feature
      * (`cfg_into_iter!(window_starts)` in variable_base.rs); g_threads == 1: the loop the reference ships (F3) */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nt(nwin)) if (g_threads > 1)
     for (unsigned wi = 0; wi < nwin; ++wi) {
         const unsigned w_start = wi * c;
         u64 *buckets = (u64 *)malloc(8 * (size_t)PJ * nb);
@@ -450,7 +457,7 @@ static void ntt_core(const fp_t *F, u64 *a, unsigned log_n, const u64 *root) {
         for (unsigned k = s; k < log_n; ++k) fp_sqr(F, wm, wm); /* root^(n/m) */
         if (g_threads > 1 && n >= 4096) { /* chunk-parallel butterflies (ark-poly's parallel FFT splits likewise) */
             const size_t CH = 2048, total = n / 2, nch = (total + CH - 1) / CH;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(nt(nch))
             for (size_t ch = 0; ch < nch; ++ch) {
                 size_t t0 = ch * CH, t1 = t0 + CH < total ? t0 + CH : total;
                 while (t0 < t1) {
@@ -557,7 +564,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     if ((int)lg > FR_TWO_ADICITY[curve]) return -1;
     const size_t D = (size_t)1 << lg;
     u64 *a = (u64 *)calloc(D, 32), *b = (u64 *)calloc(D, 32), *c = (u64 *)calloc(D, 32);
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(static) num_threads(nt(m / 1024)) if (g_threads > 1)
     for (size_t i = 0; i < m; ++i) {
         csr_row_dot(F, A, i, z, a + 4 * i);
         csr_row_dot(F, B, i, z, b + 4 * i);
@@ -568,7 +575,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     mo_ntt(curve, b, lg, 1, 0);
     mo_ntt(curve, a, lg, 0, 1);
     mo_ntt(curve, b, lg, 0, 1);
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(static) num_threads(nt(D / 2048)) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) fp_mul(F, a + 4 * i, a + 4 * i, b + 4 * i);
     mo_ntt(curve, c, lg, 1, 0);
     mo_ntt(curve, c, lg, 0, 1);
@@ -578,7 +585,7 @@ API int mo_witness_map(int curve, const mo_csr *A, const mo_csr *B, const mo_csr
     for (unsigned k = 0; k < lg; ++k) fp_sqr(F, gd, gd);
     fp_sub(F, gd, gd, F->one);
     fp_inv(F, zi, gd);
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(static) num_threads(nt(D / 2048)) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) {
         fp_sub(F, a + 4 * i, a + 4 * i, c + 4 * i);
         fp_mul(F, a + 4 * i, a + 4 * i, zi);
@@ -731,9 +738,9 @@ API int mo_groth16_prove(int curve, const mo_pk *pk, const mo_csr *A, const mo_c
     if (h_out_opt) memcpy(h_out_opt, h, D * 32);
     /* into_repr */
     u64 *zc = (u64 *)malloc(V * 32), *hc = (u64 *)malloc(D * 32);
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(static) num_threads(nt(V / 2048)) if (g_threads > 1)
     for (size_t i = 0; i < V; ++i) fp_to_canonical(F, zc + 4 * i, z + 4 * i);
-#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#pragma omp parallel for schedule(static) num_threads(nt(D / 2048)) if (g_threads > 1)
     for (size_t i = 0; i < D; ++i) fp_to_canonical(F, hc + 4 * i, h + 4 * i);
     void (*msm)(const curve_t *, const u64 *, const u64 *, size_t, u64 *) = msm_algo ? msm_arkworks : msm_naive;
     u64 h_acc[3 * MO_MAXE], l_acc[3 * MO_MAXE], g_a[3 * MO_MAXE], g1_b[3 * MO_MAXE], g2_b[3 * MO_MAXE],
@@ -807,6 +814,19 @@ API void mo_pairing_bytes(int curve, const u64 *P_g1, const u64 *Q_g2, int ark_e
     pairing_full(E, &f, P_g1, Q_g2, ark_exp);
     u64 tw[12][MO_MAXL];
     fq12_to_tower(E, tw, &f);
+    int nb = fp_nbytes(E->F);
+    for (int i = 0; i < 12; ++i) fp_write(E->F, out_bytes + i * nb, tw[i]);
+}
+/* textbook pairing f^((q^12-1)/r) raised to a further small power `mult` (arkworks' final exponentiations compute a
+ * fixed multiple of the textbook exponent: BN Fuentes-Castaneda, BLS12 Hayashida et al.) */
+API void mo_pairing_bytes_pow(int curve, const u64 *P_g1, const u64 *Q_g2, u64 mult, unsigned char *out_bytes) {
+    const pairing_t *E = &PE[curve];
+    fq12_t f, g;
+    pairing_full(E, &f, P_g1, Q_g2, 0);
+    u64 e[1] = {mult};
+    fq12_pow(E, &g, &f, e, 1);
+    u64 tw[12][MO_MAXL];
+    fq12_to_tower(E, tw, &g);
     int nb = fp_nbytes(E->F);
     for (int i = 0; i < 12; ++i) fp_write(E->F, out_bytes + i * nb, tw[i]);
 }

@@ -20,7 +20,33 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _ORACLE_DIR])
 
 
+def usable_cpus():
+    """CPUs this process may actually run on: the affinity mask, cut down by a cgroup CPU quota if there is one, and to
+    one thread per physical core when SMT siblings are visible. The all-cores CPU baseline uses this many threads --
+    `hardware_concurrency` can be far more than a container is allowed to use, and oversubscribed OpenMP barriers
+    are catastrophically slow."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = len(sib.replace("-", ",").split(","))
+        if smt > 1 and n == (os.cpu_count() or n):
+            n = max(1, n // smt)
+    except OSError:
+        pass
+    return n
+
+
 def _load():
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle OpenMP threads sleep instead of spinning
     if not os.path.exists(_SO):
         build()
     lib = ctypes.CDLL(_SO)
@@ -239,4 +265,12 @@ def pairing_bytes(curve, P, Q, ark_exp=False):
     nb = 12 * (point_bytes(curve, 1, True))
     out = ctypes.create_string_buffer(nb)
     LIB.mo_pairing_bytes(curve, _p(np.ascontiguousarray(P)), _p(np.ascontiguousarray(Q)), int(ark_exp), out)
+    return out.raw
+
+
+def pairing_bytes_pow(curve, P, Q, mult):
+    """textbook pairing value raised to `mult`, arkworks Fq12 byte order"""
+    nb = 12 * (point_bytes(curve, 1, True))
+    out = ctypes.create_string_buffer(nb)
+    LIB.mo_pairing_bytes_pow(curve, _p(np.ascontiguousarray(P)), _p(np.ascontiguousarray(Q)), ctypes.c_uint64(mult), out)
     return out.raw
