@@ -128,6 +128,10 @@ int mg_fixed_base_mul(mg_curve_t curve, int group, const uint64_t *base_affine_m
 #define MG_EC_DOUBLE 2
 #define MG_EC_MUL 3
 #define MG_EC_SUB_MIXED 4
+/*   MG_EC_MUL_FIXED  out = [k]a    b = ONE canonical scalar (4 u64) for all points: `batch_mul_fixed_scalar`
+ *                                   (manta-trusted-setup/src/util.rs:440-445; Groth16 MPC `contribute`, mpc.rs:451-468);
+ *   MG_EC_MUL with per-point scalars is `batch_mul_pointwise` (util.rs:447-455; kzg `Accumulator::update`, kzg.rs:444-468) */
+#define MG_EC_MUL_FIXED 5
 int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t *a_affine, const uint64_t *b, size_t n,
                       uint64_t *out_affine);
 /* Element-wise prime-field arithmetic on the GPU with the kernels' own device functions: the direct parity surface
@@ -149,6 +153,10 @@ int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t *a_aff
 #define MG_FIELD_INV 7
 int mg_field_op(int field, int op, int repr, int lazy_a, int lazy_b, const uint64_t *a, const uint64_t *b, size_t n,
                 uint64_t *out);
+/* Radix-2 (inverse) NTT over a vector of 2^log_n GROUP elements, natural order in and out: ark-poly
+ * `Radix2EvaluationDomain::{fft, ifft}` applied to points -- how `mpc::initialize` turns the powers of tau into the
+ * Lagrange basis (manta-trusted-setup/src/groth16/mpc.rs:378-381). Host arrays of affine Montgomery points. */
+int mg_group_ntt(mg_curve_t curve, int group, const uint64_t *points_affine, unsigned log_n, int inverse, uint64_t *out_affine);
 /* arkworks canonical serialisation of one affine point (compressed: 32/48/64/96 B) */
 int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine_mont, int compressed, uint8_t *out);
 

@@ -62,7 +62,7 @@ EXPORTS = [
     "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
     "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
-    "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_proof_decode",
+    "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_proof_decode", "mg_group_ntt",
 ]
 
 
@@ -284,7 +284,18 @@ def fixed_base_mul(curve, group, base, d_scalars: DeviceBuffer, n) -> DeviceBuff
     return out
 
 
-EC_ADD_MIXED, EC_ADD, EC_DOUBLE, EC_MUL, EC_SUB_MIXED = range(5)
+EC_ADD_MIXED, EC_ADD, EC_DOUBLE, EC_MUL, EC_SUB_MIXED, EC_MUL_FIXED = range(6)
+
+
+def group_ntt(curve, group, points, inverse=False) -> np.ndarray:
+    """`Radix2EvaluationDomain::{fft, ifft}` over a vector of 2^k group elements (`mg_group_ntt`)."""
+    pts = _u64(points)
+    n = pts.shape[0]
+    lg = n.bit_length() - 1
+    assert 1 << lg == n and pts.shape[1] == affine_limbs(curve, group)
+    out = np.zeros_like(pts)
+    _chk(LIB.mg_group_ntt(curve, group, _p(pts), lg, int(bool(inverse)), _p(out)), "mg_group_ntt")
+    return out
 
 
 def ec_elementwise(curve, group, op, a, b=None) -> np.ndarray:

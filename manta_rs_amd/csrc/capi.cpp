@@ -322,6 +322,20 @@ MG_API int mg_ec_elementwise(mg_curve_t curve, int group, int op, const uint64_t
     return e->ec_elementwise(op, (const u32 *)a_affine, (const u32 *)b, n, (u32 *)out_affine);
     MG_CATCH
 }
+// Radix2EvaluationDomain::{fft, ifft} over group elements (manta-trusted-setup/src/groth16/mpc.rs:378-381)
+MG_API int mg_group_ntt(mg_curve_t curve, int group, const uint64_t *points_affine, unsigned log_n, int inverse,
+                        uint64_t *out_affine) {
+    MG_TRY
+    GroupEngine *e = get_engine((int)curve, group);
+    FrEngine *fr = get_ntt_engine((int)curve);
+    if (!e || !fr || !points_affine || !out_affine) return MG_ERROR_INVALID_ARGUMENT;
+    const u32 *tw = nullptr;
+    u64 ninv[4];
+    int rc = fr->domain_twiddles(log_n, inverse != 0, &tw, ninv);
+    if (rc) return rc;
+    return e->group_ntt((const u32 *)points_affine, log_n, tw, inverse ? (const u32 *)ninv : nullptr, (u32 *)out_affine);
+    MG_CATCH
+}
 MG_API int mg_point_serialize(mg_curve_t curve, int group, const uint64_t *affine, int compressed, uint8_t *out) {
     MG_TRY
     GroupEngine *e = get_engine((int)curve, group);

@@ -149,6 +149,10 @@ class GroupEngine {
     // element-wise group operations on host arrays of affine points (the primitive menu of
     // manta-benchmark/src/ecc.rs; op codes in mantagpu.h), run with the MSM kernels' device functions
     virtual int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) = 0;
+    // radix-2 (I)NTT over a vector of 2^lg group elements (host affine in/out, natural order); d_twiddles_mont = the Fr
+    // domain's omega^k table on the device, n_inv_canonical != nullptr scales by n^-1 (inverse transform)
+    virtual int group_ntt(const u32 *in_affine_host, unsigned lg, const u32 *d_twiddles_mont, const u32 *n_inv_canonical,
+                          u32 *out_affine_host) = 0;
     // sum of affine points (device) -> host point
     virtual int sum_affine(const u32 *d_pts, size_t n, HostPoint *out) = 0;
 

@@ -404,6 +404,15 @@ template <class FrC> class FrEngineT : public FrEngine {
         MG_HIP(hipGetLastError());
         return MG_OK;
     }
+    int domain_twiddles(unsigned log_n, bool inverse, const u32 **d_tw, u64 n_inv_canonical[4]) override {
+        Domain *d;
+        int rc = get_domain(log_n, &d);
+        if (rc) return rc;
+        *d_tw = inverse ? d->tw_inv : d->tw_fwd;
+        const HF ninv = HF::from_mont(HF::inv(from_u64((u64)1 << log_n)));
+        std::memcpy(n_inv_canonical, ninv.v, 32);
+        return MG_OK;
+    }
     void fr_mul(const u64 a[4], const u64 b[4], u64 out[4]) const override {
         HF x, y;
         std::memcpy(x.v, a, 32);

@@ -685,13 +685,118 @@ __global__ __launch_bounds__(256) void fixed_base_mul_kernel(const u32 *__restri
     acc.store(out_xyzz + i * XYZZ<F>::WORDS);
 }
 
+// Windowed fixed-base multiplication (key generation: every element of a Groth16 key is a multiple of a generator;
+// ark-groth16 generate_parameters uses FixedBaseMSM the same way). Table T[w][d-1] = d * 2^(8w) * B for 32 windows of 8
+// bits, d = 1..255 (8160 affine points, ~0.5 / 0.8 MB in G1: L2-resident); [k]B = at most 32 mixed additions, no doubling.
+template <class F>
+__global__ __launch_bounds__(256) void fixed_base_table_kernel(const u32 *__restrict__ base_aff, u32 *__restrict__ out_xyzz) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 32 * 255) return;
+    const u32 w = t / 255, d = t % 255 + 1;
+    const Affine<F> b = Affine<F>::load(base_aff);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 7; bit >= 0; --bit) { // d * B
+        acc = XYZZ<F>::dbl(acc);
+        if ((d >> bit) & 1) acc.madd(b, false);
+    }
+    for (u32 k = 0; k < 8 * w; ++k) acc = XYZZ<F>::dbl(acc); // * 2^(8w)
+    acc.store(out_xyzz + (size_t)t * XYZZ<F>::WORDS);
+}
+template <class F>
+__global__ __launch_bounds__(256) void fixed_base_mul_table_kernel(const u32 *__restrict__ table_aff, const u32 *__restrict__ scalars,
+                                                                   size_t n, u32 *__restrict__ out_xyzz) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int limb = 0; limb < 8; ++limb) {
+        const u32 s = scalars[i * 8 + limb];
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const u32 d = (s >> (8 * k)) & 255u;
+            if (d) acc.madd(Affine<F>::load(table_aff + ((size_t)(limb * 4 + k) * 255 + d - 1) * Affine<F>::WORDS), false);
+        }
+    }
+    acc.store(out_xyzz + i * XYZZ<F>::WORDS);
+}
+
+// Radix-2 NTT over GROUP elements (`Radix2EvaluationDomain::{fft, ifft}` applied to a vector of points:
+// manta-trusted-setup/src/groth16/mpc.rs:378-381 turns powers of tau into the Lagrange basis this way). One butterfly
+// per lane and stage on XYZZ points in HBM: t = [w] b (double-and-add, w canonical from the Fr twiddle table),
+// a' = a + t, b' = a - t. Input in bit-reversed order, output natural (decimation in time).
+template <class F, class FrC>
+__global__ __launch_bounds__(256) void group_ntt_stage_kernel(u32 *__restrict__ pts, const u32 *__restrict__ tw_mont, unsigned lg,
+                                                              unsigned s) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1u << (lg - 1))) return;
+    const u32 half = 1u << (s - 1), j = k & (half - 1), g = k >> (s - 1);
+    const size_t i0 = ((size_t)g << s) | j, i1 = i0 + half;
+    constexpr size_t XW = XYZZ<F>::WORDS;
+    XYZZ<F> a = XYZZ<F>::load(pts + i0 * XW);
+    const XYZZ<F> b = XYZZ<F>::load(pts + i1 * XW);
+    XYZZ<F> t = b;
+    if (s > 1) { // twiddle w_n^(j * n / 2^s); stage 1 has w = 1
+        const Fp<FrC> wc = Fp<FrC>::from_mont(Fp<FrC>::load(tw_mont + ((size_t)j << (lg - s)) * 8));
+        t = XYZZ<F>::inf();
+        for (int limb = 7; limb >= 0; --limb) {
+            u32 w = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w = (q == limb) ? wc.v[q] : w;
+            for (int bit = 31; bit >= 0; --bit) {
+                t = XYZZ<F>::dbl(t);
+                if ((w >> bit) & 1) t.add(b);
+            }
+        }
+    }
+    XYZZ<F> d = a;
+    a.add(t);
+    if (!t.is_inf()) {
+        t.y = b_neg(bv<XYZZ<F>::BY>(t.y)).v;
+        d.add(t);
+    }
+    a.store(pts + i0 * XW);
+    d.store(pts + i1 * XW);
+}
+// affine (arkworks format) -> XYZZ internal at the bit-reversed position; and XYZZ internal -> scaled by a scalar -> std XYZZ
+template <class F>
+__global__ __launch_bounds__(256) void group_ntt_load_kernel(const u32 *__restrict__ in_aff, unsigned lg, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << lg)) return;
+    typedef typename F::Std S;
+    const u32 j = lg ? (__brev(i) >> (32 - lg)) : 0;
+    const Affine<S> s = Affine<S>::load(in_aff + (size_t)j * Affine<S>::WORDS);
+    XYZZ<F> p = XYZZ<F>::inf();
+    if (!s.is_inf()) p = XYZZ<F>{F::from_std(s.x), F::from_std(s.y), F::one(), F::one()};
+    p.store(out + (size_t)i * XYZZ<F>::WORDS);
+}
+template <class F>
+__global__ __launch_bounds__(256) void group_scale_store_kernel(const u32 *__restrict__ pts, const u32 *__restrict__ scalar_canon,
+                                                                size_t n, u32 *__restrict__ out_xyzz_std) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef typename F::Std S;
+    XYZZ<F> p = XYZZ<F>::load(pts + i * XYZZ<F>::WORDS);
+    if (scalar_canon) { // ifft: times n^-1
+        const XYZZ<F> b = p;
+        p = XYZZ<F>::inf();
+        for (int limb = 7; limb >= 0; --limb) {
+            const u32 w = scalar_canon[limb];
+            for (int bit = 31; bit >= 0; --bit) {
+                p = XYZZ<F>::dbl(p);
+                if ((w >> bit) & 1) p.add(b);
+            }
+        }
+    }
+    p.store_std(out_xyzz_std + i * XYZZ<S>::WORDS);
+}
+
 // Element-wise group operations on arrays of affine points (arkworks format in, XYZZ in arkworks format out,
 // normalised by xyzz_to_affine_batch) computed with the MSM kernels' own device functions in their internal
 // field representation -- the primitive menu of manta-benchmark/src/ecc.rs:30-128 (mixed add :69-74, projective
 // add :78-83, scalar multiplication :87-101, batch normalisation :114-119) as a parity-test surface.
 //   op 0: P + Q via madd (projective += affine)      op 1: P + Q via the general add (projective += projective)
 //   op 2: 2P                                          op 3: [k]P, k = 4 x u64 canonical (double-and-add over madd)
-//   op 4: P - Q via madd with the negate flag
+//   op 4: P - Q via madd with the negate flag            op 5: [k]P with ONE scalar k for all points (`batch_mul_fixed_scalar`,
+//                                                              manta-trusted-setup/src/util.rs:440-445): uniform control flow
 template <class F>
 __global__ __launch_bounds__(256) void ec_elementwise_kernel(int op, const u32 *__restrict__ a, const u32 *__restrict__ b,
                                                              size_t n, u32 *__restrict__ out_xyzz_std) {
@@ -720,8 +825,9 @@ __global__ __launch_bounds__(256) void ec_elementwise_kernel(int op, const u32 *
         acc = XYZZ<F>::dbl(acc);
     } else {
         acc = XYZZ<F>::inf();
+        const size_t si = op == 5 ? 0 : i; // op 5: every lane reads the same scalar
         for (int limb = 7; limb >= 0; --limb) {
-            const u32 w = b[i * 8 + limb];
+            const u32 w = b[si * 8 + limb];
             for (int bit = 31; bit >= 0; --bit) {
                 acc = XYZZ<F>::dbl(acc);
                 if ((w >> bit) & 1) acc.madd(pa, false);
@@ -1226,13 +1332,34 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             return MG_ERR_OOM;
         }
         hipMemcpyAsync(d_base, base_affine_host, AW_IO * 4, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL((fixed_base_mul_kernel<FIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
         constexpr int KB = 16;
+        static const size_t table_min = [] {
+            const char *e = getenv("MANTA_FIXED_BASE_TABLE_MIN");
+            return (size_t)(e ? atol(e) : 16384);
+        }();
+        u32 *t_xyzz = nullptr, *t_aff = nullptr;
+        if (n >= table_min) { // many multiples of one base: 32 table additions each instead of ~380 group operations
+            constexpr size_t TN = 32 * 255;
+            if (hipMalloc((void **)&t_xyzz, TN * XW_IO * 4) == hipSuccess && hipMalloc((void **)&t_aff, TN * AW_IO * 4) == hipSuccess) {
+                hipLaunchKernelGGL((fixed_base_table_kernel<FIO>), dim3(cdiv(TN, 256)), dim3(256), 0, s, d_base, t_xyzz);
+                hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(TN, KB), 256)), dim3(256), 0, s, t_xyzz, TN, t_aff,
+                                   (u32)AW_IO);
+                hipLaunchKernelGGL((fixed_base_mul_table_kernel<FIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, t_aff, d_scalars, n, tmp);
+            } else {
+                (void)hipGetLastError();
+                if (t_xyzz) hipFree(t_xyzz);
+                t_xyzz = nullptr;
+            }
+        }
+        if (!t_xyzz)
+        hipLaunchKernelGGL((fixed_base_mul_kernel<FIO>), dim3(cdiv(n, 256)), dim3(256), 0, s, d_base, d_scalars, n, tmp);
         hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, s, tmp, n,
                            d_out_affine, (u32)AW_IO);
         e = hipStreamSynchronize(s);
         hipFree(d_base);
         hipFree(tmp);
+        if (t_xyzz) hipFree(t_xyzz);
+        if (t_aff) hipFree(t_aff);
         if (e != hipSuccess) {
             set_last_hip_error(e, "fixed_base_mul", __FILE__, __LINE__);
             return MG_ERR_HIP;
@@ -1241,8 +1368,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) override {
-        if (op < 0 || op > 4 || !a_host || !out_affine_host || n == 0 || (op != 2 && !b_host)) return MG_ERR_ARG;
-        const size_t ab = n * AW_IO * 4, bb = op == 3 ? n * 32 : ab;
+        if (op < 0 || op > 5 || !a_host || !out_affine_host || n == 0 || (op != 2 && !b_host)) return MG_ERR_ARG;
+        const size_t ab = n * AW_IO * 4, bb = op == 3 ? n * 32 : (op == 5 ? 32 : ab);
         u32 *da = nullptr, *db = nullptr, *tmp = nullptr, *dout = nullptr;
         hipError_t e = hipMalloc((void **)&da, ab);
         if (e == hipSuccess) e = hipMalloc((void **)&db, bb);
@@ -1263,6 +1390,37 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipFree(dout);
         if (e != hipSuccess) {
             set_last_hip_error(e, "ec_elementwise", __FILE__, __LINE__);
+            return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+
+    // NTT over group elements: host affine in, host affine out (natural order both); tw = the Fr domain's device twiddle
+    // table (omega^k, k < n/2, Montgomery), n_inv_canonical = n^-1 for the inverse transform (nullptr: forward)
+    int group_ntt(const u32 *in_affine_host, unsigned lg, const u32 *d_twiddles_mont, const u32 *n_inv_canonical,
+                  u32 *out_affine_host) override {
+        if (!in_affine_host || !out_affine_host || lg > 26 || (lg > 0 && !d_twiddles_mont)) return MG_ERR_ARG;
+        const size_t n = (size_t)1 << lg, ab = n * AW_IO * 4;
+        u32 *d_in = nullptr, *d_pts = nullptr, *d_std = nullptr, *d_out = nullptr, *d_sc = nullptr;
+        hipError_t e = hipMalloc((void **)&d_in, ab);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_pts, n * XW * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_std, n * XW_IO * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, ab);
+        if (e == hipSuccess && n_inv_canonical) e = hipMalloc((void **)&d_sc, 32);
+        if (e == hipSuccess) e = hipMemcpy(d_in, in_affine_host, ab, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_inv_canonical) e = hipMemcpy(d_sc, n_inv_canonical, 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((group_ntt_load_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, d_in, lg, d_pts);
+            for (unsigned s = 1; s <= lg; ++s)
+                hipLaunchKernelGGL((group_ntt_stage_kernel<F, FrC>), dim3(cdiv(n / 2, 256)), dim3(256), 0, 0, d_pts, d_twiddles_mont, lg, s);
+            hipLaunchKernelGGL((group_scale_store_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, d_pts, (const u32 *)d_sc, n, d_std);
+            constexpr int KB = 16;
+            hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, 0, d_std, n, d_out, (u32)AW_IO);
+            e = hipMemcpy(out_affine_host, d_out, ab, hipMemcpyDeviceToHost);
+        }
+        hipFree(d_in), hipFree(d_pts), hipFree(d_std), hipFree(d_out), hipFree(d_sc);
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "group_ntt", __FILE__, __LINE__);
             return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
         }
         return MG_OK;

@@ -32,6 +32,8 @@ class FrEngine {
     virtual int qap_quotient(u32 *d_a, u32 *d_b, u32 *d_c, unsigned log_n, hipStream_t s, u32 batch = 1) = 0;
     // a[i] = (a[i]*b[i] - c[i]) * (g^D - 1)^-1
     virtual int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) = 0;
+    // the domain's device twiddle table (omega^k or omega^-k, k < n/2, Montgomery) and n^-1 as a canonical integer
+    virtual int domain_twiddles(unsigned log_n, bool inverse, const u32 **d_tw, u64 n_inv_canonical[4]) = 0;
     // host-side Fr helpers (Montgomery in/out unless noted)
     virtual void fr_mul(const u64 a[4], const u64 b[4], u64 out[4]) const = 0;
     virtual void fr_to_canonical(const u64 a[4], u64 out[4]) const = 0;

@@ -528,6 +528,64 @@ API int mo_ntt(int curve, u64 *data, unsigned log_n, int inverse, int coset) {
     return 0;
 }
 
+/* Radix2EvaluationDomain::{fft, ifft} over GROUP elements -- what manta-trusted-setup/src/groth16/mpc.rs:378-381 applies
+ * to the powers of tau (`domain.ifft(&batch_into_projective(..))`). pts: 2^log_n affine points, natural order in and out. */
+API int mo_group_ntt(int curve, int group, u64 *pts, unsigned log_n, int inverse) {
+    const fp_t *F = &FR[curve];
+    const curve_t *C = get_curve(curve, group);
+    if ((int)log_n > FR_TWO_ADICITY[curve]) return 1;
+    const int PA = 2 * c_el(C), PJ = 3 * c_el(C);
+    const size_t n = (size_t)1 << log_n;
+    u64 w[4], wi[4];
+    fr_domain_root(curve, log_n, w);
+    if (inverse) {
+        fp_inv(F, wi, w);
+        fp_copy(F, w, wi);
+    }
+    u64 *J = (u64 *)malloc(8 * (size_t)PJ * n);
+    for (size_t i = 0; i < n; ++i) { /* bit reversal on the way in */
+        size_t j = 0;
+        for (unsigned b = 0; b < log_n; ++b) j |= ((i >> b) & 1) << (log_n - 1 - b);
+        jac_set_inf(C, J + i * PJ);
+        jac_add_mixed(C, J + i * PJ, J + i * PJ, pts + j * PA);
+    }
+    for (unsigned s = 1; s <= log_n; ++s) {
+        const size_t m = (size_t)1 << s, half = m >> 1;
+        u64 wm[4];
+        fp_copy(F, wm, w);
+        for (unsigned k = s; k < log_n; ++k) fp_sqr(F, wm, wm);
+        for (size_t k = 0; k < n; k += m) {
+            u64 tw[4];
+            fp_set_one(F, tw);
+            for (size_t j = 0; j < half; ++j) {
+                u64 twc[4], t[3 * MO_MAXE], u[3 * MO_MAXE], nt[3 * MO_MAXE];
+                fp_to_canonical(F, twc, tw);
+                jac_mul_jac(C, t, J + (k + j + half) * PJ, twc, 4);
+                jac_copy(C, u, J + (k + j) * PJ);
+                jac_add(C, J + (k + j) * PJ, u, t);
+                jac_neg(C, nt, t);
+                jac_add(C, J + (k + j + half) * PJ, u, nt);
+                fp_mul(F, tw, tw, wm);
+            }
+        }
+    }
+    u64 ninv[4], nn[4], nc[4];
+    fp_set_u64(F, nn, (u64)n);
+    fp_inv(F, ninv, nn);
+    fp_to_canonical(F, nc, ninv);
+    for (size_t i = 0; i < n; ++i) {
+        if (inverse) {
+            u64 t[3 * MO_MAXE];
+            jac_mul_jac(C, t, J + i * PJ, nc, 4);
+            jac_to_affine(C, pts + i * PA, t);
+        } else {
+            jac_to_affine(C, pts + i * PA, J + i * PJ);
+        }
+    }
+    free(J);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ R1CS / QAP witness map
  * ark-groth16 0.3.0 r1cs_to_qap.rs R1CStoQAP::witness_map; conventions
  * mirrored in-repo at manta-trusted-setup/src/groth16/mpc.rs:299-312,367-368. */

@@ -274,3 +274,13 @@ def pairing_bytes_pow(curve, P, Q, mult):
     out = ctypes.create_string_buffer(nb)
     LIB.mo_pairing_bytes_pow(curve, _p(np.ascontiguousarray(P)), _p(np.ascontiguousarray(Q)), ctypes.c_uint64(mult), out)
     return out.raw
+
+
+def group_ntt(curve, group, pts, inverse=False):
+    """Radix2EvaluationDomain fft / ifft over a vector of 2^k group elements (affine in / out)"""
+    pts = np.array(pts, dtype=np.uint64, copy=True)
+    n = pts.shape[0]
+    lg = n.bit_length() - 1
+    assert 1 << lg == n
+    assert LIB.mo_group_ntt(curve, group, _p(pts), lg, int(bool(inverse))) == 0
+    return pts
