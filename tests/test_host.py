@@ -122,3 +122,21 @@ def test_shard_ranges_tile_the_index_space():
             r = [distributed.shard_range(n, g, world) for g in range(world)]
             assert r[0][0] == 0 and r[-1][1] == n and all(r[g][1] == r[g + 1][0] for g in range(world - 1))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_rust_sys_crate_declares_exactly_the_header():
+    """rust/mantagpu-sys/src/lib.rs (source only: no Rust toolchain here) must bind every entry point of mantagpu.h
+    and nothing else, and mirror the three structs that cross the ABI field for field."""
+    hdr = open(os.path.join(ROOT, "include", "mantagpu.h")).read()
+    rs = open(os.path.join(ROOT, "rust", "mantagpu-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", hdr))
+    bound = set(re.findall(r"pub fn (mg_[a-z0-9_]+)\s*\(", rs))
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+    for struct, n_fields in (("mg_pk_view", 13), ("mg_csr", 4), ("mg_pk_out", 12)):
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rs, re.S).group(1)
+        assert len(re.findall(r"pub \w+:", body)) == n_fields, struct
+        end = hdr.index("} %s;" % struct)
+        cbody = hdr[hdr.rindex("typedef struct", 0, end):end].split("{", 1)[1]
+        cnames = re.findall(r"\*?(\w+)\s*[;,]", re.sub(r"/\*.*?\*/", "", cbody, flags=re.S))
+        rnames = re.findall(r"pub (\w+):", body)
+        assert rnames == cnames, (struct, rnames, cnames)
