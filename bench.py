@@ -262,9 +262,9 @@ def msm_bench(args, env):
                     "algorithmic_bytes_per_launch": algo,
                     "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); int_mad gives the bound that governs",
                     "int_mad": mads}
-        if not args.no_cpu_baseline and env.world == 1:
-            cpu = msm_cpu_baseline(inst, result, n)
     line["roofline"], line["cpu_baseline"] = roofline, cpu
+    # the CPU baseline runs LAST (main): OpenMP worker threads of the oracle must not share the host with the timed GPU legs
+    line["_cpu_todo"] = (inst, result, n) if (env.rank == 0 and not args.no_cpu_baseline and env.world == 1) else None
     return line, inst
 
 
@@ -432,12 +432,23 @@ def prove_bench(args, env, shape="private_transfer", full=True):
                        "frac": round(algo_bytes * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6), "traffic": None,
                        "algorithmic_bytes_per_proof": algo_bytes,
                        "note": "whole-proof algorithmic bytes (SURVEY.md 8(d), SpMV term excluded); integer-multiply and latency bound"}
-    if env.rank == 0 and env.world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = prove_cpu_baseline(ps, proofs if proofs else pb)
-        b = res["cpu_baseline"]
-        res["speedup_vs_cpu_1_thread"] = {k: round(res[k]["proofs_per_s"] / b["value"], 1) for k in ("sequential", "two_threads", "batched") if k in res}
-        res["speedup_vs_cpu_all_cores"] = {k: round(res[k]["proofs_per_s"] / b["all_cores"]["value"], 1) for k in ("sequential", "two_threads", "batched") if k in res}
+    res["_cpu_todo"] = (ps, proofs if proofs else pb) if (env.rank == 0 and env.world == 1 and not args.no_cpu_baseline) else None
     return res
+
+
+def finish_cpu_baselines(line):
+    """the timed CPU legs, after every GPU measurement of the run"""
+    todo = line.pop("_cpu_todo", None)
+    if todo:
+        line["cpu_baseline"] = msm_cpu_baseline(*todo)
+    res = line.get("proofs")
+    if res is not None:
+        todo = res.pop("_cpu_todo", None)
+        if todo:
+            b = res["cpu_baseline"] = prove_cpu_baseline(*todo)
+            ks = [k for k in ("sequential", "two_threads", "batched") if k in res]
+            res["speedup_vs_cpu_1_thread"] = {k: round(res[k]["proofs_per_s"] / b["value"], 1) for k in ks}
+            res["speedup_vs_cpu_all_cores"] = {k: round(res[k]["proofs_per_s"] / b["all_cores"]["value"], 1) for k in ks}
 
 
 def main():
@@ -455,6 +466,7 @@ def main():
     env = Env(args)
     if args.workload == "prove":
         res = prove_bench(args, env, args.shape, full=env.world == 1)
+        finish_cpu_baselines({"proofs": res})
         if env.rank == 0:
             line = {"metric": res["metric"], "value": res["value"], "unit": "proofs/s", "n_gpus": env.world, "steps": args.steps,
                     "warmup": args.warmup, "ms_per_step": res["batched"]["ms_per_proof"], "higher_is_better": True, "scaling": "weak",
@@ -467,8 +479,8 @@ def main():
     if args.workload == "both" and not args.quick:
         if env.world > 1:
             line["strong_scaling"] = strong_scaling(args, env)
-        inst.bases.close()
         line["proofs"] = prove_bench(args, env, "private_transfer", full=env.world == 1)
+    finish_cpu_baselines(line)
     if env.rank == 0:
         print(json.dumps(line), flush=True)
     env.close()

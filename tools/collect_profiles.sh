@@ -1,19 +1,18 @@
 #!/bin/bash
-# dev tool: collect the round's measurement set on the GPU box into gpurun_out/set/ (run from the repo root)
+# dev tool: collect the round's measurement set on the GPU box into gpurun_out/$1/ (run from the repo root)
 set -x
-R=$PWD; O=$R/gpurun_out/set; mkdir -p $O
+R=$PWD; O=$R/gpurun_out/${1:-set}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-P="python bench.py --workload prove"
-$P --threads 1 --steps 100 > $O/prove.jsonl 2>> $O/bench.err
-$P --threads 2 --steps 300 --no-cpu-baseline >> $O/prove.jsonl 2>> $O/bench.err
-$P --threads 2 --batch 8 --steps 640 --no-cpu-baseline >> $O/prove.jsonl 2>> $O/bench.err
-$P --threads 2 --batch 32 --steps 1280 --no-cpu-baseline >> $O/prove.jsonl 2>> $O/bench.err
-for sh in to_private to_public; do
-  $P --shape $sh --threads 2 --steps 300 --no-cpu-baseline >> $O/prove.jsonl 2>> $O/bench.err
-  $P --shape $sh --threads 2 --batch 32 --steps 1280 --no-cpu-baseline >> $O/prove.jsonl 2>> $O/bench.err
-done
+for sh in to_private to_public; do python bench.py --workload prove --shape $sh --no-cpu-baseline >> $O/prove_shapes.jsonl 2>> $O/bench.err; done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --no-cpu-baseline > $O/bench_profiled.json 2>> $O/bench.err
+# pipelined headline (3 MSMs in flight) and latency mode (one at a time): kernel statistics + the timeline of one MSM
+rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --quick --no-cpu-baseline > $O/bench_profiled.json 2>> $O/bench.err
 python $R/tools/rocprof_summary.py $(find /tmp/pb -name "*.db" | head -1) > $O/bench_kernel_stats.txt
+MANTA_BENCH_DEPTH=1 rocprofv3 --kernel-trace --stats -d /tmp/pb1 -o b -- python $R/bench.py --quick --no-cpu-baseline > $O/bench_depth1_profiled.json 2>> $O/bench.err
+python $R/tools/rocprof_summary.py $(find /tmp/pb1 -name "*.db" | head -1) > $O/bench_depth1_kernel_stats.txt
+python $R/tools/msm_timeline.py $(find /tmp/pb1 -name "*.db" | head -1) > $O/msm_latency_timeline.txt
 rocprofv3 --kernel-trace --stats -d /tmp/pp -o p -- python $R/tools/prove_profile.py > $O/prove_profiled.txt 2>> $O/bench.err
 python $R/tools/rocprof_summary.py $(find /tmp/pp -name "*.db" | head -1) > $O/prove_kernel_stats.txt
+python $R/tools/proof_timeline.py $(find /tmp/pp -name "*.db" | head -1) > $O/proof_timeline.txt
+rocprofv3 --kernel-trace --stats -d /tmp/pq -o q -- python $R/tools/prove_batch_profile.py > $O/prove_batch_profiled.txt 2>> $O/bench.err
+python $R/tools/rocprof_summary.py $(find /tmp/pq -name "*.db" | head -1) > $O/prove_batch32_kernel_stats.txt
