@@ -43,8 +43,9 @@ WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
 DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
 ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-# v_mad_u64_u32 per mixed addition in the 14 x 28-bit representation: 8 products x 406 + 2 squarings x 315
-MADS_PER_MIXED_ADD = 8 * 406 + 2 * 315
+# v_mad_u64_u32 per mixed addition in the 14 x 28-bit representation (ec_dev.h madd_lazy): 6 products x 406 + 2 squarings x
+# 315 + one fused a*b + c*d product with a single reduction (3 x 196 + 14 = 602); round 1 had 8 x 406 + 2 x 315 = 3878
+MADS_PER_MIXED_ADD = 6 * 406 + 2 * 315 + 602
 PEAK_TMAD_S = 1024 * 64 / 4.2 * 2.4e9 / 1e12  # 1024 SIMDs x 64 lanes / 4.2 cycles (profiles/r01_ubench2_mad_u64_u32.txt) x 2.4 GHz
 
 BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,

@@ -167,7 +167,62 @@ template <class F> struct XYZZ {
         if constexpr (F::EXT) madd_call(q, neg);
         else madd_body(q, neg);
     }
+    // madd for the reduced-radix base field (the bucket-accumulate inner loop: ~16 of these per scalar), restructured
+    // around two savings the lazy representation allows:
+    //   (1) Y3 = R (Q - X3) - Y1 PPP as ONE fused product R*T + Y1*N with N = 3p - PPP: one Montgomery reduction less
+    //       (3 K^2 + K instead of 4 K^2 + 2 K multiply-adds for the pair);
+    //   (2) the differences P = U2 - X1, R = S2 - Y1, T = Q - X3, N and the negated q.y are taken carry-free (`subl`:
+    //       limbs < 3 * 2^LB, no normalisation pass) -- they only ever feed multiplications -- and the P = 0 test moves
+    //       to PP = P^2, a normalised product output (two candidates 0, p instead of eleven multiples of p).
+    // Bounds (values as multiples of p; inputs X1 < 8, Y1 < 4, ZZ1, ZZZ1, q.x, q.y < 2; F::LIM >= 169):
+    //   U2, S2 < 2;  P = U2 + 9p - X1 < 11;  R = S2 + 5p - Y1 < 7;  PP = P^2: 121 <= LIM;  PPP = P PP: 22;  Q = X1 PP: 16;
+    //   X3 = R^2 - PPP - 2Q: R^2 49 <= LIM, value < 2 + 6 = 8 (normalised: it is stored);  T = Q + 9p - X3 < 11;
+    //   N = 3p - PPP <= 3;  Y3 = R T + Y1 N: 7*11 + 4*3 = 89 <= LIM, value < 2;  ZZ3, ZZZ3 < 2.
+    MG_DEV void madd_lazy(const Affine<F> &q_in, bool negate) {
+        static_assert(!F::EXT && F::LAZY, "reduced-radix base field only");
+        static_assert(F::BX == 8 && F::BY == 4 && F::BM == 2 && F::LIM >= 121, "bound analysis above");
+        if (q_in.is_inf()) return;
+        F qy = q_in.y;
+        if (negate) qy = F::template negl<3>(q_in.y); // 3p - y with lazy limbs: feeds the product S2 only
+        if (is_inf()) {
+            x = q_in.x;
+            y = negate ? F::template neg<2>(q_in.y) : q_in.y; // stored coordinates are normalised
+            zz = F::one();
+            zzz = F::one();
+            return;
+        }
+        const F U2 = F::mul(q_in.x, zz);
+        const F S2 = F::mul(qy, zzz);
+        const F P = F::template subl<9>(U2, x);  // < 11p, lazy limbs
+        const F R = F::template subl<5>(S2, y);  // < 7p
+        const F PP = F::sqr(P);
+        if (PP.template is_zero_mod<2>()) { // P = 0 (mod p): same x -- doubling or cancellation (rare; exact)
+            if (F::normalize_u(R).template is_zero_mod<7>()) {
+                Affine<F> q{q_in.x, negate ? F::template neg<2>(q_in.y) : q_in.y};
+                *this = dbl_affine(q);
+            } else {
+                *this = inf();
+            }
+            return;
+        }
+        const F PPP = F::mul(P, PP);
+        const F Q = F::mul(x, PP);
+        const F X3 = F::template sub2<6>(F::sqr(R), PPP, Q); // R^2 + 6p - PPP - 2Q < 8p, normalised
+        const F T = F::template subl<9>(Q, X3);              // < 11p
+        const F N = F::template negl<3>(PPP);                // 3p - PPP
+        const F Y3 = F::mul_add(R, T, y, N);
+        zz = F::mul(zz, PP);
+        zzz = F::mul(zzz, PPP);
+        x = X3;
+        y = Y3;
+    }
     MG_DEV void madd_body(const Affine<F> &q_in, bool negate) {
+        if constexpr (!F::EXT && F::LAZY) {
+            if constexpr (F::LAZY_LIMBS) {
+                madd_lazy(q_in, negate);
+                return;
+            }
+        }
         if (q_in.is_inf()) return;
         Affine<F> q = q_in;
         if (negate) q.y = b_neg(bv<BM>(q.y)).v;

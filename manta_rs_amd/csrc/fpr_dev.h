@@ -110,6 +110,73 @@ template <class C> struct FpR {
         return normalize(t);
     }
     template <int M> static MG_DEV FpR neg(const FpR &a) { return sub<M>(zero(), a); }
+
+    // ---- carry-free subtraction: a + M*p - b with NO normalisation pass. M*p is taken in the redundant limb form
+    //   q_0 = m_0 + 2^LB,  q_i = m_i + 2^LB - 1 (0 < i < K-1),  q_{K-1} = m_{K-1} - 1      (same value: each limb lends one
+    // unit of 2^LB to the limb below), so that q_i - b_i >= 0 for every NORMALISED b (limbs < 2^LB, and b < (M-1)*p keeps
+    // the top limb non-negative: m_{K-1}(M) - 1 >= m_{K-1}(M-1) + p_top - 2 >= b_top). The result's limbs are < 3 * 2^LB
+    // ("lazy limbs"); it is a legal multiplication operand wherever the column accumulators have the room (LAZY_LIMBS
+    // below), which saves the 3-instructions-per-limb carry pass of `sub`.
+    static constexpr u32 multb(int M, int i) {
+        return i == 0 ? C::RR_MULT[M][0] + (1u << LB) : (i < K - 1 ? C::RR_MULT[M][i] + MASK : C::RR_MULT[M][K - 1] - 1u);
+    }
+    // worst column of a fused product with lazy operands: K * (3*3 + 3*1 + 1) * 2^(2 LB) must stay below 2^64
+    static constexpr bool LAZY_LIMBS = (double)K * 13.0 * (double)(1ull << LB) * (double)(1ull << LB) < 18446744073709551616.0;
+    template <int M> static MG_DEV FpR subl(const FpR &a, const FpR &b) { // a may itself have lazy limbs only if a is normalised: see call sites
+        static_assert(M <= C::RR_MAXM, "multiple table too short");
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) r.v[i] = a.v[i] + multb(M, i) - b.v[i];
+        return r;
+    }
+    template <int M> static MG_DEV FpR negl(const FpR &b) { return subl<M>(zero(), b); }
+    static MG_DEV FpR normalize_u(const FpR &a) { // lazy limbs (non-negative) -> normalised
+        FpR r;
+        u32 c = 0;
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i) {
+            const u32 t = a.v[i] + c;
+            c = t >> LB;
+            r.v[i] = t & MASK;
+        }
+        r.v[K - 1] = a.v[K - 1] + c;
+        return r;
+    }
+    // ---- fused almost-Montgomery product (a*b + c*d) * R'^-1 with ONE reduction: two double-width products share the
+    // column accumulators and the m*p pass -- 3 K^2 + K multiply-adds instead of 4 K^2 + 2 K. Value < 2p whenever
+    // Ba*Bb + Bc*Bd <= LIM; limbs of the operands may be lazy when LAZY_LIMBS (column bound above).
+    static MG_DEV FpR mul_add(const FpR &a, const FpR &b, const FpR &c, const FpR &d) {
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                acc += (u64)a.v[i] * b.v[k - i];
+                acc += (u64)c.v[i] * d.v[k - i];
+                acc += (u64)m[i] * C::RR_P[k - i];
+            }
+            acc += (u64)a.v[k] * b.v[0];
+            acc += (u64)c.v[k] * d.v[0];
+            m[k] = ((u32)acc * C::RR_INV) & MASK;
+            acc += (u64)m[k] * C::RR_P[0];
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int k = K; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = k - K + 1; i < K; ++i) {
+                acc += (u64)a.v[i] * b.v[k - i];
+                acc += (u64)c.v[i] * d.v[k - i];
+                acc += (u64)m[i] * C::RR_P[k - i];
+            }
+            t.v[k - K] = (u32)acc & MASK;
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
     // value < A*p (A <= 16)  ->  same residue, < 2p: subtract floor-estimate(value / p) * p, the
     // quotient estimated from the top limb (never too large, at most one too small)
     template <int A> static MG_DEV FpR reduce(const FpR &a) {
