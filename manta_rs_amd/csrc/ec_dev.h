@@ -167,6 +167,23 @@ template <class F> struct XYZZ {
         if constexpr (F::EXT) madd_call(q, neg);
         else madd_body(q, neg);
     }
+    // the mixed addition for THROUGHPUT-bound callers (>= 2 wavefronts per SIMD: the bucket-accumulate kernel): where the
+    // field has it, the single-chain coding of the products
+    MG_DEV void madd_throughput(const Affine<F> &q, bool neg) {
+        if constexpr (!F::EXT && F::LAZY) {
+            if constexpr (F::LAZY_LIMBS) {
+#ifdef MG_ACC_CHAIN // A/B build switch. Measured on MI355X inside the real kernel: SLOWER (2.69 ms against 2.52 ms for the 2^20
+                    // BLS12-381 accumulate launch) although the product alone gains 5 % in isolation -- hipcc pads the
+                    // dependent v_mad_u64_u32 chains with ~3400 s_nop per loop body. Kept for re-measurement only.
+                madd_lazy<true>(q, neg);
+#else
+                madd_lazy<false>(q, neg);
+#endif
+                return;
+            }
+        }
+        madd(q, neg);
+    }
     // madd for the reduced-radix base field (the bucket-accumulate inner loop: ~16 of these per scalar), restructured
     // around two savings the lazy representation allows:
     //   (1) Y3 = R (Q - X3) - Y1 PPP as ONE fused product R*T + Y1*N with N = 3p - PPP: one Montgomery reduction less
@@ -178,7 +195,7 @@ template <class F> struct XYZZ {
     //   U2, S2 < 2;  P = U2 + 9p - X1 < 11;  R = S2 + 5p - Y1 < 7;  PP = P^2: 121 <= LIM;  PPP = P PP: 22;  Q = X1 PP: 16;
     //   X3 = R^2 - PPP - 2Q: R^2 49 <= LIM, value < 2 + 6 = 8 (normalised: it is stored);  T = Q + 9p - X3 < 11;
     //   N = 3p - PPP <= 3;  Y3 = R T + Y1 N: 7*11 + 4*3 = 89 <= LIM, value < 2;  ZZ3, ZZZ3 < 2.
-    MG_DEV void madd_lazy(const Affine<F> &q_in, bool negate) {
+    template <bool CH = false> MG_DEV void madd_lazy(const Affine<F> &q_in, bool negate) {
         static_assert(!F::EXT && F::LAZY, "reduced-radix base field only");
         static_assert(F::BX == 8 && F::BY == 4 && F::BM == 2 && F::LIM >= 121, "bound analysis above");
         if (q_in.is_inf()) return;
@@ -191,11 +208,11 @@ template <class F> struct XYZZ {
             zzz = F::one();
             return;
         }
-        const F U2 = F::mul(q_in.x, zz);
-        const F S2 = F::mul(qy, zzz);
+        const F U2 = F::template mul_t<CH>(q_in.x, zz);
+        const F S2 = F::template mul_t<CH>(qy, zzz);
         const F P = F::template subl<9>(U2, x);  // < 11p, lazy limbs
         const F R = F::template subl<5>(S2, y);  // < 7p
-        const F PP = F::sqr(P);
+        const F PP = F::template sqr_t<CH>(P);
         if (PP.template is_zero_mod<2>()) { // P = 0 (mod p): same x -- doubling or cancellation (rare; exact)
             if (F::normalize_u(R).template is_zero_mod<7>()) {
                 Affine<F> q{q_in.x, negate ? F::template neg<2>(q_in.y) : q_in.y};
@@ -205,21 +222,21 @@ template <class F> struct XYZZ {
             }
             return;
         }
-        const F PPP = F::mul(P, PP);
-        const F Q = F::mul(x, PP);
-        const F X3 = F::template sub2<6>(F::sqr(R), PPP, Q); // R^2 + 6p - PPP - 2Q < 8p, normalised
+        const F PPP = F::template mul_t<CH>(P, PP);
+        const F Q = F::template mul_t<CH>(x, PP);
+        const F X3 = F::template sub2<6>(F::template sqr_t<CH>(R), PPP, Q); // R^2 + 6p - PPP - 2Q < 8p, normalised
         const F T = F::template subl<9>(Q, X3);              // < 11p
         const F N = F::template negl<3>(PPP);                // 3p - PPP
-        const F Y3 = F::mul_add(R, T, y, N);
-        zz = F::mul(zz, PP);
-        zzz = F::mul(zzz, PPP);
+        const F Y3 = F::template mul_add_t<CH>(R, T, y, N);
+        zz = F::template mul_t<CH>(zz, PP);
+        zzz = F::template mul_t<CH>(zzz, PPP);
         x = X3;
         y = Y3;
     }
     MG_DEV void madd_body(const Affine<F> &q_in, bool negate) {
         if constexpr (!F::EXT && F::LAZY) {
             if constexpr (F::LAZY_LIMBS) {
-                madd_lazy(q_in, negate);
+                madd_lazy<false>(q_in, negate);
                 return;
             }
         }

@@ -23,6 +23,13 @@
 
 namespace mg {
 
+// acc += a*b as ONE v_mad_u64_u32 the compiler may not re-associate: all multiply-adds of a column then form a single
+// dependent chain (the C expression is split into an a*b chain and an m*p chain joined by a v_lshl_add_u64 per column:
+// 28 more instructions per 14-limb product). Faster by 3.5-5.4 % at >= 2 wavefronts per SIMD, 35 % slower at one
+// (profiles/r02_ubench4_fma_vs_int.txt) -- so only the throughput-bound accumulate kernel asks for it (CH = true).
+MG_DEV void mad_chain_vv(u64 &acc, u32 a, u32 b) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
+MG_DEV void mad_chain_vs(u64 &acc, u32 a, u32 k) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc"); }
+
 template <class C> struct FpR {
     static constexpr int K = C::RR_K, LB = C::RR_LB;
     static constexpr int N = K; // words per element in memory
@@ -218,6 +225,102 @@ template <class C> struct FpR {
             for (int i = k - K + 1; i < K; ++i) {
                 acc += (u64)a.v[i] * b.v[k - i];
                 acc += (u64)m[i] * C::RR_P[k - i];
+            }
+            t.v[k - K] = (u32)acc & MASK;
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    // single-chain codings (see mad_chain_vv) of mul / sqr / mul_add
+    template <bool CH> static MG_DEV FpR mul_t(const FpR &a, const FpR &b) {
+        if constexpr (!CH) return mul(a, b);
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                mad_chain_vv(acc, a.v[i], b.v[k - i]);
+                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+            }
+            mad_chain_vv(acc, a.v[k], b.v[0]);
+            m[k] = ((u32)acc * C::RR_INV) & MASK;
+            mad_chain_vs(acc, m[k], C::RR_P[0]);
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int k = K; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = k - K + 1; i < K; ++i) {
+                mad_chain_vv(acc, a.v[i], b.v[k - i]);
+                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+            }
+            t.v[k - K] = (u32)acc & MASK;
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    template <bool CH> static MG_DEV FpR sqr_t(const FpR &a) {
+        if constexpr (!CH) return sqr(a);
+        u64 acc = 0;
+        u32 m[K], a2[K];
+        FpR t;
+#pragma unroll
+        for (int i = 0; i < K; ++i) a2[i] = a.v[i] << 1;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int j = k - i;
+                if (j < 0 || j >= K) continue;
+                if (i < j) mad_chain_vv(acc, a2[i], a.v[j]);
+                if (i == j) mad_chain_vv(acc, a.v[i], a.v[i]);
+                if (k < K) {
+                    if (i < k) mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+                } else {
+                    mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+                }
+            }
+            if (k < K) {
+                m[k] = ((u32)acc * C::RR_INV) & MASK;
+                mad_chain_vs(acc, m[k], C::RR_P[0]);
+            } else {
+                t.v[k - K] = (u32)acc & MASK;
+            }
+            acc >>= LB;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    template <bool CH> static MG_DEV FpR mul_add_t(const FpR &a, const FpR &b, const FpR &c, const FpR &d) {
+        if constexpr (!CH) return mul_add(a, b, c, d);
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                mad_chain_vv(acc, a.v[i], b.v[k - i]);
+                mad_chain_vv(acc, c.v[i], d.v[k - i]);
+                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+            }
+            mad_chain_vv(acc, a.v[k], b.v[0]);
+            mad_chain_vv(acc, c.v[k], d.v[0]);
+            m[k] = ((u32)acc * C::RR_INV) & MASK;
+            mad_chain_vs(acc, m[k], C::RR_P[0]);
+            acc >>= LB;
+        }
+#pragma unroll
+        for (int k = K; k < 2 * K - 1; ++k) {
+#pragma unroll
+            for (int i = k - K + 1; i < K; ++i) {
+                mad_chain_vv(acc, a.v[i], b.v[k - i]);
+                mad_chain_vv(acc, c.v[i], d.v[k - i]);
+                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
             }
             t.v[k - K] = (u32)acc & MASK;
             acc >>= LB;

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__
         }
         const u32 v = vals[j];
         const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * astride);
-        acc.madd(p, (v >> 31) != 0);
+        acc.madd_throughput(p, (v >> 31) != 0);
     }
     if (first) { // the whole chunk is one run
         pkeys[2 * t] = cur;
