@@ -198,9 +198,15 @@ template <class F> struct XYZZ {
     template <bool CH = false> MG_DEV void madd_lazy(const Affine<F> &q_in, bool negate) {
         static_assert(!F::EXT && F::LAZY, "reduced-radix base field only");
         static_assert(F::BX == 8 && F::BY == 4 && F::BM == 2 && F::LIM >= 121, "bound analysis above");
+        // LL: the column accumulators have room for lazy limbs (BLS12-381's 14 x 28 bits); otherwise (BN254's 9 x 29
+        // bits) the differences are normalised as before and only the fused product and the cheap zero test remain
+        constexpr bool LL = F::LAZY_LIMBS;
         if (q_in.is_inf()) return;
         F qy = q_in.y;
-        if (negate) qy = F::template negl<3>(q_in.y); // 3p - y with lazy limbs: feeds the product S2 only
+        if (negate) {
+            if constexpr (LL) qy = F::template negl<3>(q_in.y); // 3p - y with lazy limbs: feeds the product S2 only
+            else qy = F::template neg<2>(q_in.y);
+        }
         if (is_inf()) {
             x = q_in.x;
             y = negate ? F::template neg<2>(q_in.y) : q_in.y; // stored coordinates are normalised
@@ -210,11 +216,17 @@ template <class F> struct XYZZ {
         }
         const F U2 = F::template mul_t<CH>(q_in.x, zz);
         const F S2 = F::template mul_t<CH>(qy, zzz);
-        const F P = F::template subl<9>(U2, x);  // < 11p, lazy limbs
-        const F R = F::template subl<5>(S2, y);  // < 7p
+        F P, R;
+        if constexpr (LL) {
+            P = F::template subl<9>(U2, x); // < 11p, lazy limbs
+            R = F::template subl<5>(S2, y); // < 7p
+        } else {
+            P = F::template sub<8>(U2, x); // < 10p
+            R = F::template sub<4>(S2, y); // < 6p
+        }
         const F PP = F::template sqr_t<CH>(P);
         if (PP.template is_zero_mod<2>()) { // P = 0 (mod p): same x -- doubling or cancellation (rare; exact)
-            if (F::normalize_u(R).template is_zero_mod<7>()) {
+            if ((LL ? F::normalize_u(R) : R).template is_zero_mod<7>()) {
                 Affine<F> q{q_in.x, negate ? F::template neg<2>(q_in.y) : q_in.y};
                 *this = dbl_affine(q);
             } else {
@@ -225,8 +237,14 @@ template <class F> struct XYZZ {
         const F PPP = F::template mul_t<CH>(P, PP);
         const F Q = F::template mul_t<CH>(x, PP);
         const F X3 = F::template sub2<6>(F::template sqr_t<CH>(R), PPP, Q); // R^2 + 6p - PPP - 2Q < 8p, normalised
-        const F T = F::template subl<9>(Q, X3);              // < 11p
-        const F N = F::template negl<3>(PPP);                // 3p - PPP
+        F T, N;
+        if constexpr (LL) {
+            T = F::template subl<9>(Q, X3); // < 11p
+            N = F::template negl<3>(PPP);   // 3p - PPP
+        } else {
+            T = F::template sub<8>(Q, X3); // < 10p
+            N = F::template neg<2>(PPP);   // 2p - PPP
+        }
         const F Y3 = F::template mul_add_t<CH>(R, T, y, N);
         zz = F::template mul_t<CH>(zz, PP);
         zzz = F::template mul_t<CH>(zzz, PPP);
@@ -235,10 +253,8 @@ template <class F> struct XYZZ {
     }
     MG_DEV void madd_body(const Affine<F> &q_in, bool negate) {
         if constexpr (!F::EXT && F::LAZY) {
-            if constexpr (F::LAZY_LIMBS) {
-                madd_lazy<false>(q_in, negate);
-                return;
-            }
+            madd_lazy<false>(q_in, negate);
+            return;
         }
         if (q_in.is_inf()) return;
         Affine<F> q = q_in;

@@ -149,6 +149,8 @@ template <class C> struct FpR {
         r.v[K - 1] = a.v[K - 1] + c;
         return r;
     }
+    // (fused products with NORMALISED operands need K * 3 * 2^(2 LB) < 2^64: true for both fields)
+    static_assert((double)K * 3.0 * (double)(1ull << LB) * (double)(1ull << LB) < 18446744073709551616.0, "fused column overflow");
     // ---- fused almost-Montgomery product (a*b + c*d) * R'^-1 with ONE reduction: two double-width products share the
     // column accumulators and the m*p pass -- 3 K^2 + K multiply-adds instead of 4 K^2 + 2 K. Value < 2p whenever
     // Ba*Bb + Bc*Bd <= LIM; limbs of the operands may be lazy when LAZY_LIMBS (column bound above).
