@@ -384,6 +384,38 @@ class ProveSetup:
         return env.max_over_ranks(time.perf_counter() - t0), proofs
 
 
+def verify_bench(ps, proofs):
+    """mg_groth16_verify / mg_groth16_verify_batch on the proofs just produced (same circuit and inputs for all of them:
+    the verifier's work does not depend on that). Proof decoding (decompression + subgroup checks, host) is outside the
+    timed region, as a `Proof` arrives deserialised in the reference."""
+    api = ps.api
+    vctx = api.VerifyingContext(ps.curve, ps.pk)
+    inputs = ps.c.z[1:ps.c.P]
+    pts = [api.proof_decode(ps.curve, p) for p in proofs[:256]]
+    assert api.groth16_verify(vctx, inputs, pts[0])
+    bad = inputs.copy()
+    bad[0] = ps.rs[0][0]
+    assert not api.groth16_verify(vctx, bad, pts[0])
+    t0 = time.perf_counter()
+    n1 = 20
+    for i in range(n1):
+        api.groth16_verify(vctx, inputs, pts[i % len(pts)])
+    t1 = (time.perf_counter() - t0) / n1
+    k = len(pts)
+    rnd = np.random.RandomState(7).randint(1, 1 << 62, size=(k, 2)).astype(np.uint64)
+    allin = np.stack([inputs] * k)
+    assert api.groth16_verify_batch(vctx, allin, pts, rnd)
+    t0 = time.perf_counter()
+    nb = 3
+    for _ in range(nb):
+        api.groth16_verify_batch(vctx, allin, pts, rnd)
+    tb = (time.perf_counter() - t0) / nb
+    vctx.close()
+    return {"single_ms": round(t1 * 1e3, 3), "single_proofs_per_s": round(1 / t1, 1), "batch": k, "batch_ms": round(tb * 1e3, 3),
+            "batch_proofs_per_s": round(k / tb, 1),
+            "how": "3 / k + 3 Miller loops (one GPU lane each) + one final exponentiation; accepted and a fuzzed input rejected before timing"}
+
+
 def prove_cpu_baseline(ps, proofs, ncpu=8):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # checker, here as the timed CPU baseline (and a free byte-parity check)
@@ -435,6 +467,8 @@ def prove_bench(args, env, shape="private_transfer", full=True):
     res["batched"] = {"proofs_per_s": round(env.world * nb / dt, 2), "host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,
                       "ms_per_proof": round(dt / nb * 1e3, 4)}
     res["value"] = res["batched"]["proofs_per_s"]
+    if full:  # SURVEY f-2: `Groth16::verify` on the GPU -- one proof at a time and 256 at once by random linear combination
+        res["verify"] = verify_bench(ps, pb)
     res["n_gpus"] = env.world
     res["scaling"] = "weak (replicas: every GPU proves its own stream, no collective)"
     algo_bytes = 7 * 64 * D + 32 * V + 32 * D + 64 * (3 * V - P + D) + 128 * V

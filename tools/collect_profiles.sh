@@ -16,3 +16,12 @@ python $R/tools/rocprof_summary.py $(find /tmp/pp -name "*.db" | head -1) > $O/p
 python $R/tools/proof_timeline.py $(find /tmp/pp -name "*.db" | head -1) > $O/proof_timeline.txt
 rocprofv3 --kernel-trace --stats -d /tmp/pq -o q -- python $R/tools/prove_batch_profile.py > $O/prove_batch_profiled.txt 2>> $O/bench.err
 python $R/tools/rocprof_summary.py $(find /tmp/pq -name "*.db" | head -1) > $O/prove_batch32_kernel_stats.txt
+# PMC passes (own runs, --kernel-trace only): HBM traffic and VALU mix of the accumulate kernel
+for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_WAVES; do
+  rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o m -- python $R/bench.py --quick --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $O/bench.err
+  python $R/tools/pmc_kernels.py $(find /tmp/pmc_$c -name "*.db" | head -1) 2>/dev/null | grep -E "accumulate_chunks|digits_kernel|gather_only" >> $O/pmc_kernels.txt
+done
+MANTA_ACC_GATHER_ONLY=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_g -o m -- python $R/tools/gather_calibration.py 16 > /dev/null 2>> $O/bench.err
+for db in $(find /tmp/pmc_g -name "*.db"); do python $R/tools/pmc_kernels.py $db 2>/dev/null | grep -E "gather_only|accumulate_chunks" >> $O/pmc_gather_only.txt; done
+python $R/tools/gather_calibration.py 16 > $O/gather_calibration.jsonl 2>> $O/bench.err
+python $R/tools/hbm_bw.py > $O/hbm_bw.txt 2>> $O/bench.err
