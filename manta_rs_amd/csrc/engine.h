@@ -172,7 +172,7 @@ GroupEngine *make_engine_bls381_g1();
 GroupEngine *make_engine_bls381_g2();
 GroupEngine *get_engine(int curve, int group); // cached singleton per (curve, group)
 
-// radix sort of (key,val) pairs, keys < 2^end_bit (sort.hip; hipCUB device-wide radix sort)
+// radix sort of (key,val) pairs, keys < 2^end_bit (sort.hip: hand-written wave64 LSD radix sort)
 size_t sort_pairs_temp_bytes(size_t n);
 // d_count (optional): the number of pairs actually present, on the device (n is then the capacity)
 bool sort_pairs_takes_device_count(int end_bit);

@@ -12,11 +12,10 @@
 //                  their rank is a popcount of the lanes before them plus the wave's running count for the
 //                  digit; no atomics, stable by construction. The tile is then laid out digit-sorted in LDS so
 //                  that consecutive lanes store to consecutive addresses within each digit run.
-// 20 B of HBM traffic per element per pass. `MANTA_SORT=cub` selects the library sort instead (A/B, fallback).
+// 20 B of HBM traffic per element per pass. The only sort on the product path: keys wider than 32 bits' worth of
+// 8-bit passes do not occur (msm_launch caps the bucket-key space at 2^24), and no library sort is linked.
 #include "engine.h"
 #include <cstdlib>
-#include <string>
-#include <hipcub/hipcub.hpp>
 
 namespace mg {
 
@@ -163,34 +162,17 @@ __global__ __launch_bounds__(256) void radix_scatter(const u32 *__restrict__ key
     }
 }
 
-static bool use_cub() {
-    static const bool v = [] {
-        const char *e = std::getenv("MANTA_SORT");
-        return e && std::string(e) == "cub";
-    }();
-    return v;
-}
-
 size_t sort_pairs_temp_bytes(size_t n) {
-    size_t cub = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, cub, (const u32 *)nullptr, (u32 *)nullptr, (const u32 *)nullptr,
-                                       (u32 *)nullptr, (int)n, 0, 32, (hipStream_t)0);
     const size_t ntiles = (n + SORT_TILE - 1) / SORT_TILE;
-    const size_t mine = 2 * n * 4 /* ping-pong pair */ + 256 * ntiles * 4 + 256 * 4 + 256;
-    return cub > mine ? cub : mine;
+    return 2 * n * 4 /* ping-pong pair */ + 256 * ntiles * 4 + 256 * 4 + 256;
 }
 
-bool sort_pairs_takes_device_count(int end_bit) { return !(use_cub() || end_bit > 24); }
+bool sort_pairs_takes_device_count(int end_bit) { return end_bit >= 1 && end_bit <= 32; }
 
 int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_out, size_t n, int end_bit,
                void *tmp, size_t tmp_bytes, hipStream_t s, const u32 *d_count) {
     if (n == 0) return MG_OK;
-    if (!sort_pairs_takes_device_count(end_bit)) {
-        if (d_count) return MG_ERR_ARG; // the library sort needs the count on the host
-        MG_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0,
-                                                  end_bit, s));
-        return MG_OK;
-    }
+    if (end_bit < 1 || end_bit > 32 || n >= (1ull << 32) || tmp_bytes < sort_pairs_temp_bytes(n)) return MG_ERR_ARG;
     const u32 M = (u32)n;
     const u32 ntiles = (u32)((n + SORT_TILE - 1) / SORT_TILE);
     const int passes = (end_bit + 7) / 8;
