@@ -218,7 +218,7 @@ static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, co
         if (!rc && !ws) rc = MG_ERROR_HIP;
         if (ws) {
             job->sh.push_back(JobShard{s.eng, ws, s.device, d_tmp});
-            rc = s.eng->msm_launch(s.bs, d_sc, n, (scalar_flags & MG_SCALARS_MONT) != 0, window_bits, ws, 1, 0,
+            rc = s.eng->msm_launch(s.bs, d_sc, n, (scalar_flags & MG_SCALARS_MONT) ? SCALARS_MONT : SCALARS_CANONICAL, window_bits, ws, 1, 0,
                                    (scalar_flags & MG_SCALARS_SPARSE) != 0);
         } else if (d_tmp) {
             hipFree(d_tmp);

@@ -46,6 +46,8 @@ struct DevBuf {
     template <class T> T *as() const { return (T *)p; }
 };
 
+enum { SCALARS_CANONICAL = 0, SCALARS_MONT = 1, SCALARS_WORK = 2 };
+
 // Pippenger plan. Signed digits of c bits, B = 2^(c-1) buckets per bucket-window.
 struct MsmPlan {
     int c = 0;       // window bits
@@ -120,7 +122,9 @@ class GroupEngine {
     // sparse: the scalars are expected to have many zero digits (a witness: 40 % zeros, 25 % ones) -- the digit
     // kernel then compacts the zero digits away before the sort (two passes over the digits and one atomic per
     // wavefront: ~3 % slower on uniform scalars, up to 18 % faster on witness-like ones).
-    virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
+    // scalar_mode: SCALARS_CANONICAL (`into_repr` done by the caller), SCALARS_MONT (arkworks Montgomery words, converted
+    // on the device), SCALARS_WORK (the witness map's reduced-radix work form, 9 words per scalar: the h MSM)
+    virtual int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, int scalar_mode, int c_override,
                            MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) = 0;
     // Waits for the stream, folds the staged partial points on the host. out = `batch` XYZZ host points.
     // already_synced: the caller has synchronised with the work itself (hipGraph replay of a whole proof)

@@ -188,8 +188,10 @@ template <class C> struct FpR {
     }
     // value < A*p (A <= 16)  ->  same residue, < 2p: subtract floor-estimate(value / p) * p, the
     // quotient estimated from the top limb (never too large, at most one too small)
+    // (valid for any A with A*p < 2^(LB*K): with T the top limb and D = p_top + 1, the estimate q' = floor(T*RECIP/2^32) is
+    // never above value/p and lies less than 1/8 + (A + 1)/p_top < 1 below T/D <= value/p, p_top >= 2^16 for all four fields)
     template <int A> static MG_DEV FpR reduce(const FpR &a) {
-        static_assert(A <= 16, "reduce: bound too large for the top-limb quotient estimate");
+        static_assert(A <= 64 && A <= C::RR_LIM, "reduce: A*p must fit the representation");
         const u32 q = (u32)(((u64)a.v[K - 1] * C::RR_RECIP) >> 32);
         FpR r;
         long long c = 0;
@@ -378,6 +380,64 @@ template <class C> struct FpR {
         return acc;
     }
 
+    // ---- cheap conversions for fields with R'/R = 2^(LB*K - 32N) small (Fr: 2^261 / 2^256 = 2^5): the arkworks Montgomery
+    // form a*R is turned into a*R' by SHIFTING the integer left while repacking its limbs (value < 2^5 p) and one reduce --
+    // no multiplication; and a*R' becomes the canonical integer a by one almost-Montgomery product with the integer 1.
+    static MG_DEV FpR from_std_shift(const Std &s) {
+        constexpr int SH = LB * K - 32 * C::N; // R' = 2^SH * R
+        static_assert(SH >= 0 && SH < 8 && (1 << SH) <= 64 && (1 << SH) <= C::RR_LIM, "shift conversion needs a small R'/R");
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int bit = i * LB - SH; // limb i of (value << SH) = bits [bit, bit + LB) of value
+            u64 x = 0;
+            const int w = bit >= 0 ? (bit >> 5) : -1, o = bit >= 0 ? (bit & 31) : 0;
+            if (bit >= 0) {
+                x = w < C::N ? s.v[w] : 0;
+                if (w + 1 < C::N) x |= (u64)s.v[w + 1] << 32;
+                r.v[i] = (u32)(x >> o) & MASK;
+            } else { // only limb 0: its low SH bits are zero
+                r.v[i] = ((u32)s.v[0] << (-bit)) & MASK;
+            }
+        }
+        return reduce<(1 << SH)>(r);
+    }
+    // value (< 4p, any representative) -> the canonical integer a, as 32-bit words (ark-ff into_repr)
+    MG_DEV Std to_canonical() const {
+        FpR one_plain = zero();
+        one_plain.v[0] = 1;
+        return mul(*this, one_plain).canonical_words();
+    }
+    // a value < 2p with normalised limbs -> fully reduced, repacked into 32-bit words
+    MG_DEV Std canonical_words() const {
+        FpR y = *this;
+        int t[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) t[i] = (int)y.v[i] - (int)C::RR_P[i];
+        int cy = 0;
+        u32 d[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int sum = t[i] + cy;
+            cy = sum >> LB;
+            d[i] = (u32)sum & MASK;
+        }
+        const bool ge = cy == 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) y.v[i] = ge ? d[i] : y.v[i];
+        Std r;
+#pragma unroll
+        for (int w = 0; w < C::N; ++w) {
+            u64 x = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int lo = i * LB - w * 32;
+                if (lo > -LB && lo < 32) x |= lo >= 0 ? ((u64)y.v[i] << lo) : ((u64)y.v[i] >> (-lo));
+            }
+            r.v[w] = (u32)x;
+        }
+        return r;
+    }
     // ---- conversions to / from the arkworks (32-bit limb, R = 2^(32N)) Montgomery form
     static MG_DEV FpR from_std(const Std &s) {
         Std c;

@@ -9,6 +9,7 @@
 // generator; natural order in and out.
 #pragma once
 #include "fp_dev.h"
+#include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
 #include "prover.h"
@@ -30,111 +31,138 @@ __global__ __launch_bounds__(256) void powers_kernel(u32 *__restrict__ out, cons
     acc.store(out + (size_t)i * 8);
 }
 
-template <class FrC> __global__ __launch_bounds__(256) void bitrev_kernel(u32 *__restrict__ data, unsigned log_n) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1u << log_n)) return;
-    const u32 j = __brev(i) >> (32 - log_n);
-    if (i < j) {
-        uint4 *p = reinterpret_cast<uint4 *>(data);
-        uint4 a0 = p[2 * (size_t)i], a1 = p[2 * (size_t)i + 1];
-        uint4 b0 = p[2 * (size_t)j], b1 = p[2 * (size_t)j + 1];
-        p[2 * (size_t)i] = b0;
-        p[2 * (size_t)i + 1] = b1;
-        p[2 * (size_t)j] = a0;
-        p[2 * (size_t)j + 1] = a1;
-    }
-}
-
-template <class FrC>
-__global__ __launch_bounds__(256) void scale_table_kernel(u32 *__restrict__ data, const u32 *__restrict__ table,
-                                                          u32 n) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    typedef Fp<FrC> F;
-    F::mul(F::load(data + (size_t)i * 8), F::load(table + (size_t)i * 8)).store(data + (size_t)i * 8);
-}
-template <class FrC>
-__global__ __launch_bounds__(256) void scale_const_kernel(u32 *__restrict__ data, const u32 *__restrict__ k, u32 n) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    typedef Fp<FrC> F;
-    F::mul(F::load(data + (size_t)i * 8), F::load(k)).store(data + (size_t)i * 8);
-}
-
 // ---------------------------------------------------------------------------------------------------
+// Reduced-radix scalar field (round 2). Inside the NTT / witness-map pipeline an Fr element is FpR<FrC>: 9 limbs of
+// 29 bits, Montgomery radix R' = 2^261 = 2^5 R, lazily reduced (fpr_dev.h) -- the butterfly's product is 171 carry-free
+// v_mad_u64_u32 instead of 136 multiply-adds + 136 carry additions, additions are limb-wise with one normalisation
+// pass. Elements are 9 words (36 B) in HBM and in LDS. Conversions at the ends cost no multiplication going in (the
+// arkworks form a*R becomes a*R' by a 5-bit shift folded into the limb repacking + one reduce, from_std_shift) and
+// one product coming out (to_std / to_canonical). Tables (twiddles, scale tables) hold canonical values (< p).
+//
 // LDS-fused NTT pass: `ns` consecutive butterfly stages (global stages s0 .. s0+ns-1) of up to three
 // vectors (blockIdx.y) in one launch. A workgroup owns the 2^ns elements that differ only in index bits
-// [s0-1, s0-1+ns), for 2^cb adjacent values of the low bits (so that every global access is a run of
-// 2^cb * 32 contiguous bytes); the tile lives in LDS as limb-major SoA (conflict-free ds_read_b32) and
-// is read from / written to HBM exactly once per pass -- 64 B per element per pass instead of per stage.
+// [s0-1, s0-1+ns), for 2^cb adjacent values of the low bits; the tile lives in LDS as limb-major SoA
+// (conflict-free ds_read_b32) and is read from / written to HBM exactly once per pass.
 //   DIT (DIF = false): stages ascending, input bit-reversed -> output natural (Cooley-Tukey)
 //   DIF (DIF = true) : stages descending, input natural -> output bit-reversed (Gentleman-Sande)
-// `post` (optional) multiplies element i by post[i] on the way out (n^-1 and coset powers, tabulated in
-// the order the pass leaves the data in), so scaling never costs a pass of its own.
+// Bounds (multiples of p; uniform per stage, tracked in `B`): tile values enter < 4p. DIT: t = b w < 2p, a' = a + t,
+// b' = a + 2p - t, so B grows by 2 per stage (<= 4 + 5 + 2*9 = 27 over ten stages, within LIM = 70 / 169 for the only
+// product, b w) and one reduce at the end of the pass brings everything below 2p. DIF: x = a + b doubles B, so x is
+// reduced whenever 2B would exceed 8; y = (a + 9p - b) w < 2p. `post` (optional, last pass) multiplies element i by
+// post[i] on the way out (n^-1 and coset powers, tabulated in the order the pass leaves the data in).
 template <class FrC, bool DIF>
-__global__ __launch_bounds__(1024) void ntt_pass_kernel(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
-                                                       const u32 *__restrict__ tw, unsigned lg, unsigned s0,
-                                                       unsigned ns, unsigned cb, const u32 *__restrict__ post) {
+__global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
+                                                   const u32 *__restrict__ tw, unsigned lg, unsigned s0, unsigned ns,
+                                                   unsigned cb, const u32 *__restrict__ post) {
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
-    typedef Fp<FrC> F;
-    // blockIdx.y: which of the (up to three) vectors; blockIdx.z: which member of a batch of such vectors,
-    // stored back to back (2^lg elements apart)
-    u32 *__restrict__ data = (blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2)) + ((size_t)blockIdx.z << (lg + 3));
+    typedef FpR<FrC> R;
+    constexpr int K = R::K;
+    static_assert(K == 9 && R::LIM >= 64, "bound analysis above");
+    u32 *__restrict__ data = (blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2)) + ((size_t)blockIdx.z << lg) * K;
     const u32 E = 1u << ns, TOT = E << cb, CM = (1u << cb) - 1;
     const u32 lo_bits = s0 - 1;
-    const u32 nlo = (1u << lo_bits) >> cb; // groups of 2^cb low-index values
+    const u32 nlo = (1u << lo_bits) >> cb;
     const u32 lo_base = (blockIdx.x % nlo) << cb, hi = blockIdx.x / nlo;
     const size_t base = ((size_t)hi << (lo_bits + ns)) + lo_base;
     for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
         const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
-        const uint4 *p = reinterpret_cast<const uint4 *>(data + gi * 8);
-        const uint4 x = p[0], y = p[1];
-        sm[0 * TOT + t] = x.x, sm[1 * TOT + t] = x.y, sm[2 * TOT + t] = x.z, sm[3 * TOT + t] = x.w;
-        sm[4 * TOT + t] = y.x, sm[5 * TOT + t] = y.y, sm[6 * TOT + t] = y.z, sm[7 * TOT + t] = y.w;
+        const u32 *p = data + gi * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) sm[l * TOT + t] = p[l];
     }
     __syncthreads();
+    int B = 4; // every value in the tile is < B*p
     for (unsigned st = 0; st < ns; ++st) {
         const unsigned tl = DIF ? ns - st : st + 1; // local stage 1..ns
         const unsigned s = s0 + tl - 1;             // global stage
         const u32 half = 1u << (tl - 1);
+        const bool has_w = s > 1;
+        const bool red = DIF && 2 * B > 8; // uniform
         for (u32 k = threadIdx.x; k < TOT / 2; k += blockDim.x) {
             const u32 c = k & CM, kk = k >> cb;
             const u32 jl = kk & (half - 1), g = kk >> (tl - 1);
             const u32 i0 = ((((g << tl) | jl)) << cb) + c, i1 = i0 + (half << cb);
-            F a, b;
+            R a, b;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) a.v[l] = sm[l * TOT + i0], b.v[l] = sm[l * TOT + i1];
-            F w;
-            const bool has_w = s > 1;
+            for (int l = 0; l < K; ++l) a.v[l] = sm[l * TOT + i0], b.v[l] = sm[l * TOT + i1];
+            R w;
             if (has_w) {
                 const size_t j = ((size_t)jl << lo_bits) | (lo_base + c);
-                w = F::load(tw + (j << (lg - s)) * 8);
+                const uint4 *q = reinterpret_cast<const uint4 *>(tw + (j << (lg - s)) * 12); // 48 B records
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+                w.v[0] = q0.x, w.v[1] = q0.y, w.v[2] = q0.z, w.v[3] = q0.w, w.v[4] = q1.x, w.v[5] = q1.y, w.v[6] = q1.z,
+                w.v[7] = q1.w, w.v[8] = q2.x;
             }
-            F x, y;
+            R x, y;
             if (DIF) {
-                x = F::add(a, b);
-                y = F::sub(a, b);
-                if (has_w) y = F::mul(y, w);
+                x = R::add(a, b);                    // < 2B p
+                y = R::template sub<9>(a, b);        // a + 9p - b (b < 8p) < (B + 9) p
+                if (has_w) y = R::mul(y, w);         // < 2p
+                else y = R::template reduce<17>(y);  // last DIF stage (w = 1)
+                if (red) x = R::template reduce<16>(x);
             } else {
-                if (has_w) b = F::mul(b, w);
-                x = F::add(a, b);
-                y = F::sub(a, b);
+                if (has_w) {
+                    b = R::mul(b, w); // < 2p
+                    x = R::add(a, b);
+                    y = R::template sub<2>(a, b);
+                } else { // first DIT stage (w = 1): b < 4p
+                    x = R::add(a, b);
+                    y = R::template sub<5>(a, b);
+                }
             }
 #pragma unroll
-            for (int l = 0; l < 8; ++l) sm[l * TOT + i0] = x.v[l], sm[l * TOT + i1] = y.v[l];
+            for (int l = 0; l < K; ++l) sm[l * TOT + i0] = x.v[l], sm[l * TOT + i1] = y.v[l];
         }
+        if (DIF) B = red ? 2 : 2 * B;
+        else B = has_w ? B + 2 : B + 5;
         __syncthreads();
     }
     for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
         const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
-        F v;
+        R v;
 #pragma unroll
-        for (int l = 0; l < 8; ++l) v.v[l] = sm[l * TOT + t];
-        if (post) v = F::mul(v, F::load(post + gi * 8));
-        uint4 *p = reinterpret_cast<uint4 *>(data + gi * 8);
-        p[0] = make_uint4(v.v[0], v.v[1], v.v[2], v.v[3]);
-        p[1] = make_uint4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        for (int l = 0; l < K; ++l) v.v[l] = sm[l * TOT + t];
+        if (post) v = R::mul(v, R::load(post + gi * K)); // any B <= 27 times a canonical table entry: < 2p
+        else if (DIF ? B > 4 : true) v = R::template reduce<32>(v);
+        u32 *p = data + gi * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) p[l] = v.v[l];
     }
+}
+
+// arkworks-format table (Montgomery, 8 words) -> canonical reduced-radix table with `stride` words per entry
+template <class FrC>
+__global__ __launch_bounds__(256) void std_to_rr_table_kernel(const u32 *__restrict__ in, u32 n, u32 *__restrict__ out, u32 stride) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef FpR<FrC> R;
+    const R r = R::from_std(Fp<FrC>::load(in + (size_t)i * 8)); // canonical (< p)
+#pragma unroll
+    for (int l = 0; l < R::K; ++l) out[(size_t)i * stride + l] = r.v[l];
+    for (u32 l = R::K; l < stride; ++l) out[(size_t)i * stride + l] = 0;
+}
+// public-API entry: out_rr[i] = in_std[bitrev(i)] (x pre[bitrev(i)] for the forward coset transform), < 2p
+template <class FrC>
+__global__ __launch_bounds__(256) void ntt_load_rr_kernel(const u32 *__restrict__ in_std, unsigned lg, const u32 *__restrict__ pre_rr,
+                                                          u32 *__restrict__ out_rr) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << lg)) return;
+    typedef FpR<FrC> R;
+    const u32 j = lg ? (__brev(i) >> (32 - lg)) : 0;
+    R r = R::from_std_shift(Fp<FrC>::load(in_std + (size_t)j * 8));
+    if (pre_rr) r = R::mul(r, R::load(pre_rr + (size_t)j * R::K));
+    r.store(out_rr + (size_t)i * R::K);
+}
+// reduced radix (< 4p) -> arkworks format, optionally times a constant first
+template <class FrC>
+__global__ __launch_bounds__(256) void rr_to_std_kernel(const u32 *__restrict__ in_rr, size_t n, const u32 *__restrict__ scale_rr,
+                                                        u32 *__restrict__ out_std) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typedef FpR<FrC> R;
+    R r = R::load(in_rr + i * R::K);
+    if (scale_rr) r = R::mul(r, R::load(scale_rr));
+    r.to_std().store(out_std + i * 8);
 }
 
 // out[p] = in[bitrev(p)]
@@ -149,61 +177,49 @@ __global__ __launch_bounds__(256) void permute_bitrev_kernel(u32 *__restrict__ o
     q[1] = p[1];
 }
 
-// CSR row dot products: one lane per row (rows of the manta-pay circuits hold <= a handful of terms)
-template <class FrC>
-__global__ __launch_bounds__(256) void spmv_kernel(const u32 *__restrict__ row_ptr, const u32 *__restrict__ col,
-                                                   const u32 *__restrict__ val, const u32 *__restrict__ z,
-                                                   u32 *__restrict__ out, u32 m, size_t z_stride, size_t out_stride) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    z += (size_t)blockIdx.y * z_stride; // batch member
-    out += (size_t)blockIdx.y * out_stride;
-    typedef Fp<FrC> F;
-    F acc = F::zero();
-    const F one = F::one();
-    for (u32 k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
-        F c = F::load(val + (size_t)k * 8);
-        F x = F::load(z + (size_t)col[k] * 8);
-        acc = F::add(acc, c == one ? x : F::mul(x, c));
-    }
-    acc.store(out + (size_t)i * 8);
-}
-
-// the same for three matrices at once (blockIdx.z): A z, B z, C z of the witness map
+// the same for three matrices at once (blockIdx.z): A z, B z, C z of the witness map. Outputs are written in the
+// reduced-radix form of the NTT pipeline (9 words per element); matrix 0 (A) also fills the input-consistency rows
+// a[m + j] = z_j, j < P (mpc.rs:299-312).
 struct Csr3 {
     const u32 *row_ptr[3], *col[3], *val[3];
     u32 *out[3];
 };
 template <class FrC>
-__global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, size_t z_stride, size_t out_stride) {
+__global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, u32 P, size_t z_stride, size_t out_stride) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
     const int t = blockIdx.z;
-    const u32 *__restrict__ row_ptr = M.row_ptr[t], *__restrict__ col = M.col[t], *__restrict__ val = M.val[t];
+    if (i >= m + (t == 0 ? P : 0)) return;
     z += (size_t)blockIdx.y * z_stride; // batch member
     u32 *__restrict__ out = M.out[t] + (size_t)blockIdx.y * out_stride;
     typedef Fp<FrC> F;
+    typedef FpR<FrC> R;
     F acc = F::zero();
-    const F one = F::one();
-    for (u32 k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
-        F c = F::load(val + (size_t)k * 8);
-        F x = F::load(z + (size_t)col[k] * 8);
-        acc = F::add(acc, c == one ? x : F::mul(x, c));
+    if (i >= m) {
+        acc = F::load(z + (size_t)(i - m) * 8);
+    } else {
+        const u32 *__restrict__ row_ptr = M.row_ptr[t], *__restrict__ col = M.col[t], *__restrict__ val = M.val[t];
+        const F one = F::one();
+        for (u32 k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            F c = F::load(val + (size_t)k * 8);
+            F x = F::load(z + (size_t)col[k] * 8);
+            acc = F::add(acc, c == one ? x : F::mul(x, c));
+        }
     }
-    acc.store(out + (size_t)i * 8);
+    R::from_std_shift(acc).store(out + (size_t)i * R::K);
 }
 
+// a[i] = (a[i] b[i] - c[i]) * (g^D - 1)^-1, reduced-radix vectors (inputs < 4p, output < 2p)
 template <class FrC>
 __global__ __launch_bounds__(256) void qap_pointwise_kernel(u32 *__restrict__ a, const u32 *__restrict__ b,
-                                                            const u32 *__restrict__ c, const u32 *__restrict__ zinv,
+                                                            const u32 *__restrict__ c, const u32 *__restrict__ zinv_rr,
                                                             u32 n) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    a += (size_t)blockIdx.y * n * 8, b += (size_t)blockIdx.y * n * 8, c += (size_t)blockIdx.y * n * 8; // batch member
-    typedef Fp<FrC> F;
-    F ab = F::mul(F::load(a + (size_t)i * 8), F::load(b + (size_t)i * 8));
-    ab = F::sub(ab, F::load(c + (size_t)i * 8));
-    F::mul(ab, F::load(zinv)).store(a + (size_t)i * 8);
+    typedef FpR<FrC> R;
+    const size_t o = ((size_t)blockIdx.y * n + i) * R::K; // batch member
+    R ab = R::mul(R::load(a + o), R::load(b + o));            // 4 * 4 <= LIM: < 2p
+    ab = R::template sub<5>(ab, R::load(c + o));              // + 5p - c (c < 4p): < 7p
+    R::mul(ab, R::load(zinv_rr)).store(a + o);
 }
 
 template <class FrC> class FrEngineT : public FrEngine {
@@ -216,7 +232,12 @@ template <class FrC> class FrEngineT : public FrEngine {
         u32 *consts = nullptr;                    // [0] n^-1, [1] (g^n - 1)^-1
         u32 *t1_br = nullptr;                     // n^-1 * g^bitrev(p)   (between ifft and coset fft)
         u32 *t2_br = nullptr;                     // n^-1 * g^-bitrev(p)  (after the final coset ifft)
+        // the same tables in the NTT pipeline's reduced-radix form (canonical values): twiddles 12 words per entry
+        // (three 16-byte loads), everything else 9
+        u32 *tw_fwd_rr = nullptr, *tw_inv_rr = nullptr, *coset_fwd_rr = nullptr, *coset_inv_rr = nullptr, *consts_rr = nullptr,
+            *t1_br_rr = nullptr, *t2_br_rr = nullptr;
     };
+    static constexpr int RK = FpR<FrC>::K; // words per reduced-radix element
     int two_adicity() const override { return FrC::TWO_ADICITY; }
 
     static HF host_load(const u32 *w) {
@@ -298,6 +319,27 @@ template <class FrC> class FrEngineT : public FrEngine {
         }
         MG_HIP(hipDeviceSynchronize());
         hipFree(d_sq);
+        { // reduced-radix copies
+            struct T {
+                u32 **dst;
+                const u32 *src;
+                size_t cnt;
+                u32 stride;
+            } tabs[] = {{&d.tw_fwd_rr, d.tw_fwd, half, 12},    {&d.tw_inv_rr, d.tw_inv, half, 12},
+                        {&d.coset_fwd_rr, d.coset_fwd, n, RK}, {&d.coset_inv_rr, d.coset_inv, n, RK},
+                        {&d.consts_rr, d.consts, 2, RK},       {&d.t1_br_rr, d.t1_br, n, RK},
+                        {&d.t2_br_rr, d.t2_br, n, RK}};
+            for (T &t : tabs) {
+                MG_HIP(hipMalloc((void **)t.dst, t.cnt * t.stride * 4));
+                hipLaunchKernelGGL((std_to_rr_table_kernel<FrC>), dim3((u32)((t.cnt + 255) / 256)), dim3(256), 0, 0, t.src, (u32)t.cnt,
+                                   *t.dst, t.stride);
+            }
+            MG_HIP(hipDeviceSynchronize());
+            // the saturated copies the pipeline no longer reads are released (the public NTT keeps none of them either)
+            // (tw_fwd / tw_inv stay: the group-domain NTT reads them)
+            hipFree(d.t1_br), hipFree(d.t2_br), hipFree(d.coset_fwd), hipFree(d.coset_inv);
+            d.t1_br = d.t2_br = d.coset_fwd = d.coset_inv = nullptr;
+        }
         auto ins = domains_.emplace(log_n, d);
         *out = &ins.first->second;
         return MG_OK;
@@ -310,11 +352,17 @@ template <class FrC> class FrEngineT : public FrEngine {
         }();
         return v;
     }
-    // all stages of one transform over up to 3 vectors as LDS-fused passes of <= 10 stages
+    // all stages of one transform over up to 3 reduced-radix vectors as LDS-fused passes of <= 10 stages
     template <bool DIF>
-    static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw, unsigned lg, const u32 *post, hipStream_t s,
+    static void run_passes(u32 *d0, u32 *d1, u32 *d2, int nvec, const u32 *tw_rr, unsigned lg, const u32 *post_rr, hipStream_t s,
                            u32 batch = 1) {
         if (lg == 0) return;
+        static const bool attr_set = [] { // tiles of 2048 elements x 36 B = 72 KB: above the 64 KB default of dynamic LDS
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_rr<FrC, DIF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                36 * 2048);
+            return true;
+        }();
+        (void)attr_set;
         const unsigned npass = (lg + 9) / 10;
         unsigned done = 0;
         for (unsigned p = 0; p < npass; ++p) {
@@ -322,42 +370,51 @@ template <class FrC> class FrEngineT : public FrEngine {
             // DIT walks the stages upwards, DIF downwards
             const unsigned s0 = DIF ? (lg - done - ns + 1) : (done + 1);
             const unsigned lo_bits = s0 - 1;
-            unsigned cb = ns >= 11 ? 0 : 11 - ns; // tile <= 2048 elements = 64 KB of LDS
+            unsigned cb = ns >= 11 ? 0 : 11 - ns; // tile <= 2048 elements = 72 KB of LDS (two workgroups per CU)
             if (cb > lo_bits) cb = lo_bits;
             if (cb > 3) cb = 3;
             const u32 blocks = (u32)(((size_t)1 << lg) >> (ns + cb));
-            const size_t lds = ((size_t)32 << (ns + cb));
+            const size_t lds = ((size_t)(4 * RK) << (ns + cb));
             const bool last = p + 1 == npass;
             // one butterfly per thread and stage when the tile is full (2048 elements -> 1024 threads = 4 wavefronts
             // per SIMD): a pass is a chain of dependent multiplications, more resident waves hide its latency
             const u32 tot = 1u << (ns + cb);
             const u32 threads = ntt_threads() ? ntt_threads() : (tot >= 2048 ? 1024u : tot >= 128 ? tot / 2 : 64u);
-            hipLaunchKernelGGL((ntt_pass_kernel<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw, lg, s0,
-                               ns, cb, last ? post : (const u32 *)nullptr);
+            hipLaunchKernelGGL((ntt_pass_rr<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw_rr, lg, s0,
+                               ns, cb, last ? post_rr : (const u32 *)nullptr);
             done += ns;
         }
     }
 
+    // Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place on 2^log_n arkworks-format elements in HBM:
+    // converted to the reduced-radix form on the way in (bit-reversal and the coset pre-scaling folded into that
+    // kernel), DIT passes, scaled and converted back on the way out.
     int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) override {
         Domain *d;
         int rc = get_domain(log_n, &d);
         if (rc) return rc;
         const u32 n = 1u << log_n;
         const u32 gn = (n + 255) / 256;
-        if (!inverse && coset) hipLaunchKernelGGL((scale_table_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->coset_fwd, n);
-        if (log_n > 0) {
-            hipLaunchKernelGGL((bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, log_n);
-            const u32 *post = inverse ? (coset ? d->coset_inv : nullptr) : nullptr;
-            run_passes<false>(d_data, d_data, d_data, 1, inverse ? d->tw_inv : d->tw_fwd, log_n, post, s);
-            if (inverse && !coset) hipLaunchKernelGGL((scale_const_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->consts, n);
-        } else if (inverse && coset) {
-            hipLaunchKernelGGL((scale_table_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, d->coset_inv, n);
+        u32 *tmp = nullptr;
+        MG_HIP(hipMalloc((void **)&tmp, (size_t)n * RK * 4));
+        hipLaunchKernelGGL((ntt_load_rr_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, log_n,
+                           (!inverse && coset) ? d->coset_fwd_rr : (const u32 *)nullptr, tmp);
+        const u32 *post = inverse && coset && log_n > 0 ? d->coset_inv_rr : nullptr; // n^-1 g^-i, natural order
+        run_passes<false>(tmp, tmp, tmp, 1, inverse ? d->tw_inv_rr : d->tw_fwd_rr, log_n, post, s);
+        // plain ifft: times n^-1 in the conversion kernel (for n = 1 the coset tables are 1 as well)
+        hipLaunchKernelGGL((rr_to_std_kernel<FrC>), dim3(gn), dim3(256), 0, s, tmp, (size_t)n,
+                           (inverse && !coset && log_n > 0) ? d->consts_rr : (const u32 *)nullptr, d_data);
+        hipError_t e = hipStreamSynchronize(s); // the scratch vector is freed below
+        hipFree(tmp);
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "ntt transform", __FILE__, __LINE__);
+            return MG_ERR_HIP;
         }
         MG_HIP(hipGetLastError());
         return MG_OK;
     }
-    // QAP quotient in place: a, b, c hold the constraint evaluations; on return a holds the coefficients
-    // of h = (A B - C)/Z in BIT-REVERSED order (the h-query bases are stored in the same order).
+    // QAP quotient in place on reduced-radix vectors: a, b, c hold the constraint evaluations; on return a holds the
+    // coefficients of h = (A B - C)/Z in BIT-REVERSED order (the h-query bases are stored in the same order), < 2p.
     // ifft = DIF (natural -> bit-reversed) with n^-1 g^i folded into its last pass, coset fft = DIT
     // (bit-reversed -> natural): no permutation pass, 2 x ceil(lg/10) launches per transform, a/b/c batched.
     int qap_quotient(u32 *a, u32 *b, u32 *c, unsigned lg, hipStream_t s, u32 batch = 1) override {
@@ -366,41 +423,30 @@ template <class FrC> class FrEngineT : public FrEngine {
         if (rc) return rc;
         const u32 n = 1u << lg;
         if (lg == 0) { // degenerate domain: h = (a b - c) / (g - 1) scaled as the general path would
-            hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1, batch), dim3(256), 0, s, a, b, c, d->consts + 8, n);
+            hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1, batch), dim3(256), 0, s, a, b, c, d->consts_rr + RK, n);
             MG_HIP(hipGetLastError());
             return MG_OK;
         }
-        run_passes<true>(a, b, c, 3, d->tw_inv, lg, d->t1_br, s, batch);
-        run_passes<false>(a, b, c, 3, d->tw_fwd, lg, nullptr, s, batch);
-        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, b, c, d->consts + 8, n);
-        run_passes<true>(a, a, a, 1, d->tw_inv, lg, d->t2_br, s, batch);
+        run_passes<true>(a, b, c, 3, d->tw_inv_rr, lg, d->t1_br_rr, s, batch);
+        run_passes<false>(a, b, c, 3, d->tw_fwd_rr, lg, nullptr, s, batch);
+        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, b, c, d->consts_rr + RK, n);
+        run_passes<true>(a, a, a, 1, d->tw_inv_rr, lg, d->t2_br_rr, s, batch);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }
-    int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s, u32 batch = 1, size_t z_stride = 0,
-             size_t out_stride = 0) override {
-        if (m == 0) return MG_OK;
-        hipLaunchKernelGGL((spmv_kernel<FrC>), dim3((u32)((m + 255) / 256), batch), dim3(256), 0, s, M.row_ptr, M.col, M.val,
-                           d_z, d_out, (u32)m, z_stride, out_stride);
-        MG_HIP(hipGetLastError());
-        return MG_OK;
-    }
-    int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m,
+    int work_words() const override { return RK; }
+    int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m, u64 P,
               hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0) override {
         if (m == 0) return MG_OK;
         Csr3 M{{A.row_ptr, B.row_ptr, C.row_ptr}, {A.col, B.col, C.col}, {A.val, B.val, C.val}, {d_a, d_b, d_c}};
-        hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((m + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m,
+        hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((m + P + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m, (u32)P,
                            z_stride, out_stride);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }
-    int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) override {
-        Domain *d;
-        int rc = get_domain(log_n, &d);
-        if (rc) return rc;
-        const u32 n = 1u << log_n;
-        hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256), dim3(256), 0, s, d_a, d_b, d_c,
-                           d->consts + 8, n);
+    // reduced-radix vector -> arkworks format (tests / mg_witness_map)
+    int work_to_std(const u32 *d_rr, size_t n, u32 *d_std, hipStream_t s) override {
+        hipLaunchKernelGGL((rr_to_std_kernel<FrC>), dim3((u32)((n + 255) / 256)), dim3(256), 0, s, d_rr, n, (const u32 *)nullptr, d_std);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }

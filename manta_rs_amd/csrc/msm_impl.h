@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ sca
     const u32 src = (i < n) ? (map ? map[i] : i) : 0xffffffffu; // which scalar belongs to stored base i
     const bool have = i < n && src < n_scalars; // the scalar vector may be shorter than the base set: zip
     u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (have) {
+    if (have && mont == 2) { // the witness map's reduced-radix work form (9 words): one product with the integer 1
+        typedef FpR<FrC> R;
+        const Fp<FrC> f = R::load(scalars + (size_t)src * R::K).to_canonical();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = f.v[j];
+    } else if (have) {
         const uint4 *p = reinterpret_cast<const uint4 *>(scalars + (size_t)src * 8);
         uint4 a = p[0], b = p[1];
         s[0] = a.x, s[1] = a.y, s[2] = a.z, s[3] = a.w, s[4] = b.x, s[5] = b.y, s[6] = b.z, s[7] = b.w;
@@ -1107,7 +1112,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // ---------------------------------------------------------------- launch
-    int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, bool scalars_mont, int c_override,
+    int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, int scalar_mode, int c_override,
                    MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) override {
         if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig || batch == 0 || batch > 65535) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
@@ -1147,7 +1152,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             MG_HIP(hipMemsetAsync(d_count, 0, 4, s));
         }
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256), batch), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
-                           pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalars_mont ? 1 : 0, invalid,
+                           pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalar_mode, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
                            scalar_stride_words, seg_keys, d_count);
         if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),

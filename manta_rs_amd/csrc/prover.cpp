@@ -455,22 +455,21 @@ class ProverImpl : public Prover {
     // Witness map for the slot's w->k assignments (stored back to back, like the three work vectors: member q of
     // a batch lives V resp. D elements after member q-1); h ends up in w->a.
     int reserve_witness_map(ProveWs *w) {
-        const size_t D = (size_t)1 << log_d_, k = w->k;
+        const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words() * 4; // bytes per work element
         int rc;
-        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(3 * k * D * 32))) return rc;
+        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(3 * k * D * ww))) return rc;
         return MG_OK;
     }
     // everything after the upload of z, on w->stream (this is what the witness-map graph captures)
     int enqueue_witness_map_body(ProveWs *w) {
-        const size_t D = (size_t)1 << log_d_, k = w->k;
+        const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words(); // u32 per work element
         int rc;
         hipStream_t s = w->stream;
-        MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * 32, s));
-        u32 *a = w->a.as<u32>(), *b = a + k * D * 8, *c = b + k * D * 8, *zz = w->z.as<u32>();
-        const size_t zs = (size_t)V_ * 8, ds = D * 8;
-        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, s, (u32)k, zs, ds))) return rc;
-        // input-consistency rows: a[m + j] = z_j for j < P (mpc.rs:299-312)
-        MG_HIP(hipMemcpy2DAsync(a + (size_t)m_ * 8, D * 32, zz, V_ * 32, P_ * 32, k, hipMemcpyDeviceToDevice, s));
+        MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s)); // rows past m + P are zero (the all-zero words are 0 in the work form too)
+        u32 *a = w->a.as<u32>(), *b = a + k * D * ww, *c = b + k * D * ww, *zz = w->z.as<u32>();
+        const size_t zs = (size_t)V_ * 8, ds = D * ww;
+        // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j
+        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds))) return rc;
         // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
         if ((rc = fr_->qap_quotient(a, b, c, log_d_, s, (u32)k))) return rc;
         return MG_OK;
@@ -506,8 +505,12 @@ class ProverImpl : public Prover {
         if (!rc) {
             const size_t D = (size_t)1 << log_d_;
             std::vector<uint64_t> tmp(D * 4);
-            hipError_t e = hipMemcpyAsync(tmp.data(), w->a.p, D * 32, hipMemcpyDeviceToHost, w->stream);
+            u32 *d_std = nullptr; // h leaves the pipeline in the work form: convert for the host
+            hipError_t e = hipMalloc((void **)&d_std, D * 32);
+            if (e == hipSuccess && fr_->work_to_std(w->a.as<u32>(), D, d_std, w->stream)) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d_std, D * 32, hipMemcpyDeviceToHost, w->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+            if (d_std) hipFree(d_std);
             if (e != hipSuccess) {
                 set_last_hip_error(e, "witness_map_host", __FILE__, __LINE__);
                 rc = MG_ERR_HIP;
@@ -543,9 +546,9 @@ class ProverImpl : public Prover {
         return MsmArgs{{wide && a_bs_wide_ ? a_bs_wide_ : a_bs_, wide && b1_bs_wide_ ? b1_bs_wide_ : b1_bs_,
                         wide && b2_bs_wide_ ? b2_bs_wide_ : b2_bs_, wide && l_bs_wide_ ? l_bs_wide_ : l_bs_,
                         wide && h_bs_wide_ ? h_bs_wide_ : h_bs_},
-                       {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * 8},
+                       {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * (size_t)fr_->work_words()},
                        {zn, zn, zn, ln, hn},
-                       {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * 8}};
+                       {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * (size_t)fr_->work_words()}};
     }
     static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
 
@@ -566,7 +569,7 @@ class ProverImpl : public Prover {
             return MG_OK;
         }
         // the z MSMs see witness scalars (mostly 0 / 1 / small): compact their zero digits; h is dense
-        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i], i != 4);
+        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
     }
     int enqueue_part_a(ProveWs *w, bool use_graphs) {
         int rc;
@@ -641,7 +644,7 @@ class ProverImpl : public Prover {
         for (int i = 0; ok && i < 5; ++i) {
             w->mw[i]->capturing = true; // no event records inside the capture: the replay path records `done`
             ok = capture_segment(msm_stream(w, i), &w->g_msm[i], [&] {
-                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], true, 0, w->mw[i], w->k, a.stride[i], i != 4);
+                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
             });
             w->mw[i]->capturing = false;
             w->mw[i]->pending = 0;

@@ -19,19 +19,19 @@ class FrEngine {
     // In-place radix-2 NTT of 2^log_n Montgomery elements in HBM, natural order in/out
     // (ark-poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place semantics).
     virtual int transform(u32 *d_data, unsigned log_n, bool inverse, bool coset, hipStream_t s) = 0;
-    // out[i] = sum_k val[k] * z[col[k]] over row i, i < m
+    // Inside the witness-map pipeline an Fr element is held in the reduced-radix form of fpr_dev.h: work_words() u32 per
+    // element (9). The three products A z, B z, C z of the witness map in one launch, written in that form; the A
+    // vector also receives the input-consistency rows a[m + j] = z_j, j < P
     // (batch members: z vectors z_stride u32 apart, outputs out_stride u32 apart)
-    virtual int spmv(const DevCsr &M, const u32 *d_z, u32 *d_out, u64 m, hipStream_t s, u32 batch = 1,
-                     size_t z_stride = 0, size_t out_stride = 0) = 0;
-    // the three products A z, B z, C z of the witness map in one launch
-    virtual int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m,
+    virtual int work_words() const = 0;
+    virtual int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m, u64 P,
                       hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0) = 0;
-    // a, b, c = constraint evaluations over the domain -> a = coefficients of h = (AB - C)/Z in
-    // bit-reversed order (ifft, coset fft x3, pointwise, coset ifft; fused, permutation-free)
+    // a, b, c = constraint evaluations over the domain (work form) -> a = coefficients of h = (AB - C)/Z in
+    // bit-reversed order, work form, < 2p (ifft, coset fft x3, pointwise, coset ifft; fused, permutation-free)
     // batch > 1: a, b, c each hold `batch` vectors back to back
     virtual int qap_quotient(u32 *d_a, u32 *d_b, u32 *d_c, unsigned log_n, hipStream_t s, u32 batch = 1) = 0;
-    // a[i] = (a[i]*b[i] - c[i]) * (g^D - 1)^-1
-    virtual int qap_pointwise(u32 *d_a, const u32 *d_b, const u32 *d_c, unsigned log_n, hipStream_t s) = 0;
+    // work form -> arkworks format
+    virtual int work_to_std(const u32 *d_work, size_t n, u32 *d_std, hipStream_t s) = 0;
     // the domain's device twiddle table (omega^k or omega^-k, k < n/2, Montgomery) and n^-1 as a canonical integer
     virtual int domain_twiddles(unsigned log_n, bool inverse, const u32 **d_tw, u64 n_inv_canonical[4]) = 0;
     // host-side Fr helpers (Montgomery in/out unless noted)

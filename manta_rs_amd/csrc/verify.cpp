@@ -309,7 +309,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         int rc = e == hipSuccess ? MG_OK : MG_ERR_HIP;
         MsmWorkspace *ws = rc ? nullptr : g1_->ws_acquire();
         if (!rc && !ws) rc = MG_ERR_HIP;
-        if (!rc) rc = g1_->msm_launch(abc_bs_, d, n, true, 0, ws);
+        if (!rc) rc = g1_->msm_launch(abc_bs_, d, n, SCALARS_MONT, 0, ws);
         if (!rc) rc = g1_->msm_finish(ws, out);
         else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
         if (ws) g1_->ws_release(ws);
@@ -388,7 +388,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
             hipError_t e = hipMalloc((void **)&d, k * 32);
             if (e == hipSuccess) e = hipMemcpy(d, r_can.data(), k * 32, hipMemcpyHostToDevice);
             MsmWorkspace *ws = e == hipSuccess ? g1_->ws_acquire() : nullptr;
-            rc = ws ? g1_->msm_launch(cb, d, k, false, 0, ws) : MG_ERR_HIP;
+            rc = ws ? g1_->msm_launch(cb, d, k, SCALARS_CANONICAL, 0, ws) : MG_ERR_HIP;
             if (!rc) rc = g1_->msm_finish(ws, &csum);
             else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
             if (ws) g1_->ws_release(ws);
