@@ -236,6 +236,7 @@ template <class FrC> class FrEngineT : public FrEngine {
         // (three 16-byte loads), everything else 9
         u32 *tw_fwd_rr = nullptr, *tw_inv_rr = nullptr, *coset_fwd_rr = nullptr, *coset_inv_rr = nullptr, *consts_rr = nullptr,
             *t1_br_rr = nullptr, *t2_br_rr = nullptr;
+        u32 *scratch_rr = nullptr; // one work vector for the public in-place transform (guarded by scratch_mu_)
     };
     static constexpr int RK = FpR<FrC>::K; // words per reduced-radix element
     int two_adicity() const override { return FrC::TWO_ADICITY; }
@@ -395,8 +396,11 @@ template <class FrC> class FrEngineT : public FrEngine {
         if (rc) return rc;
         const u32 n = 1u << log_n;
         const u32 gn = (n + 255) / 256;
-        u32 *tmp = nullptr;
-        MG_HIP(hipMalloc((void **)&tmp, (size_t)n * RK * 4));
+        // the transform runs on a work vector owned by the domain: calls on one domain size are serialised (they are
+        // synchronous at the ABI anyway), none pays an allocation
+        std::lock_guard<std::mutex> g(scratch_mu_);
+        if (!d->scratch_rr) MG_HIP(hipMalloc((void **)&d->scratch_rr, (size_t)n * RK * 4));
+        u32 *tmp = d->scratch_rr;
         hipLaunchKernelGGL((ntt_load_rr_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, log_n,
                            (!inverse && coset) ? d->coset_fwd_rr : (const u32 *)nullptr, tmp);
         const u32 *post = inverse && coset && log_n > 0 ? d->coset_inv_rr : nullptr; // n^-1 g^-i, natural order
@@ -404,8 +408,7 @@ template <class FrC> class FrEngineT : public FrEngine {
         // plain ifft: times n^-1 in the conversion kernel (for n = 1 the coset tables are 1 as well)
         hipLaunchKernelGGL((rr_to_std_kernel<FrC>), dim3(gn), dim3(256), 0, s, tmp, (size_t)n,
                            (inverse && !coset && log_n > 0) ? d->consts_rr : (const u32 *)nullptr, d_data);
-        hipError_t e = hipStreamSynchronize(s); // the scratch vector is freed below
-        hipFree(tmp);
+        hipError_t e = hipStreamSynchronize(s); // the scratch vector is handed to the next caller after this
         if (e != hipSuccess) {
             set_last_hip_error(e, "ntt transform", __FILE__, __LINE__);
             return MG_ERR_HIP;
@@ -555,7 +558,7 @@ template <class FrC> class FrEngineT : public FrEngine {
     }
 
   private:
-    std::mutex mu_;
+    std::mutex mu_, scratch_mu_;
     std::map<unsigned, Domain> domains_;
 };
 
