@@ -49,7 +49,7 @@ MG_DEV u32 limb_at(const u32 (&s)[8], int i) { // dynamic index without scratch
 // order is irrelevant, the sort follows); every later stage reads the pair count from the device.
 // count == nullptr selects the fixed layout o = w*n + i with an `invalid` key for zero digits (library-sort path).
 template <class FrC>
-__global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
+__global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
                                                      int precomp, u32 tstride, int mont, u32 invalid,
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
                                                      const u32 *__restrict__ map, u32 n_scalars,
@@ -119,9 +119,21 @@ __global__ __launch_bounds__(256) void digits_kernel(const u32 *__restrict__ sca
             total += (u32)__popcll(__ballot(d != 0));
         }
     }
-    u32 base = 0;
-    if (lane == 0 && total) base = atomicAdd(count, total);
-    base = __shfl(base, 0, 64);
+    // one atomic per WORKGROUP (up to sixteen wavefronts add up through LDS): the counter is a single address shared
+    // by the whole grid, and atomics on it serialise at ~50 ns each -- one per wavefront (16 384 at 2^20 scalars) made the
+    // kernel 0.41 ms, one per 256 threads 0.28 ms
+    __shared__ u32 wave_tot[16], block_base;
+    const int wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    if (lane == 0) wave_tot[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 t = 0;
+        for (int q = 0; q < nwv; ++q) t += wave_tot[q];
+        block_base = t ? atomicAdd(count, t) : 0;
+    }
+    __syncthreads();
+    u32 base = block_base;
+    for (int q = 0; q < wv; ++q) base += wave_tot[q];
     // pass 2: write them, window-major inside the wavefront's slice
     const unsigned long long lt = (1ull << lane) - 1ull;
     u32 carry = 0, neg;
@@ -1151,7 +1163,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             d_count = ws->count.as<u32>();
             MG_HIP(hipMemsetAsync(d_count, 0, 4, s));
         }
-        hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, 256), batch), dim3(256), 0, s, d_scalars, (u32)n, pl.c, pl.W,
+        static const u32 dthreads_sparse = [] {
+            const char *e = getenv("MANTA_DIGITS_THREADS");
+            const int v = e ? atoi(e) : 0;
+            return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); // measured: 256 beats 512 and 1024 on the same box
+        }();
+        const u32 dthreads = d_count ? dthreads_sparse : 256u; // compacting path: fewer, larger workgroups = fewer atomics on the counter
+        hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, dthreads), batch), dim3(dthreads), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalar_mode, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
                            scalar_stride_words, seg_keys, d_count);
