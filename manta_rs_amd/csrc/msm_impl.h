@@ -36,17 +36,14 @@ namespace mg {
 // --------------------------------------------------------------------------------------------
 // K5: digits
 // --------------------------------------------------------------------------------------------
-MG_DEV u32 limb_at(const u32 (&s)[8], int i) { // dynamic index without scratch
-    u32 r = 0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r = (i == j) ? s[j] : r;
-    return r;
-}
 // One lane per (stored base, scalar vector of the batch): W signed c-bit digits -> (bucket key, base index | sign)
 // pairs. Zero digits produce NO pair: real witnesses are 40 % zeros and 25 % ones, so two thirds of all digits
 // vanish here instead of being carried through the sort. The surviving pairs are appended to the arrays in
 // wave-sized, window-major groups (one atomicAdd on `count` per wavefront, positions by ballot/popcount: the
 // order is irrelevant, the sort follows); every later stage reads the pair count from the device.
+// (A count -> scan -> write version without the atomic was measured too: the kernel is bound by the scalar loads and the
+// Montgomery conversion, not by the append, so running it twice costs more than the atomics do -- 2 x 105 + 46 us against
+// 127 us for 32 x 2^15 scalars.)
 // count == nullptr selects the fixed layout o = w*n + i with an `invalid` key for zero digits (library-sort path).
 template <class FrC>
 __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ scalars, u32 n, int c, int W, u32 B,
@@ -81,20 +78,17 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
         }
     }
     const u32 mask = (1u << c) - 1;
-    auto digit = [&](int w, u32 &carry, u32 &neg) -> u32 { // signed digit of window w (0 = nothing to add)
-        const int start = w * c;
-        const int limb = start >> 5, off = start & 31;
-        u64 v = limb < 8 ? (u64)limb_at(s, limb) : 0;
-        if (limb + 1 < 8) v |= (u64)limb_at(s, limb + 1) << 32;
-        u32 d = ((u32)(v >> off) & mask) + carry;
-        neg = 0;
-        carry = 0;
-        if (d > B) {
-            d = (1u << c) - d;
-            neg = 1;
-            carry = 1;
-        }
-        return d;
+    // signed digit of the NEXT window (0 = nothing to add): the low c bits, then the scalar moves right by c -- eight
+    // funnel shifts instead of a dynamically indexed limb pair (~90 instructions per window in selects, which made this
+    // kernel issue-bound at 5k instructions per scalar: 172 -> 127 us for 32 x 2^15 scalars, 40 -> 23 us for one 2^15)
+    auto next_digit = [&](u32 (&t)[8], u32 &carry, u32 &neg) -> u32 {
+        u32 d = (t[0] & mask) + carry;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) t[j] = __funnelshift_r(t[j], t[j + 1], c);
+        t[7] >>= c;
+        neg = d > B;
+        carry = neg;
+        return neg ? (1u << c) - d : d;
     };
     if (!count) { // fixed layout
         if (i >= n) return;
@@ -102,7 +96,7 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
         vals += (size_t)blockIdx.y * W * n;
         u32 carry = 0, neg;
         for (int w = 0; w < W; ++w) {
-            const u32 d = have ? digit(w, carry, neg) : 0;
+            const u32 d = next_digit(s, carry, neg); // s = 0 without a scalar
             const size_t o = (size_t)w * n + i;
             keys[o] = d ? key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1)) : invalid;
             vals[o] = d ? ((precomp ? ((u32)w * tstride + i) : i) | (neg << 31)) : 0;
@@ -113,11 +107,10 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
     const int lane = threadIdx.x & 63;
     u32 total = 0;
     {
-        u32 carry = 0, neg;
-        for (int w = 0; w < W; ++w) {
-            const u32 d = have ? digit(w, carry, neg) : 0;
-            total += (u32)__popcll(__ballot(d != 0));
-        }
+        u32 t[8], carry = 0, neg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = s[j];
+        for (int w = 0; w < W; ++w) total += (u32)__popcll(__ballot(next_digit(t, carry, neg) != 0));
     }
     // one atomic per WORKGROUP (up to sixteen wavefronts add up through LDS): the counter is a single address shared
     // by the whole grid, and atomics on it serialise at ~50 ns each -- one per wavefront (16 384 at 2^20 scalars) made the
@@ -138,7 +131,7 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
     const unsigned long long lt = (1ull << lane) - 1ull;
     u32 carry = 0, neg;
     for (int w = 0; w < W; ++w) {
-        const u32 d = have ? digit(w, carry, neg) : 0;
+        const u32 d = next_digit(s, carry, neg);
         const unsigned long long m = __ballot(d != 0);
         if (d) {
             const u32 o = base + (u32)__popcll(m & lt);
