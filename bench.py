@@ -9,7 +9,7 @@ BASELINE.json's metric has two halves and the default line carries both:
       registered (resident, with their 2^(c w) multiples) before timing.
   "Groth16 proofs/sec (manta-pay PrivateTransfer)"  (the line's `proofs` object): whole proofs of the shape-exact
       PrivateTransfer circuit (BN254, D = 2^16, V = 35 175, P = 27) through mg_groth16_prove / _prove_batch --
-      sequential latency, two host threads on one context, and batches of 32 -- with its own cpu_baseline.
+      sequential latency, two host threads on one context, and batches of 256 -- with its own cpu_baseline.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -443,7 +443,7 @@ def prove_cpu_baseline(ps, proofs, ncpu=8):
 
 
 def prove_bench(args, env, shape="private_transfer", full=True):
-    """The proofs/s half of the metric. full: sequential / 2 threads / batch 32 (N = 1); else only the batched stream."""
+    """The proofs/s half of the metric. full: sequential / 2 threads / batches of 256 (N = 1); else only the batched stream."""
     ps = ProveSetup(shape)
     D, V, P = ps.synth.SHAPES[shape]
     first = ps.api.Groth16.prove_with_randomness(ps.ctx, ps.c.z, ps.rs[0][0], ps.rs[0][1])
@@ -460,8 +460,10 @@ def prove_bench(args, env, shape="private_transfer", full=True):
         n2 = 3 * n1
         dt, _ = ps.timed(env, n2, 2, 1)
         res["two_threads"] = {"proofs_per_s": round(env.world * n2 / dt, 2), "host_threads": 2, "proofs_per_call": 1}
-    K = 32
-    nb = 256 * (2 if full else 1)  # configs[4]: batches of 256 proofs streamed through per-GPU pipelines
+    # configs[4]: batches of 256 proofs streamed through per-GPU pipelines -- one mg_groth16_prove_batch call per batch (the
+    # library runs it as passes of ~29 proofs, three in flight); two host threads keep a second batch queued behind the first
+    K = 256
+    nb = K * (4 if full else 2)
     dt, pb = ps.timed(env, nb, 2, K)
     assert pb[0] == first
     res["batched"] = {"proofs_per_s": round(env.world * nb / dt, 2), "host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,

@@ -16,8 +16,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <shared_mutex>
+#include <thread>
 #include <vector>
 
 namespace mg {
@@ -661,13 +664,54 @@ class ProverImpl : public Prover {
         return prove_batch(1, z, r, s, proof_out);
     }
 
-    // k proofs of this circuit in ONE pass of the GPU pipeline (k = 1: a single proof). The kernels are the same;
-    // every (assignment, window) pair is its own bucket segment and the NTT / SpMV grids get a batch dimension,
-    // so a batch costs one chain of latency-bound launches instead of k. (Splitting a batch into two passes in
-    // flight, to assemble one half on the host while the GPU works on the other, was measured and gains nothing:
-    // the smaller passes lose what the overlap wins. Two calling threads with a batch each do overlap.)
+    // k proofs of this circuit. Up to BATCH_CHUNK of them are ONE pass of the GPU pipeline (k = 1: a single proof): the
+    // kernels are the same; every (assignment, window) pair is its own bucket segment and the NTT / SpMV grids get a
+    // batch dimension, so a pass costs one chain of latency-bound launches instead of k. A longer batch is streamed
+    // through as passes of BATCH_CHUNK with BATCH_INFLIGHT of them in flight on their own slots (library threads): the
+    // witness-map head and the bucket-reduce tail of one pass then overlap the accumulate kernels of the others --
+    // measured on MI355X for the PrivateTransfer shape, passes of 32: 2 280 proofs/s with one pass in flight, 3 350 with
+    // two, 3 820 with three, 3 680 with four; passes of 16 or 64 are no better. (Splitting ONE pass of 32 into two
+    // halves in flight was measured too and gains nothing: the smaller passes lose what the overlap wins.)
+    static constexpr u64 BATCH_CHUNK = 32;
+    static int batch_inflight() {
+        static const int n = [] {
+            const char *e = std::getenv("MANTA_BATCH_INFLIGHT");
+            const int v = e ? std::atoi(e) : 3;
+            return v >= 1 && v <= (int)MAX_IDLE_SLOTS ? v : 3;
+        }();
+        return n;
+    }
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
+        if (k64 <= BATCH_CHUNK) return prove_pass(k64, z, r, s, proofs_out);
+        // passes of equal size, their number a multiple of the passes in flight (256 proofs -> 9 passes of 29/28, not 8 of 32
+        // that leave one of three workers idle for the last round)
+        const u64 fl = (u64)batch_inflight();
+        u64 chunks = (k64 + BATCH_CHUNK - 1) / BATCH_CHUNK;
+        if (chunks > fl && chunks % fl) chunks += fl - chunks % fl;
+        const u64 per = (k64 + chunks - 1) / chunks;
+        chunks = (k64 + per - 1) / per;
+        const size_t pbytes = 2 * (size_t)g1_->point_bytes(true) + (size_t)g2_->point_bytes(true); // compressed A, B, C
+        std::atomic<u64> next{0};
+        std::atomic<int> first_rc{MG_OK};
+        auto worker = [&] {
+            for (;;) {
+                const u64 c = next.fetch_add(1);
+                if (c >= chunks || first_rc.load() != MG_OK) return;
+                const u64 lo = c * per, n = std::min(per, k64 - lo);
+                const int rc = prove_pass(n, z + lo * V_ * 4, r + lo * 4, s + lo * 4, proofs_out + lo * pbytes);
+                int ok = MG_OK;
+                if (rc) first_rc.compare_exchange_strong(ok, rc);
+            }
+        };
+        const int nthreads = (int)std::min<u64>(fl, chunks);
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+        worker();
+        for (auto &t : th) t.join();
+        return first_rc.load();
+    }
+    int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) {
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
         locks.emplace_back(shape_mu_);

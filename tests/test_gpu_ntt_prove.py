@@ -264,6 +264,26 @@ def test_prove_batch_matches_single_proofs_and_oracle(gpu, curve, k):
     assert gpu.Groth16.prove_with_randomness(ctx, zs[0].z, rs[0], rs[k]) == O.groth16_prove(zs[0], pk, rs[0], rs[k])
 
 
+def test_prove_batch_longer_than_a_pass_is_streamed(gpu):
+    """k = 70 > 32: the library streams the batch as passes of 32, 32 and 6 with three in flight on their own slots;
+    every proof is still the bytes of the single-proof path, and a sample is checked against the oracle."""
+    curve = 0
+    c0 = synth.make_circuit(curve, 300, 260, 4, seed=61)
+    pk = O.groth16_setup(c0, H.toxic(curve, seed=15))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c0))
+    k = 70
+    zs = [synth.reassign(c0, seed=300 + q) for q in range(k)]
+    rs = H.rand_fr_mont(curve, 2 * k, seed=81)
+    zk = np.stack([z.z for z in zs])
+    single = [gpu.Groth16.prove_with_randomness(ctx, zs[q].z, rs[q], rs[k + q]) for q in range(k)]
+    for rep in range(4):
+        got = gpu.Groth16.prove_batch(ctx, zk, rs[:k], rs[k:])
+        assert got == single, rep
+    for q in (0, 31, 32, 63, 64, 69):
+        assert single[q] == O.groth16_prove(zs[q], pk, rs[q], rs[k + q]), q
+
+
 def test_prove_batch_real_shape_with_r_zero_member(gpu):
     """ToPrivate-shape circuit, batch of 4 with one member's r = 0 (that member skips g1_b like create_proof)."""
     curve = 0
