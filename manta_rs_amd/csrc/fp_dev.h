@@ -53,6 +53,38 @@ MG_DEV void acc_shr32(Acc96 &c) {
     c.lo = (c.lo >> 32) | ((u64)c.hi << 32);
     c.hi = 0;
 }
+// Q accumulators advanced in ONE asm block (see Fp::mul_many): the compiler's scheduler otherwise regroups separate blocks
+// into one chain per accumulator, which is the dependent sequence the interleaving is meant to avoid
+MG_DEV void mac3_vv(Acc96 &c0, Acc96 &c1, Acc96 &c2, u32 a0, u32 b0, u32 a1, u32 b1, u32 a2, u32 b2) {
+    asm("v_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_mad_u64_u32 %4, vcc, %10, %11, %4\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc"
+        : "+v"(c0.lo), "+v"(c0.hi), "+v"(c1.lo), "+v"(c1.hi), "+v"(c2.lo), "+v"(c2.hi)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2)
+        : "vcc");
+}
+MG_DEV void mac3_vs(Acc96 &c0, Acc96 &c1, Acc96 &c2, u32 a0, u32 a1, u32 a2, u32 k) {
+    asm("v_mad_u64_u32 %0, vcc, %6, %9, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %2, vcc, %7, %9, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc\n\t"
+        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_addc_co_u32 %5, vcc, 0, %5, vcc"
+        : "+v"(c0.lo), "+v"(c0.hi), "+v"(c1.lo), "+v"(c1.hi), "+v"(c2.lo), "+v"(c2.hi)
+        : "v"(a0), "v"(a1), "v"(a2), "s"(k)
+        : "vcc");
+}
+MG_DEV void mac2_vv(Acc96 &c0, Acc96 &c1, u32 a0, u32 b0, u32 a1, u32 b1) {
+    asm("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"
+        : "+v"(c0.lo), "+v"(c0.hi), "+v"(c1.lo), "+v"(c1.hi)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1)
+        : "vcc");
+}
+MG_DEV void mac2_vs(Acc96 &c0, Acc96 &c1, u32 a0, u32 a1, u32 k) {
+    asm("v_mad_u64_u32 %0, vcc, %4, %6, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %6, %2\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"
+        : "+v"(c0.lo), "+v"(c0.hi), "+v"(c1.lo), "+v"(c1.hi)
+        : "v"(a0), "v"(a1), "s"(k)
+        : "vcc");
+}
 
 // C supplies: static constexpr int N; static constexpr u32 P[N], R[N] (one), R2[N], INV;
 template <class C> struct Fp {
@@ -181,6 +213,55 @@ template <class C> struct Fp {
     }
     static MG_DEV Fp sqr(const Fp &a) { return mul(a, a); }
 
+    // Q independent Montgomery products in ONE instruction stream (the Karatsuba terms of an Fq2 product, the two halves
+    // of an Fq2-by-Fq product). A single product is one chain of dependent multiply-adds; with a lone wavefront on the SIMD
+    // (the wave-cooperative pairing, pairing_coop.h) each costs ~12 cycles, and Q interleaved chains issue back to back.
+    template <int Q> static MG_DEV void mul_many(const Fp (&a)[Q], const Fp (&b)[Q], Fp (&r)[Q]) {
+        static_assert(Q == 2 || Q == 3, "two or three interleaved products");
+        Acc96 c[Q];
+        u32 m[Q][N];
+        Fp t[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) c[q] = Acc96{0, 0};
+        auto vv = [&](int i, int j) {
+            if constexpr (Q == 3) mac3_vv(c[0], c[1], c[2], a[0].v[i], b[0].v[j], a[1].v[i], b[1].v[j], a[2].v[i], b[2].v[j]);
+            else mac2_vv(c[0], c[1], a[0].v[i], b[0].v[j], a[1].v[i], b[1].v[j]);
+        };
+        auto vs = [&](int i, u32 k) {
+            if constexpr (Q == 3) mac3_vs(c[0], c[1], c[2], m[0][i], m[1][i], m[2][i], k);
+            else mac2_vs(c[0], c[1], m[0][i], m[1][i], k);
+        };
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int i = 0; i < k; ++i) {
+                vv(i, k - i);
+                vs(i, C::P[k - i]);
+            }
+            vv(k, 0);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) m[q][k] = (u32)c[q].lo * C::INV;
+            vs(k, C::P[0]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) acc_shr32(c[q]);
+        }
+#pragma unroll
+        for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+            for (int i = k - N + 1; i < N; ++i) {
+                vv(i, k - i);
+                vs(i, C::P[k - i]);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                t[q].v[k - N] = (u32)c[q].lo;
+                acc_shr32(c[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) r[q] = reduce_once(t[q], (u32)c[q].lo);
+    }
+
     // Montgomery -> canonical (ark-ff into_repr): a * 1 * R^-1
     static MG_DEV Fp from_mont(const Fp &a) {
         Fp o = zero();
@@ -239,7 +320,7 @@ template <class C> struct Fp2 {
     B c0, c1;
     static MG_DEV Fp2 zero() { return Fp2{B::zero(), B::zero()}; }
     static MG_DEV Fp2 one() { return Fp2{B::one(), B::zero()}; }
-    MG_DEV bool is_zero() const { return c0.is_zero() & c1.is_zero(); }
+    MG_DEV bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
     MG_DEV bool operator==(const Fp2 &o) const { return (c0 == o.c0) & (c1 == o.c1); }
     static MG_DEV Fp2 add(const Fp2 &a, const Fp2 &b) { return Fp2{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
     static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return Fp2{B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }

@@ -1,0 +1,470 @@
+// Wave-cooperative pairing: ONE WAVEFRONT per pairing, the Fq12 state in LDS, one Fq2 product per lane.
+//
+// pairing_dev.h runs a pairing on one lane; that is the right shape for hundreds of independent pairings but leaves a
+// single Groth16 verification (three Miller loops and one final exponentiation) with 54 dependent Fq
+// products per Fq12 product: 45.7 ms per verification on MI355X, 26.9 ms of it the final exponentiation on ONE lane
+// (profiles/r02_verify_*.txt). Here an Fq12 is a polynomial of degree < 6 in w over Fq2 (w^6 = xi, w^2 = v of the
+// arkworks tower), a product is the 36 coefficient products a_i b_j on 36 lanes followed by six lanes folding them
+// (c_m = sum_{i+j=m} + xi sum_{i+j=m+6}), i.e. ONE Fq2 product deep instead of eighteen; line multiplications use 18 lanes,
+// Frobenius maps six, the G2 doubling / addition steps of G2Prepared up to five. The arithmetic (canonical saturated
+// Montgomery Fp<> of fp_dev.h) and every formula are those of pairing_dev.h, so results are the same bytes -- the
+// committed verifying keys of the reference stay the known-answer test.
+//
+// LDS layout: slots of one Fq2 (2N words). Slots 0..35 hold the coefficient products; Fq12 register r occupies the six
+// slots REG0 + 6 r .. in arkworks' memory order c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (slot s = 3 i + j holds the
+// coefficient of w^(i + 2 j)). A workgroup is exactly one wavefront, so __syncthreads() is a wave-level fence.
+#pragma once
+#include "pairing_dev.h"
+
+namespace mg {
+
+extern __shared__ u32 mg_pairing_lds[];
+
+template <class K> struct PairingWave {
+    typedef Pairing<K> P;
+    typedef typename P::F F;
+    typedef typename P::F2 F2;
+    typedef typename P::F12 F12;
+    static constexpr int W = P::F2W, N = P::N;
+    static constexpr int PROD = 0, REG0 = 36;
+    static constexpr int R(int r) { return REG0 + 6 * r; }
+    static constexpr size_t lds_bytes(int regs) { return (size_t)(REG0 + 6 * regs) * W * 4; }
+    // (everything is static and addresses the workgroup's dynamic LDS block directly: the compiler then emits ds_read /
+    // ds_write instead of flat accesses, and the out-of-line functions take their few integer arguments in registers)
+    static MG_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
+    static MG_DEV int wave_id() { return (int)(threadIdx.x >> 6); }
+    // LDS block of a workgroup: [wave 0: products + its registers][wave 1 of the Miller kernel: the G2 arithmetic's slots]
+    // [ring of RING coefficient triples][produced, consumed]
+    static constexpr int MILLER_WORDS = (REG0 + 6) * W, RING = 4;
+    static MG_DEV u32 *base() { return mg_pairing_lds + wave_id() * MILLER_WORDS; }
+    static MG_DEV F2 ld(int slot) { return F2::load(base() + slot * W); }
+    static MG_DEV void st(int slot, const F2 &v) { v.store(base() + slot * W); }
+    // Fq2 products inlined down to the Fq product (a real function with its operands in VGPRs, fp_dev.h); pairing_dev.h's
+    // out-of-line Fq2 helpers pass their operands through scratch memory, which costs more than the arithmetic here
+    // (by value: operands and result travel in VGPRs; the three Karatsuba products run interleaved, Fp::mul_many)
+    static __device__ __noinline__ F2 mul2(const F2 a, const F2 b) {
+        const F x[3] = {a.c0, a.c1, F::add(a.c0, a.c1)}, y[3] = {b.c0, b.c1, F::add(b.c0, b.c1)};
+        F v[3];
+        F::template mul_many<3>(x, y, v);
+        return F2{F::sub(v[0], v[1]), F::sub(F::sub(v[2], v[0]), v[1])};
+    }
+    static __device__ __noinline__ F2 mul2_fp(const F2 a, const F k) {
+        const F x[2] = {a.c0, a.c1}, y[2] = {k, k};
+        F v[2];
+        F::template mul_many<2>(x, y, v);
+        return F2{v[0], v[1]};
+    }
+    static MG_DEV F2 sqr2(const F2 &a) { return mul2(a, a); }
+    static MG_DEV F2 mul2_xi(const F2 &a) {
+        return F2{F::sub(P::small_mul(a.c0), a.c1), F::add(P::small_mul(a.c1), a.c0)};
+    }
+    // A wavefront runs in lockstep and its LDS operations complete in order, so lanes exchange data through LDS with a
+    // compiler-level fence only -- no s_barrier. (The Miller kernel runs two wavefronts with different programs in one
+    // workgroup; a workgroup barrier here would have to be matched instruction for instruction.)
+    static MG_DEV void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    static MG_DEV int slot_of(int m) { return 3 * (m & 1) + (m >> 1); } // exponent of w -> slot inside a register
+
+    // a / 2: the Montgomery representative halves with the value
+    static MG_DEV F half(const F &a) {
+        u32 t[N];
+        const u32 odd = 0u - (a.v[0] & 1u);
+        u64 c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c += (u64)a.v[i] + (K::Fq::P[i] & odd);
+            t[i] = (u32)c;
+            c >>= 32;
+        }
+        F r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> 1) | ((i + 1 < N ? t[i + 1] : (u32)c) << 31);
+        return r;
+    }
+    static MG_DEV F2 half2(const F2 &a) { return F2{half(a.c0), half(a.c1)}; }
+    static MG_DEV F2 triple(const F2 &a) { return P::add(P::dbl(a), a); }
+
+    // Twelve lanes, one per Fq component of the result: coefficient m = sum over i of the product in slot 6 i + ((m - i) mod 6),
+    // for the columns that were filled (bit j of `cols`). The products that wrap around w^6 = xi were multiplied by xi by the
+    // lane that made them, so this is a plain sum of at most six Fq values -- the first version folded on six lanes with the
+    // xi multiplication at the end and spent more time here (6.6 us) than in the 36 products (5 us).
+    static __device__ __noinline__ void fold(int d, u32 cols) {
+        if (lane_id() < 12) {
+            const int m = lane_id() >> 1, comp = lane_id() & 1;
+            F acc = F::zero();
+#pragma unroll 1
+            for (int i = 0; i < 6; ++i) {
+                int j = m - i;
+                j += j < 0 ? 6 : 0;
+                if ((cols >> j) & 1u) acc = F::add(acc, F::load(base() + (PROD + 6 * i + j) * W + comp * N));
+            }
+            acc.store(base() + (d + slot_of(m)) * W + comp * N);
+        }
+        sync();
+    }
+    // d = a * b (registers; d may be a or b)
+    static __device__ __noinline__ void mul12(int d, int a, int b) {
+        if (lane_id() < 36) {
+            const int i = lane_id() / 6, j = lane_id() - 6 * i;
+            F2 v = mul2(ld(a + slot_of(i)), ld(b + slot_of(j)));
+            if (i + j >= 6) v = mul2_xi(v);
+            st(PROD + lane_id(), v);
+        }
+        sync();
+        fold(d, 0x3fu);
+    }
+    // f *= line(P), arkworks `ell`: D-type twist (BN254) c0 py + (c1 px) w + c2 w^3 (mul_by_034), M-type (BLS12-381)
+    // c0 + (c1 px) w^2 + (c2 py) w^3 (mul_by_014); co = the coefficient triple in global memory
+    static __device__ __noinline__ void ell(int f, const u32 *co, const F &px, const F &py) {
+        if (lane_id() < 18) {
+            const int i = lane_id() / 3, t = lane_id() - 3 * i;
+            F2 c = F2::load(co + t * W);
+            const int plain = K::TWIST_D ? 2 : 0, with_py = K::TWIST_D ? 0 : 2;
+            if (t != plain) c = mul2_fp(c, F::select(t == with_py, py, px));
+            const int j = K::TWIST_D ? (t == 2 ? 3 : t) : (t == 0 ? 0 : t + 1);
+            F2 v = mul2(ld(f + slot_of(i)), c);
+            if (i + j >= 6) v = mul2_xi(v);
+            st(PROD + 6 * i + j, v);
+        }
+        sync();
+        fold(f, K::TWIST_D ? 0x0bu : 0x0du);
+    }
+    static MG_DEV void set_one(int d) {
+        if (lane_id() < 6) st(d + lane_id(), lane_id() == 0 ? F2::one() : F2::zero());
+        sync();
+    }
+    static MG_DEV void copy12(int d, int a) {
+        if (lane_id() < 6) st(d + lane_id(), ld(a + lane_id()));
+        sync();
+    }
+    static MG_DEV void conj12(int d) { // the p^6-power Frobenius: odd powers of w change sign
+        if (lane_id() >= 3 && lane_id() < 6) st(d + lane_id(), P::neg(ld(d + lane_id())));
+        sync();
+    }
+    // x -> x^(q^k), in place
+    template <int k> static __device__ __noinline__ void frob12(int d) {
+        if (lane_id() < 6) {
+            const int i = lane_id() / 3, j = lane_id() - 3 * i;
+            F2 v = ld(d + lane_id());
+            if (k & 1) v = P::conj(v);
+            const auto &ca = k == 1 ? K::FROB6A_1 : (k == 2 ? K::FROB6A_2 : K::FROB6A_3);
+            const auto &cb = k == 1 ? K::FROB6B_1 : (k == 2 ? K::FROB6B_2 : K::FROB6B_3);
+            const auto &cg = k == 1 ? K::FROB12_1 : (k == 2 ? K::FROB12_2 : K::FROB12_3);
+            if (j) v = mul2(v, F2::select(j == 1, P::f2const(ca), P::f2const(cb)));
+            if (i) v = mul2(v, P::f2const(cg));
+            st(d + lane_id(), v);
+        }
+        sync();
+    }
+    // 1/a in Fq by the binary extended Euclidean algorithm on the Montgomery representative y = a R (an integer below p):
+    // y^-1 = a^-1 R^-1, and one Montgomery product with R^3 turns it into a^-1 R. ~500 shift / subtract steps of 8-word
+    // integers instead of the ~380 dependent Montgomery products of Fermat's a^(p-2) (fp_dev.h Fp::inv: 0.5 ms on one lane).
+    // a != 0 (an Fq12 norm of a non-zero element).
+    static __device__ __noinline__ F inv_euclid(const F &a) {
+        F u = a, v, x1 = F::zero(), x2 = F::zero();
+#pragma unroll
+        for (int i = 0; i < N; ++i) v.v[i] = K::Fq::P[i];
+        x1.v[0] = 1; // plain integers from here on: u x1' = y ... invariants  u = x1 y, v = x2 y (mod p)
+        auto is_one = [](const F &t) {
+            u32 r = t.v[0] ^ 1u;
+#pragma unroll
+            for (int i = 1; i < N; ++i) r |= t.v[i];
+            return r == 0;
+        };
+        auto shr1 = [](F &t) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) t.v[i] = (t.v[i] >> 1) | ((i + 1 < N ? t.v[i + 1] : 0u) << 31);
+        };
+        auto geq = [](const F &s, const F &t) { // s >= t
+            bool ge = true;
+#pragma unroll
+            for (int i = 0; i < N; ++i) ge = s.v[i] != t.v[i] ? s.v[i] > t.v[i] : ge;
+            return ge;
+        };
+        auto isub = [](F &s, const F &t) { // plain s -= t (s >= t)
+            u32 bw = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const u64 dd = (u64)s.v[i] - t.v[i] - bw;
+                s.v[i] = (u32)dd;
+                bw = (u32)(dd >> 63);
+            }
+        };
+        while (!is_one(u) && !is_one(v)) {
+            while (!(u.v[0] & 1u)) shr1(u), x1 = half(x1);
+            while (!(v.v[0] & 1u)) shr1(v), x2 = half(x2);
+            if (geq(u, v)) isub(u, v), x1 = F::sub(x1, x2);
+            else isub(v, u), x2 = F::sub(x2, x1);
+        }
+        const F yinv = is_one(u) ? x1 : x2;
+        F r2;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r2.v[i] = K::Fq::R2[i];
+        return F::mul(yinv, F::mul(r2, r2)); // R^3 = mont(R^2, R^2)
+    }
+    // the one inversion of a final exponentiation stays on lane 0: pairing_dev.h's tower inversion (Fq12 -> Fq6 -> Fq2 -> Fq)
+    // with the Fq inverse above
+    static __device__ __noinline__ void inv12(int d, int a) {
+        if (lane_id() == 0) {
+            typedef typename P::F6 F6;
+            F12 x, y;
+            P::load12(x, base() + a * W);
+            F6 t, s6, ti;
+            P::mul6(t, x.c0, x.c0);
+            P::mul6(s6, x.c1, x.c1);
+            t = P::sub6(t, P::mulv6(s6));
+            { // inv6 with the Fq2 inverse through inv_euclid
+                const F2 t0 = P::sub(P::sqr(t.c0), P::mul_xi(P::mul(t.c1, t.c2)));
+                const F2 t1 = P::sub(P::mul_xi(P::sqr(t.c2)), P::mul(t.c0, t.c1));
+                const F2 t2 = P::sub(P::sqr(t.c1), P::mul(t.c0, t.c2));
+                const F2 dd = P::add(P::mul(t.c0, t0), P::mul_xi(P::add(P::mul(t.c2, t1), P::mul(t.c1, t2))));
+                const F n = inv_euclid(F::add(F::sqr(dd.c0), F::sqr(dd.c1)));
+                const F2 di{F::mul(dd.c0, n), F::neg(F::mul(dd.c1, n))};
+                ti.c0 = P::mul(t0, di), ti.c1 = P::mul(t1, di), ti.c2 = P::mul(t2, di);
+            }
+            P::mul6(y.c0, x.c0, ti);
+            P::mul6(s6, x.c1, ti);
+            y.c1 = P::neg6(s6);
+            P::store12(y, base() + d * W);
+        }
+        sync();
+    }
+    // d = a^|x| (d != a)
+    static __device__ __noinline__ void pow_x(int d, int a) {
+        copy12(d, a);
+        int top = 63;
+        while (!((K::X >> top) & 1)) --top;
+#pragma unroll 1
+        for (int i = top - 1; i >= 0; --i) {
+            mul12(d, d, d);
+            if ((K::X >> i) & 1) mul12(d, d, a);
+        }
+    }
+    static MG_DEV void exp_by_neg_x(int d, int a) {
+        pow_x(d, a);
+        if constexpr (!K::X_NEG) conj12(d);
+    }
+    static MG_DEV void exp_by_x(int d, int a) {
+        pow_x(d, a);
+        if constexpr (K::X_NEG) conj12(d);
+    }
+    static constexpr int FINAL_EXP_REGS = 19;
+    // register 0 := final_exponentiation(register 0); registers 1..18 are scratch. The sequence is pairing_dev.h's
+    // final_exp (ark-ec 0.3 models/{bn,bls12}/mod.rs), squarings as products.
+    static __device__ void final_exp() {
+        const int f = R(0), f1 = R(1), f2 = R(2), r = R(3);
+        copy12(f1, f);
+        conj12(f1);
+        inv12(f2, f);
+        mul12(r, f1, f2);
+        copy12(f2, r);
+        frob12<2>(r);
+        mul12(r, r, f2);
+        if constexpr (K::BN) {
+            const int y0 = R(4), y1 = R(5), y2 = R(6), y3 = R(7), y4 = R(8), y5 = R(9), y6 = R(10), y7 = R(11), y8 = R(12),
+                      y9 = R(13), y10 = R(14), y11 = R(15), y12 = R(16), y13 = R(17), y14 = R(18), y15 = R(1);
+            exp_by_neg_x(y0, r);
+            mul12(y1, y0, y0);
+            mul12(y2, y1, y1);
+            mul12(y3, y2, y1);
+            exp_by_neg_x(y4, y3);
+            mul12(y5, y4, y4);
+            exp_by_neg_x(y6, y5);
+            conj12(y3);
+            conj12(y6);
+            mul12(y7, y6, y4);
+            mul12(y8, y7, y3);
+            mul12(y9, y8, y1);
+            mul12(y10, y8, y4);
+            mul12(y11, y10, r);
+            copy12(y12, y9);
+            frob12<1>(y12);
+            mul12(y13, y12, y11);
+            frob12<2>(y8);
+            mul12(y14, y8, y13);
+            conj12(r);
+            mul12(y15, r, y9);
+            frob12<3>(y15);
+            mul12(f, y15, y14);
+        } else {
+            const int y0 = R(4), y1 = R(5), y2 = R(6), y3 = R(7), y4 = R(8), y5 = R(9);
+            mul12(y0, r, r);
+            conj12(y0);
+            exp_by_x(y5, r);
+            mul12(y1, y5, y5);
+            mul12(y3, y0, y5);
+            exp_by_x(y0, y3);
+            exp_by_x(y2, y0);
+            exp_by_x(y4, y2);
+            mul12(y4, y4, y1);
+            exp_by_x(y1, y4);
+            conj12(y3);
+            mul12(y1, y1, y3);
+            mul12(y1, y1, r);
+            copy12(y3, r);
+            conj12(y3);
+            mul12(y0, y0, r);
+            frob12<3>(y0);
+            mul12(y4, y4, y3);
+            frob12<1>(y4);
+            mul12(y5, y5, y2);
+            frob12<2>(y5);
+            mul12(y5, y5, y0);
+            mul12(y5, y5, y4);
+            mul12(f, y5, y1);
+        }
+    }
+    static MG_DEV signed char loop_digit(int i) {
+        signed char dgt = 0;
+#pragma unroll
+        for (int k = 0; k < K::LOOP_LEN; ++k) dgt = (k == i) ? K::LOOP[k] : dgt;
+        return dgt;
+    }
+    // ---- the ring through which wave 1 of the Miller kernel (G2Prepared::from(Q), below) hands line coefficients to wave 0
+    static constexpr int PREP_WORDS_ = 8 * W; // = PREP_SLOTS * W (the enum is declared further down)
+    static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * P::COEFFW;
+    static constexpr size_t miller_lds_bytes() { return (size_t)(CNT_OFF + 2) * 4; }
+    static MG_DEV volatile u32 *counters() { return (volatile u32 *)(mg_pairing_lds + CNT_OFF); } // [0] produced, [1] consumed
+    static MG_DEV u32 *ring_slot(int o) { return mg_pairing_lds + RING_OFF + (o % RING) * P::COEFFW; }
+    static MG_DEV const u32 *ring_acquire(int o) { // consumer: triple number o is complete
+        while ((int)counters()[0] <= o) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return ring_slot(o);
+    }
+    static MG_DEV void ring_release(int o) { // consumer: done with triples 0..o
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane_id() == 0) counters()[1] = (u32)(o + 1);
+    }
+    static MG_DEV u32 *ring_reserve(int o) { // producer: the slot of triple o is free again
+        while (o - (int)counters()[1] >= RING) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        return ring_slot(o);
+    }
+    static MG_DEV void ring_publish(int o) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane_id() == 0) counters()[0] = (u32)(o + 1);
+    }
+    // register f := Miller loop of ONE pair: P affine G1 (px, py); Q as prepared coefficients in memory, or (FRESH) as they
+    // come out of wave 1's G2 arithmetic
+    template <bool FRESH> static __device__ void miller(int f, const F &px, const F &py, const u32 *coeffs) {
+        set_one(f);
+        int o = 0;
+        auto line = [&]() {
+            if constexpr (FRESH) {
+                ell(f, ring_acquire(o), px, py);
+                ring_release(o);
+            } else {
+                ell(f, coeffs + (size_t)o * P::COEFFW, px, py);
+            }
+            ++o;
+        };
+#pragma unroll 1
+        for (int i = K::LOOP_LEN - 2; i >= 0; --i) {
+            if (i != K::LOOP_LEN - 2) mul12(f, f, f);
+            line();
+            if (loop_digit(i) != 0) line();
+        }
+        if constexpr (K::BN) {
+            line();
+            line();
+        }
+        if constexpr (K::X_NEG) conj12(f);
+    }
+
+    // ---- G2Prepared::from(Q) on one wavefront: the doubling / addition steps of pairing_dev.h with their independent
+    // Fq2 products on different lanes (three / four products deep instead of ten / twelve)
+    enum { SX = 0, SY, SZ, T0, T1, T2, T3, T4, PREP_SLOTS };
+    static constexpr size_t prep_lds_bytes() { return (size_t)PREP_SLOTS * W * 4; }
+    // operand k of this level's product on lane k: every lane runs the same instruction stream (a chain of `if (lane == ..)`
+    // branches would execute the products one after another)
+    static MG_DEV F2 pick(int k, const F2 &a0, const F2 &a1, const F2 &a2, const F2 &a3, const F2 &a4) {
+        return F2::select(k == 0, a0, F2::select(k == 1, a1, F2::select(k == 2, a2, F2::select(k == 3, a3, a4))));
+    }
+    static __device__ __noinline__ void doubling_step(u32 *out) {
+        const F2 x = ld(SX), y = ld(SY), z = ld(SZ), yz = P::add(y, z);
+        if (lane_id() < 5) st(T0 + lane_id(), mul2(pick(lane_id(), x, y, z, x, yz), pick(lane_id(), y, y, z, x, yz))); // xy, y^2, z^2, x^2, (y+z)^2
+        sync();
+        const F2 a = half2(ld(T0)), b = ld(T1), c = ld(T2), j = ld(T3), s = ld(T4);
+        sync();
+        if (lane_id() == 0) st(T0, mul2(P::f2const(K::B2), triple(c)));
+        sync();
+        const F2 e = ld(T0), f = triple(e), g = half2(P::add(b, f)), h = P::sub(s, P::add(b, c)), i = P::sub(e, b);
+        sync();
+        if (lane_id() < 4) st(T0 + lane_id(), mul2(pick(lane_id(), a, g, e, b, b), pick(lane_id(), P::sub(b, f), g, e, h, h))); // x3, g^2, e^2, z3
+        if (lane_id() == 4) {
+            const F2 j3 = triple(j), nh = P::neg(h);
+            if constexpr (K::TWIST_D) P::store_coeff(typename P::Coeff{nh, j3, i}, out);
+            else P::store_coeff(typename P::Coeff{i, j3, nh}, out);
+        }
+        sync();
+        const F2 x3 = ld(T0), y3 = P::sub(ld(T1), triple(ld(T2))), z3 = ld(T3);
+        sync();
+        if (lane_id() < 3) st(SX + lane_id(), pick(lane_id(), x3, y3, z3, z3, z3));
+        sync();
+    }
+    static __device__ __noinline__ void addition_step(const F2 &qx, const F2 &qy, u32 *out) {
+        const F2 x = ld(SX), y = ld(SY), z = ld(SZ);
+        if (lane_id() < 2) st(T0 + lane_id(), mul2(pick(lane_id(), qy, qx, qx, qx, qx), z));
+        sync();
+        const F2 theta = P::sub(y, ld(T0)), lambda = P::sub(x, ld(T1));
+        sync();
+        if (lane_id() < 4) // theta^2, lambda^2, theta qx, lambda qy
+            st(T0 + lane_id(), mul2(pick(lane_id(), theta, lambda, theta, lambda, lambda), pick(lane_id(), theta, lambda, qx, qy, qy)));
+        sync();
+        const F2 c = ld(T0), d = ld(T1), jj = P::sub(ld(T2), ld(T3));
+        sync();
+        if (lane_id() < 3) st(T0 + lane_id(), mul2(pick(lane_id(), lambda, z, x, x, x), pick(lane_id(), d, c, d, d, d))); // e, f, g
+        sync();
+        const F2 e = ld(T0), f = ld(T1), g = ld(T2), h = P::sub(P::add(e, f), P::dbl(g));
+        sync();
+        if (lane_id() < 4) // x3, theta (g - h), e y, z3
+            st(T0 + lane_id(), mul2(pick(lane_id(), lambda, theta, e, z, z), pick(lane_id(), h, P::sub(g, h), y, e, e)));
+        if (lane_id() == 4) {
+            const F2 nt = P::neg(theta);
+            if constexpr (K::TWIST_D) P::store_coeff(typename P::Coeff{lambda, nt, jj}, out);
+            else P::store_coeff(typename P::Coeff{jj, nt, lambda}, out);
+        }
+        sync();
+        const F2 x3 = ld(T0), y3 = P::sub(ld(T1), ld(T2)), z3 = ld(T3);
+        sync();
+        if (lane_id() < 3) st(SX + lane_id(), pick(lane_id(), x3, y3, z3, z3, z3));
+        sync();
+    }
+    // NCOEFF triples (Q affine, not infinity), in the order the Miller loop consumes them
+    template <bool TO_RING> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out) {
+        static_assert(PREP_SLOTS * W == PREP_WORDS_, "layout");
+        if (lane_id() == 0) st(SX, qx), st(SY, qy), st(SZ, F2::one());
+        sync();
+        const F2 nqy = P::neg(qy);
+        int o = 0;
+        auto dst = [&]() { return TO_RING ? ring_reserve(o) : out + (size_t)o * P::COEFFW; };
+        auto done = [&]() {
+            if constexpr (TO_RING) ring_publish(o);
+            ++o;
+        };
+#pragma unroll 1
+        for (int i = K::LOOP_LEN - 2; i >= 0; --i) {
+            doubling_step(dst());
+            done();
+            const signed char dgt = loop_digit(i);
+            if (dgt != 0) {
+                addition_step(qx, dgt > 0 ? qy : nqy, dst());
+                done();
+            }
+        }
+        if constexpr (K::BN) { // + pi(Q) - pi^2(Q)
+            const F2 tx = P::f2const(K::TWQ_X), ty = P::f2const(K::TWQ_Y);
+            const F2 q1x = mul2(P::conj(qx), tx), q1y = mul2(P::conj(qy), ty);
+            const F2 q2x = mul2(P::conj(q1x), tx), q2y = P::neg(mul2(P::conj(q1y), ty));
+            addition_step(q1x, q1y, dst());
+            done();
+            addition_step(q2x, q2y, dst());
+            done();
+        }
+    }
+};
+
+} // namespace mg

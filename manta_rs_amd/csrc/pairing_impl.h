@@ -2,72 +2,92 @@
 // (pairing_bn254.hip / pairing_bls381.hip). SURVEY.md row f-2.
 #pragma once
 #include "engine.h"
-#include "pairing_dev.h"
+#include "pairing_coop.h"
 #include "verify.h"
+#include <cstring>
 #include <vector>
 
 namespace mg {
 
-// lane i: G2Prepared::from(Q_i) -> NCOEFF line-coefficient triples (infinity: all-zero block, never consumed)
+// One WAVEFRONT per unit of work (pairing_coop.h); every workgroup is a single wavefront with its Fq12 state in LDS.
+// workgroup i: G2Prepared::from(Q_i) -> NCOEFF line-coefficient triples (infinity: all-zero block, never consumed)
 template <class K>
 __global__ __launch_bounds__(64) void g2_prepare_kernel(const u32 *__restrict__ q, size_t n, u32 *__restrict__ out) {
     typedef Pairing<K> P;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const size_t i = blockIdx.x;
+    typedef PairingWave<K> w;
     const typename P::F2 qx = P::F2::load(q + i * 2 * P::F2W), qy = P::F2::load(q + i * 2 * P::F2W + P::F2W);
     u32 *o = out + i * (size_t)P::NCOEFF * P::COEFFW;
-    if (qx.is_zero() & qy.is_zero()) {
-        for (int k = 0; k < P::NCOEFF * P::COEFFW; ++k) o[k] = 0;
+    if (qx.is_zero() && qy.is_zero()) { // uniform over the wavefront
+        for (int k = threadIdx.x; k < P::NCOEFF * P::COEFFW; k += 64) o[k] = 0;
         return;
     }
-    P::prepare(qx, qy, o);
+    w::template prepare<false>(qx, qy, o);
 }
 
-// lane i: f_i = Miller(P_i, coeffs[i]); a pair with an infinity member contributes 1 (ark-ec filters such pairs)
+// workgroup i (two wavefronts): f_i = Miller(P_i, Q_i); a pair with an infinity member contributes 1 (ark-ec filters such
+// pairs). Q_i is either prepared already (coeffs[i] != null; wave 1 has nothing to do) or given as an affine point in
+// q[i]: then wave 1 runs G2Prepared::from(Q_i) and feeds the line coefficients to wave 0's Miller loop through LDS as they
+// appear -- the two chains overlap instead of running one after the other in two kernels.
 template <class K>
-__global__ __launch_bounds__(64) void miller_kernel(const u32 *__restrict__ p, const u32 *const *__restrict__ coeffs,
-                                                    const unsigned char *__restrict__ skip, size_t n, u32 *__restrict__ out) {
+__global__ __launch_bounds__(128) void miller_kernel(const u32 *__restrict__ p, const u32 *const *__restrict__ coeffs,
+                                                     const u32 *__restrict__ q, const unsigned char *__restrict__ skip, size_t n,
+                                                     u32 *__restrict__ out) {
     typedef Pairing<K> P;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    typename P::F12 f = P::one12();
+    typedef PairingWave<K> PW;
+    typedef PW w;
+    const size_t i = blockIdx.x;
+    const u32 *co = coeffs[i];
     const typename P::F px = P::F::load(p + i * 2 * P::N), py = P::F::load(p + i * 2 * P::N + P::N);
-    if (!(skip[i] || (px.is_zero() & py.is_zero()))) P::miller(f, px, py, coeffs[i]);
-    P::store12(f, out + i * P::F12W);
+    const bool one = skip[i] || (px.is_zero() && py.is_zero());
+    if (threadIdx.x == 0) w::counters()[0] = 0, w::counters()[1] = 0;
+    __syncthreads(); // the only workgroup barrier: from here on the two wavefronts run different programs
+    if (w::wave_id() == 1) {
+        if (!co && !one) {
+            const u32 *qi = q + i * 2 * P::F2W;
+            w::template prepare<true>(P::F2::load(qi), P::F2::load(qi + P::F2W), nullptr);
+        }
+        return;
+    }
+    if (one) w::set_one(PW::R(0));
+    else if (co) w::template miller<false>(PW::R(0), px, py, co);
+    else w::template miller<true>(PW::R(0), px, py, nullptr);
+    if (threadIdx.x < 6) w::ld(PW::R(0) + threadIdx.x).store(out + i * P::F12W + threadIdx.x * P::F2W);
 }
 
-// lane t: out[t] = product of in[t*chunk .. min(n, (t+1)*chunk))
+// workgroup t: out[t] = product of in[t*chunk .. min(n, (t+1)*chunk))
 template <class K>
 __global__ __launch_bounds__(64) void f12_product_kernel(const u32 *__restrict__ in, size_t n, size_t chunk, u32 *__restrict__ out) {
     typedef Pairing<K> P;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t lo = t * chunk;
-    if (lo >= n) return;
-    const size_t hi = lo + chunk < n ? lo + chunk : n;
-    typename P::F12 acc, x, y;
-    P::load12(acc, in + lo * P::F12W);
+    typedef PairingWave<K> PW;
+    const size_t t = blockIdx.x;
+    typedef PW w;
+    const size_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    if (threadIdx.x < 6) w::st(PW::R(0) + threadIdx.x, P::F2::load(in + lo * P::F12W + threadIdx.x * P::F2W));
+    PW::sync();
     for (size_t j = lo + 1; j < hi; ++j) {
-        P::load12(x, in + j * P::F12W);
-        P::mul12(y, acc, x);
-        acc = y;
+        if (threadIdx.x < 6) w::st(PW::R(1) + threadIdx.x, P::F2::load(in + j * P::F12W + threadIdx.x * P::F2W));
+        PW::sync();
+        w::mul12(PW::R(0), PW::R(0), PW::R(1));
     }
-    P::store12(acc, out + t * P::F12W);
+    if (threadIdx.x < 6) w::ld(PW::R(0) + threadIdx.x).store(out + t * P::F12W + threadIdx.x * P::F2W);
 }
 
-template <class K>
-__global__ __launch_bounds__(64) void final_exp_kernel(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out) {
+// one workgroup: out = final_exponentiation(in)
+template <class K> __global__ __launch_bounds__(64) void final_exp_kernel(const u32 *__restrict__ in, u32 *__restrict__ out) {
     typedef Pairing<K> P;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    typename P::F12 f, r;
-    P::load12(f, in + i * P::F12W);
-    P::final_exp(r, f);
-    P::store12(r, out + i * P::F12W);
+    typedef PairingWave<K> PW;
+    typedef PW w;
+    if (threadIdx.x < 6) w::st(PW::R(0) + threadIdx.x, P::F2::load(in + threadIdx.x * P::F2W));
+    PW::sync();
+    w::final_exp();
+    if (threadIdx.x < 6) w::ld(PW::R(0) + threadIdx.x).store(out + threadIdx.x * P::F2W);
 }
 
 template <class K> class PairingEngineT : public PairingEngine {
   public:
     typedef Pairing<K> P;
+    typedef PairingWave<K> PW;
     int n_coeffs() const override { return P::NCOEFF; }
     int coeff_words() const override { return P::COEFFW; }
     int f12_words() const override { return P::F12W; }
@@ -81,7 +101,7 @@ template <class K> class PairingEngineT : public PairingEngine {
         if (e == hipSuccess) e = hipMalloc((void **)&dc, cb);
         if (e == hipSuccess) e = hipMemcpy(dq, q_affine_host, qb, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((g2_prepare_kernel<K>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, dq, n, dc);
+            hipLaunchKernelGGL((g2_prepare_kernel<K>), dim3((unsigned)n), dim3(64), PW::prep_lds_bytes(), 0, dq, n, dc);
             e = hipDeviceSynchronize();
         }
         hipFree(dq);
@@ -94,46 +114,47 @@ template <class K> class PairingEngineT : public PairingEngine {
         return MG_OK;
     }
 
-    int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const unsigned char *skip, size_t n,
-                        bool do_final_exp, u32 *out_f12_host) override {
+    int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
+                        const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) override {
         if (!p_affine_host || !d_coeffs || !n || !out_f12_host) return MG_ERR_ARG;
-        u32 *dp = nullptr, *df = nullptr, *dg = nullptr;
-        const u32 **dcp = nullptr;
-        unsigned char *dskip = nullptr;
-        std::vector<unsigned char> sk(n, 0);
-        if (skip) sk.assign(skip, skip + n);
-        hipError_t e = hipMalloc((void **)&dp, n * 2 * P::N * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&df, n * P::F12W * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&dg, (n / 8 + 2) * P::F12W * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&dcp, n * sizeof(u32 *));
-        if (e == hipSuccess) e = hipMalloc((void **)&dskip, n);
-        if (e == hipSuccess) e = hipMemcpy(dp, p_affine_host, n * 2 * P::N * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dcp, d_coeffs, n * sizeof(u32 *), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(dskip, sk.data(), n, hipMemcpyHostToDevice);
+        for (size_t i = 0; i < n; ++i)
+            if (!d_coeffs[i] && !q_affine_host) return MG_ERR_ARG;
+        // one device block and one upload: [P | Q | coefficient pointers | skip flags] then the Fq12 work arrays
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t pb = n * 2 * P::N * 4, qb = q_affine_host ? n * 2 * P::F2W * 4 : 0, cb = n * sizeof(u32 *);
+        const size_t o_q = up(pb), o_c = o_q + up(qb), o_s = o_c + up(cb), in_bytes = o_s + up(n);
+        const size_t o_f = in_bytes, o_g = o_f + up(n * P::F12W * 4), total = o_g + up((n / 8 + 2) * P::F12W * 4);
+        std::vector<unsigned char> stage(in_bytes, 0);
+        std::memcpy(stage.data(), p_affine_host, pb);
+        if (qb) std::memcpy(stage.data() + o_q, q_affine_host, qb);
+        std::memcpy(stage.data() + o_c, d_coeffs, cb);
+        if (skip) std::memcpy(stage.data() + o_s, skip, n);
+        unsigned char *d = nullptr;
+        hipError_t e = hipMalloc((void **)&d, total);
+        if (e == hipSuccess) e = hipMemcpy(d, stage.data(), in_bytes, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, dp, dcp, dskip, n, df);
-            // product tree: chunks of 8 per lane until one element is left
+            u32 *df = (u32 *)(d + o_f), *dg = (u32 *)(d + o_g);
+            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n), dim3(128), PW::miller_lds_bytes(), 0, (const u32 *)d,
+                               (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
+                               n, df);
+            // product tree: chunks of 8 per wavefront until one element is left
             u32 *src = df, *dst = dg;
             size_t m = n;
             while (m > 1) {
                 const size_t chunk = 8, outn = (m + chunk - 1) / chunk;
-                hipLaunchKernelGGL((f12_product_kernel<K>), dim3((unsigned)((outn + 63) / 64)), dim3(64), 0, 0, src, m, chunk, dst);
+                hipLaunchKernelGGL((f12_product_kernel<K>), dim3((unsigned)outn), dim3(64), PW::lds_bytes(2), 0, src, m, chunk, dst);
                 u32 *t = src;
                 src = dst;
                 dst = t;
                 m = outn;
             }
             if (do_final_exp) {
-                hipLaunchKernelGGL((final_exp_kernel<K>), dim3(1), dim3(64), 0, 0, src, (size_t)1, dst);
+                hipLaunchKernelGGL((final_exp_kernel<K>), dim3(1), dim3(64), PW::lds_bytes(PW::FINAL_EXP_REGS), 0, src, dst);
                 src = dst;
             }
             e = hipMemcpy(out_f12_host, src, P::F12W * 4, hipMemcpyDeviceToHost);
         }
-        hipFree(dp);
-        hipFree(df);
-        hipFree(dg);
-        hipFree(dcp);
-        hipFree(dskip);
+        if (d) hipFree(d);
         if (e != hipSuccess) {
             set_last_hip_error(e, "pairing product", __FILE__, __LINE__);
             return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;

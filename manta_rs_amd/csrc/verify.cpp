@@ -238,7 +238,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         alpha_beta_.resize(pe_->f12_words());
         const u32 *cp[1] = {d_beta_};
         unsigned char skip[1] = {(unsigned char)is_zero_limbs(beta, G2L)};
-        return pe_->pairing_product((const u32 *)alpha_.data(), cp, skip, 1, true, alpha_beta_.data());
+        return pe_->pairing_product((const u32 *)alpha_.data(), cp, nullptr, skip, 1, true, alpha_beta_.data());
     }
     const u32 *d_gamma_neg() const { return d_gneg_; }
     const u32 *d_delta_neg() const { return d_dneg_ ? d_dneg_ : d_gneg_ + (size_t)pe_->n_coeffs() * pe_->coeff_words(); }
@@ -334,13 +334,13 @@ template <class Curve, class K> class VerifierT : public Verifier {
         std::memcpy(ps.data(), A, G1L * 8);
         g1_->hp_to_affine(&pi, (u32 *)(ps.data() + G1L));
         std::memcpy(ps.data() + 2 * G1L, Cc, G1L * 8);
-        u32 *d_cb = nullptr;
-        if ((rc = pe_->prepare((const u32 *)B, 1, &d_cb))) return rc;
-        const u32 *cp[3] = {d_cb, d_gamma_neg(), d_delta_neg()};
+        // B is the one G2 point that is new with every proof: its line coefficients are computed next to its Miller loop
+        const u32 *cp[3] = {nullptr, d_gamma_neg(), d_delta_neg()};
+        std::vector<u64> qs(3 * G2L, 0);
+        std::memcpy(qs.data(), B, G2L * 8);
         unsigned char skip[3] = {(unsigned char)is_zero_limbs(B, G2L), 0, 0};
         std::vector<u32> out(pe_->f12_words());
-        rc = pe_->pairing_product((const u32 *)ps.data(), cp, skip, 3, true, out.data());
-        hipFree(d_cb);
+        rc = pe_->pairing_product((const u32 *)ps.data(), cp, (const u32 *)qs.data(), skip, 3, true, out.data());
         if (rc) return rc;
         *ok = std::memcmp(out.data(), alpha_beta_.data(), out.size() * 4) == 0;
         return MG_OK;
@@ -412,20 +412,15 @@ template <class Curve, class K> class VerifierT : public Verifier {
         g1_->hp_to_affine(&pi, (u32 *)(ps.data() + k * G1L));
         g1_->hp_to_affine(&csum, (u32 *)(ps.data() + (k + 1) * G1L));
         g1_->hp_to_affine(&al, (u32 *)(ps.data() + (k + 2) * G1L));
-        u32 *d_cb = nullptr;
-        if ((rc = pe_->prepare((const u32 *)bs.data(), k, &d_cb))) return rc;
-        const size_t cw = (size_t)pe_->n_coeffs() * pe_->coeff_words();
-        std::vector<const u32 *> cp(n);
+        std::vector<const u32 *> cp(n, nullptr); // the k proof points B_i are prepared on the fly
         std::vector<unsigned char> skip(n, 0);
-        for (u64 i = 0; i < k; ++i) {
-            cp[i] = d_cb + i * cw;
-            skip[i] = (unsigned char)is_zero_limbs(bs.data() + i * G2L, G2L);
-        }
+        std::vector<u64> qs(n * G2L, 0);
+        std::memcpy(qs.data(), bs.data(), k * G2L * 8);
+        for (u64 i = 0; i < k; ++i) skip[i] = (unsigned char)is_zero_limbs(bs.data() + i * G2L, G2L);
         cp[k] = d_gamma_neg(), cp[k + 1] = d_delta_neg(), cp[k + 2] = d_beta_;
         skip[k + 2] = (unsigned char)is_zero_limbs(beta_.data(), G2L);
         std::vector<u32> out(pe_->f12_words());
-        rc = pe_->pairing_product((const u32 *)ps.data(), cp.data(), skip.data(), n, true, out.data());
-        hipFree(d_cb);
+        rc = pe_->pairing_product((const u32 *)ps.data(), cp.data(), (const u32 *)qs.data(), skip.data(), n, true, out.data());
         if (rc) return rc;
         std::vector<u32> one(out.size(), 0u);
         HF::one().store_words(one.data());

@@ -14,10 +14,12 @@ class PairingEngine {
     virtual int fq_words() const = 0;
     // G2Prepared::from for n affine points (host, Montgomery) -> device array n x n_coeffs x coeff_words (hipFree it)
     virtual int prepare(const u32 *q_affine_host, size_t n, u32 **d_out) = 0;
-    // out = [final_exponentiation] ( prod_i MillerLoop(P_i, prepared_i) ): P host affine G1; d_coeffs[i] device pointers;
+    // out = [final_exponentiation] ( prod_i MillerLoop(P_i, Q_i) ): P host affine G1; Q_i either prepared (d_coeffs[i] a
+    // device pointer from prepare()) or, where d_coeffs[i] is null, the affine G2 point q_affine_host[i] (prepared on the
+    // fly next to its Miller loop; q_affine_host may be null when every pair is prepared);
     // skip[i] != 0 leaves pair i out (its G2 point was infinity)
-    virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const unsigned char *skip, size_t n,
-                                bool do_final_exp, u32 *out_f12_host) = 0;
+    virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
+                                const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) = 0;
 };
 PairingEngine *make_pairing_engine_bn254();
 PairingEngine *make_pairing_engine_bls381();

@@ -4,7 +4,10 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 ps = bench.ProveSetup("private_transfer")
-for K, ths in ((32, (1, 2, 3)), (96, (1, 2)), (256, (1, 2)), (1024, (1,))):
+CASES = ((32, (1, 2, 3)), (96, (1, 2)), (256, (1, 2)), (1024, (1,)))
+if len(sys.argv) > 1:
+    CASES = ((int(sys.argv[1]), (2,)),)
+for K, ths in CASES:
     for th in ths:
         n = max(1024, K * th * 2)
         ps.run(max(4 * K * th, 8), th, K)
