@@ -413,7 +413,7 @@ def verify_bench(ps, proofs):
     vctx.close()
     return {"single_ms": round(t1 * 1e3, 3), "single_proofs_per_s": round(1 / t1, 1), "batch": k, "batch_ms": round(tb * 1e3, 3),
             "batch_proofs_per_s": round(k / tb, 1),
-            "how": "3 / k + 3 Miller loops (one GPU lane each) + one final exponentiation; accepted and a fuzzed input rejected before timing"}
+            "how": "3 / k + 3 Miller loops (one wavefront each, the proof's G2 point prepared by a second wavefront alongside) + one wave-cooperative final exponentiation; accepted and a fuzzed input rejected before timing"}
 
 
 def prove_cpu_baseline(ps, proofs, ncpu=8):

@@ -18,6 +18,7 @@
 #include <map>
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -700,7 +701,9 @@ class ProverImpl : public Prover {
                 const u64 c = next.fetch_add(1);
                 if (c >= chunks || first_rc.load() != MG_OK) return;
                 const u64 lo = c * per, n = std::min(per, k64 - lo);
+                stream_gate_acquire(); // at most `fl` streamed passes in flight per context, however many callers
                 const int rc = prove_pass(n, z + lo * V_ * 4, r + lo * 4, s + lo * 4, proofs_out + lo * pbytes);
+                stream_gate_release();
                 int ok = MG_OK;
                 if (rc) first_rc.compare_exchange_strong(ok, rc);
             }
@@ -711,6 +714,23 @@ class ProverImpl : public Prover {
         worker();
         for (auto &t : th) t.join();
         return first_rc.load();
+    }
+    // two callers streaming a batch each would otherwise put six passes in flight, which is slower than three (measured:
+    // 2 x 256 proofs 3 465 proofs/s against 3 650-3 840 for one caller)
+    std::mutex gate_mu_;
+    std::condition_variable gate_cv_;
+    int gate_busy_ = 0;
+    void stream_gate_acquire() {
+        std::unique_lock<std::mutex> lk(gate_mu_);
+        gate_cv_.wait(lk, [&] { return gate_busy_ < batch_inflight(); });
+        ++gate_busy_;
+    }
+    void stream_gate_release() {
+        {
+            std::lock_guard<std::mutex> lk(gate_mu_);
+            --gate_busy_;
+        }
+        gate_cv_.notify_one();
     }
     int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) {
         // shared against set_r1cs on every shard for the length of the pass

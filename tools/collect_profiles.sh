@@ -25,3 +25,9 @@ MANTA_ACC_GATHER_ONLY=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_g 
 for db in $(find /tmp/pmc_g -name "*.db"); do python $R/tools/pmc_kernels.py $db 2>/dev/null | grep -E "gather_only|accumulate_chunks" >> $O/pmc_gather_only.txt; done
 python $R/tools/gather_calibration.py 16 > $O/gather_calibration.jsonl 2>> $O/bench.err
 python $R/tools/hbm_bw.py > $O/hbm_bw.txt 2>> $O/bench.err
+# single verification + a batch (wave-cooperative pairing), and its building blocks
+rocprofv3 --kernel-trace --stats -d /tmp/pv -o v -- python $R/tools/verify_profile.py > $O/verify_profiled.txt 2>> $O/bench.err
+python $R/tools/rocprof_summary.py $(find /tmp/pv -name "*.db" | head -1) | grep -E "kernel  |miller|final_exp|prepare|f12" > $O/verify_kernel_stats.txt
+[ -x $R/tools/ubench_pairing ] && $R/tools/ubench_pairing > $O/ubench_pairing.txt
+python $R/tools/batch_threads_sweep.py > $O/batch_threads_sweep.txt 2>> $O/bench.err
+python $R/tools/config3_bls_2_20.py 1 20 > $O/config3_bls12_381_2_20.jsonl 2>> $O/bench.err
