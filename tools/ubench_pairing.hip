@@ -23,7 +23,7 @@ template <int MODE> __global__ __launch_bounds__(64) void bench(u32 *buf, int it
         if (MODE == 0) PW::mul12(PW::R(0), PW::R(0), PW::R(1));
         if (MODE == 1) PW::ell(PW::R(0), buf, px, py);
         if (MODE == 2) PW::template frob12<1>(PW::R(0));
-        if (MODE == 3) PW::inv12(PW::R(0), PW::R(0));
+        if (MODE == 3) PW::inv12(PW::R(1), PW::R(0), PW::R(2), PW::R(3));
         if (MODE == 4) PW::doubling_step(buf + 1024);
         if (MODE == 5) PW::addition_step(qx, qy, buf + 1024);
         if (MODE == 6) PW::fold(PW::R(0), 0x3fu);
@@ -32,6 +32,7 @@ template <int MODE> __global__ __launch_bounds__(64) void bench(u32 *buf, int it
         if (MODE == 9) qacc = PW::mul2_xi(qacc);
         if (MODE == 10) qacc = P::F2::add(qacc, qx);
         if (MODE == 11) qacc.c0 = P::F::mul(qacc.c0, qx.c0);
+        if (MODE == 13) qacc.c0 = PW::inv_euclid(P::F::add(qacc.c0, qx.c0));
         if (MODE == 12) { PW::st(PW::R(1), qacc); PW::sync(); qacc = PW::ld(PW::R(1) + 1); }
     }
     if (threadIdx.x < 6) PW::ld(PW::R(0) + threadIdx.x).store(buf + 2048 + threadIdx.x * P::F2W);
@@ -45,12 +46,12 @@ int main() {
     hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0), hipEventCreate(&e1);
-    const char *names[13] = {"mul12", "ell (line product)", "frob12<1>", "inv12 (lane 0)", "G2 doubling step", "G2 addition step", "fold only", "conj12", "Fq2 product (registers)", "xi * Fq2", "Fq2 add", "Fq product", "LDS store + sync + load"};
+    const char *names[14] = {"mul12", "ell (line product)", "frob12<1>", "inv12 (lane 0)", "G2 doubling step", "G2 addition step", "fold only", "conj12", "Fq2 product (registers)", "xi * Fq2", "Fq2 add", "Fq product", "LDS store + sync + load", "Fq inverse (binary Euclid, lane 0)"};
     auto run = [&](int mode, auto kern, int iters) {
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64), PW::lds_bytes(2), 0, buf, 1);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), PW::lds_bytes(4), 0, buf, 1);
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        hipLaunchKernelGGL(kern, dim3(1), dim3(64), PW::lds_bytes(2), 0, buf, iters);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), PW::lds_bytes(4), 0, buf, iters);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -59,6 +60,6 @@ int main() {
     };
     run(0, bench<0>, 2000); run(1, bench<1>, 2000); run(2, bench<2>, 2000); run(3, bench<3>, 20);
     run(4, bench<4>, 2000); run(5, bench<5>, 2000); run(6, bench<6>, 2000); run(7, bench<7>, 2000);
-    run(8, bench<8>, 2000); run(9, bench<9>, 2000); run(10, bench<10>, 2000); run(11, bench<11>, 2000); run(12, bench<12>, 2000);
+    run(8, bench<8>, 2000); run(9, bench<9>, 2000); run(10, bench<10>, 2000); run(11, bench<11>, 2000); run(12, bench<12>, 2000); run(13, bench<13>, 50);
     return 0;
 }
