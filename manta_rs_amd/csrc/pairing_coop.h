@@ -54,8 +54,42 @@ template <class K> struct PairingWave {
         return F2{v[0], v[1]};
     }
     static MG_DEV F2 sqr2(const F2 &a) { return mul2(a, a); }
+    // 9 a mod p as ONE small multiple: t = 9 a (N + 1 words), a quotient estimate q from its top 64 bits (never above
+    // floor(t / p), at most one below: the divisor is p's top word + 1 and the float product is biased down by 2^-20), then
+    // t - q p < 2p and one conditional subtraction -- ~45 instructions against 4 modular additions (~150): xi = 9 + u is
+    // applied to every wrapped coefficient product (1.7 -> 0.9 us of an Fq12 product's 6.3 us on BN254)
+    static MG_DEV F times9(const F &a) {
+        u32 t[N + 1];
+        u64 c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            c += (u64)a.v[i] * 9u;
+            t[i] = (u32)c;
+            c >>= 32;
+        }
+        t[N] = (u32)c;
+        const u64 top64 = ((u64)t[N] << 32) | t[N - 1];
+        const float inv = (1.0f - 1.0f / 1048576.0f) / (float)((u64)K::Fq::P[N - 1] + 1u);
+        const u32 q = (u32)((float)top64 * inv);
+        F r;
+        u64 m = 0;
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            m += (u64)q * K::Fq::P[i];
+            const u64 d = (u64)t[i] - (u32)m - bw;
+            r.v[i] = (u32)d;
+            bw = (u32)(d >> 63);
+            m >>= 32;
+        }
+        return F::reduce_once(r, t[N] - (u32)m - bw);
+    }
+    static MG_DEV F xi_real(const F &a) { // U0 a, xi = U0 + u
+        if constexpr (K::U0 == 9) return times9(a);
+        else return P::small_mul(a);
+    }
     static MG_DEV F2 mul2_xi(const F2 &a) {
-        return F2{F::sub(P::small_mul(a.c0), a.c1), F::add(P::small_mul(a.c1), a.c0)};
+        return F2{F::sub(xi_real(a.c0), a.c1), F::add(xi_real(a.c1), a.c0)};
     }
     // A wavefront runs in lockstep and its LDS operations complete in order, so lanes exchange data through LDS with a
     // compiler-level fence only -- no s_barrier. (The Miller kernel runs two wavefronts with different programs in one
