@@ -232,7 +232,7 @@ int mg_groth16_prove(const mg_ctx *ctx, const uint64_t *z_mont, const uint64_t r
 /* k proofs of the context's circuit (throughput mode: a wallet / ledger simulation proving many transfers
  * against one ProvingContext, manta-pay/src/simulation/mod.rs:75-79; the shim collects k `prove` calls or
  * exposes a `prove_many`). Up to 32 proofs are ONE pass of the GPU pipeline; a longer batch is streamed
- * through as equal passes of <= 32 with three in flight (library threads), so one call with k >= 96 keeps the
+ * through as passes of 32 with three in flight (library threads), so one call with k >= 96 keeps the
  * GPU as busy as three callers would. z = k assignments back to back (k x V x 4 u64), r, s = k blinding
  * scalars each (k x 4 u64), proofs_out = k proofs back to back. Proof q is byte-identical to
  * mg_groth16_prove(ctx, z_q, r_q, s_q). 1 <= k <= 1024. */

@@ -2,9 +2,15 @@
 // the per-engine MSM workspace pool and the (curve, group) engine registry.
 #include "engine.h"
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
+
+// (The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, default 4; streams that share one
+// serialise. The library leaves the variable alone: measured on MI355X, PrivateTransfer shape, 6 queues against 4 give
+// +6 % batched proofs/s and -4 % sequential latency in a process that only proves (tools/hw_queues_sweep.sh) but -20 % for
+// two threads of single proofs and nothing for the batched stream inside bench.py's process; 8 queues halve everything.)
 
 namespace mg {
 
