@@ -146,7 +146,8 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
 // K7a: chunk accumulate
 // --------------------------------------------------------------------------------------------
 // (179 VGPRs for BLS12-381 G1 -> two wavefronts per SIMD, which already saturates the integer pipe; forcing
-// three through the launch bounds spills and is slower, software-prefetching the gather changes nothing)
+// three through the launch bounds spills and is slower, software-prefetching the gather changes nothing; BN254 G1 needs 130
+// -> three per SIMD, and asking for four -- amdgpu_waves_per_eu(4, 4): 128 VGPRs, two spilled -- changes nothing either)
 template <class F>
 __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
