@@ -78,7 +78,7 @@ template <int T, class F, int A> MG_DEV Bv<F, T> b_fit(const Bv<F, A> &a) {
 
 template <class F> struct Affine {
     F x, y;
-    MG_DEV bool is_inf() const { return x.is_zero_exact() & y.is_zero_exact(); }
+    MG_DEV bool is_inf() const { return x.is_zero_exact() && y.is_zero_exact(); }
     static MG_DEV Affine load(const u32 *p) { return Affine{F::load(p), F::load(p + F::N)}; }
     MG_DEV void store(u32 *p) const {
         x.store(p);

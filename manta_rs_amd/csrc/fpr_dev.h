@@ -563,7 +563,7 @@ template <class C> struct Fp2R {
     B c0, c1;
     static MG_DEV Fp2R zero() { return Fp2R{B::zero(), B::zero()}; }
     static MG_DEV Fp2R one() { return Fp2R{B::one(), B::zero()}; }
-    MG_DEV bool is_zero_exact() const { return c0.is_zero_exact() & c1.is_zero_exact(); }
+    MG_DEV bool is_zero_exact() const { return c0.is_zero_exact() && c1.is_zero_exact(); }
     template <int A> MG_DEV bool is_zero_mod() const { return c0.template is_zero_mod<A>() && c1.template is_zero_mod<A>(); }
     static MG_DEV Fp2R add(const Fp2R &a, const Fp2R &b) { return Fp2R{B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
     static MG_DEV Fp2R dbl(const Fp2R &a) { return add(a, a); }

@@ -127,13 +127,17 @@ template <class K> struct PairingWave {
     static __device__ __noinline__ void fold(int d, u32 cols) {
         if (lane_id() < 12) {
             const int m = lane_id() >> 1, comp = lane_id() & 1;
-            F acc = F::zero();
-#pragma unroll 1
+            // all six loads first (their LDS latencies overlap), then a three-deep tree of additions; a column that was not
+            // filled contributes zero
+            F t[6];
+#pragma unroll
             for (int i = 0; i < 6; ++i) {
                 int j = m - i;
                 j += j < 0 ? 6 : 0;
-                if ((cols >> j) & 1u) acc = F::add(acc, F::load(base() + (PROD + 6 * i + j) * W + comp * N));
+                t[i] = F::load(base() + (PROD + 6 * i + j) * W + comp * N);
+                if (!((cols >> j) & 1u)) t[i] = F::zero();
             }
+            const F acc = F::add(F::add(F::add(t[0], t[1]), F::add(t[2], t[3])), F::add(t[4], t[5]));
             acc.store(base() + (d + slot_of(m)) * W + comp * N);
         }
         sync();
