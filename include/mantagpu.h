@@ -270,11 +270,17 @@ void mg_vk_destroy(mg_vk *vk);
  * *ok = 1 iff the proof verifies; the return value reports only operational failures. */
 int mg_groth16_verify(const mg_vk *vk, const uint64_t *inputs_mont, const uint64_t *proof_points, int *ok);
 /* k proofs against one key by random linear combination: rand128 = k x 2 u64 non-zero 128-bit coefficients from the
- * caller's RNG. k + 3 Miller loops (one GPU lane each), two small MSMs and one final exponentiation. *ok = 1 iff ALL
+ * caller's RNG. k + 3 Miller loops (one wavefront each), two small MSMs and one final exponentiation. *ok = 1 iff ALL
  * k proofs verify (up to the 2^-128 soundness error of the combination); on 0 fall back to mg_groth16_verify to find
  * the offender. */
 int mg_groth16_verify_batch(const mg_vk *vk, uint64_t k, const uint64_t *inputs_mont, const uint64_t *proof_points,
                             const uint64_t *rand128, int *ok);
+/* prod_i e(P_i, Q_i) == 1 ? -- the pairing-product test behind `PairingEngineExt::has_same` / `same_ratio`
+ * (manta-crypto/src/arkworks/pairing.rs:88-109), which the trusted-setup verifier applies to random linear
+ * combinations of whole queries (`verify_transform`, manta-trusted-setup/src/groth16/mpc.rs:470-508). P_i affine
+ * G1, Q_i affine G2 (Montgomery limbs; an all-zero point is infinity and its pair contributes 1). n Miller loops
+ * (one wavefront each, every Q_i prepared alongside by a second one) and one final exponentiation. */
+int mg_pairing_check(mg_curve_t curve, const uint64_t *g1_affine, const uint64_t *g2_affine, size_t n, int *ok);
 /* `Proof::deserialize` (arkworks compressed a | b | c) -> a | b | c affine Montgomery limbs; rejects non-canonical
  * encodings, points off the curve or outside the subgroup. */
 int mg_proof_decode(mg_curve_t curve, const uint8_t *proof_bytes, uint64_t *points_out);

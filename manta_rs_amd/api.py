@@ -62,7 +62,7 @@ EXPORTS = [
     "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
     "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
-    "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_proof_decode", "mg_group_ntt",
+    "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
 ]
 
 
@@ -573,6 +573,18 @@ class Groth16:
         _chk(LIB.mg_groth16_prove_batch(context.handle, ctypes.c_uint64(k), _p(zs), _p(rs), _p(ss), out),
              "mg_groth16_prove_batch")
         return [out.raw[i * n:(i + 1) * n] for i in range(k)]
+
+
+def pairing_check(curve, g1_points, g2_points) -> bool:
+    """prod_i e(P_i, Q_i) == 1 (`mg_pairing_check`): the test behind `PairingEngineExt::has_same` / `same_ratio`
+    (manta-crypto/src/arkworks/pairing.rs:88-109). g1_points [n, 2 * limbs], g2_points [n, 4 * limbs] affine Montgomery."""
+    g1 = _u64(g1_points).reshape(-1, affine_limbs(curve, 1))
+    g2 = _u64(g2_points).reshape(-1, affine_limbs(curve, 2))
+    if g1.shape[0] != g2.shape[0] or g1.shape[0] == 0:
+        raise ValueError("pairing_check: as many G1 as G2 points, at least one")
+    ok = ctypes.c_int(0)
+    _chk(LIB.mg_pairing_check(curve, _p(g1), _p(g2), ctypes.c_size_t(g1.shape[0]), ctypes.byref(ok)), "mg_pairing_check")
+    return bool(ok.value)
 
 
 def proof_decode(curve, proof_bytes) -> np.ndarray:

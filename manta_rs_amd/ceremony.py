@@ -6,6 +6,9 @@ manta-trusted-setup's hot loops, every group operation through the C ABI (`mg_ec
     contribute                  groth16/mpc.rs:451-468                    l_query, h_query *= 1/delta; delta_g1, delta_g2 *= delta
     accumulator_update          groth16/kzg.rs:444-468                    powers of tau times tau^i (and alpha, beta)
     lagrange_basis / initialize groth16/mpc.rs:355-431                    group-domain IFFTs of the powers, then the QAP sums
+    merge_pairs_affine          util.rs:314-332                           one random linear combination of two point vectors (2 MSMs)
+    same_ratio                  manta-crypto/src/arkworks/pairing.rs:88-109   e(a0, b1) == e(a1, b0) as one pairing product (`mg_pairing_check`)
+    check_transform             groth16/mpc.rs:487-508                    the verifier's consistency checks of one contribution
 
 Scalars are Python integers (the ceremony's RNG stays with the caller); points are [n, limbs] uint64 affine Montgomery
 arrays, infinity = zeros -- the C ABI's format. Not used by the prover; a ceremony is a one-off, which is why SURVEY.md
@@ -46,6 +49,62 @@ def contribute(curve, pk, delta):
     out.delta_g1 = batch_mul_fixed_scalar(curve, 1, np.asarray(pk.delta_g1).reshape(1, -1), delta)
     out.delta_g2 = batch_mul_fixed_scalar(curve, 2, np.asarray(pk.delta_g2).reshape(1, -1), delta)
     return out
+
+
+def g1_neg(curve, point) -> np.ndarray:
+    """-P for an affine G1 point in Montgomery limbs (negation is linear: the representative of -y is p - y R)."""
+    q, nl = synth.FQ_MODULUS[curve], synth.FQ_LIMBS[curve]
+    pt = np.asarray(point, dtype=np.uint64).reshape(-1).copy()
+    if not pt.any():
+        return pt
+    y = synth.limbs_to_ints(pt[nl:].reshape(1, nl))[0]
+    pt[nl:] = synth.ints_to_limbs([(q - y) % q], nl)[0]
+    return pt
+
+
+def merge_pairs_affine(curve, group, lhs, rhs, rho=None):
+    """util.rs:314-332 `merge_pairs_affine`: (sum rho_i lhs_i, sum rho_i rhs_i) for one vector of random scalars -- two
+    MSMs over the same scalars (the reference multiplies point by point and folds; the sums are the same group elements).
+    rho: the scalars as integers (tests), else drawn from the OS like the reference's `OsRng`."""
+    import secrets
+    lhs, rhs = np.asarray(lhs, dtype=np.uint64), np.asarray(rhs, dtype=np.uint64)
+    n = lhs.shape[0]
+    if rhs.shape[0] != n or n == 0:
+        raise ValueError("merge_pairs_affine: two non-empty vectors of the same length")
+    r = synth.FR_MODULUS[curve]
+    rho = [secrets.randbelow(r) for _ in range(n)] if rho is None else [int(k) % r for k in rho]
+    sc = synth.ints_to_limbs(rho, 4)
+    out = []
+    for pts in (lhs, rhs):
+        bases = api.Bases(curve, group, pts)
+        out.append(api.VariableBaseMSM.multi_scalar_mul(bases, sc))
+        bases.close()
+    return out[0], out[1]
+
+
+def same_ratio(curve, lhs, rhs) -> bool:
+    """pairing.rs:101-109 `same_ratio((a0, a1), (b0, b1))`: e(a0, b1) == e(a1, b0), evaluated as the single product
+    e(a0, b1) e(-a1, b0) == 1 (two Miller loops and one final exponentiation on the GPU)."""
+    a0, a1 = lhs
+    b0, b1 = rhs
+    return api.pairing_check(curve, np.stack([np.asarray(a0, dtype=np.uint64).reshape(-1), g1_neg(curve, a1)]),
+                             np.stack([np.asarray(b1, dtype=np.uint64).reshape(-1), np.asarray(b0, dtype=np.uint64).reshape(-1)]))
+
+
+def check_transform(curve, prev, nxt, ratio=None, rho=None) -> str:
+    """mpc.rs:487-508, the consistency checks of `verify_transform` between two states of the key (the ratio proof's own
+    verification -- a hash to the curve -- stays with the caller, who passes its (ratio_0, ratio_1) pair or None):
+    returns "" if the contribution is consistent, else the name of the reference's error variant."""
+    d2 = (np.asarray(prev.delta_g2).reshape(-1), np.asarray(nxt.delta_g2).reshape(-1))
+    if ratio is not None and not same_ratio(curve, ratio, d2):
+        return "InconsistentDeltaChange"
+    if not same_ratio(curve, (np.asarray(prev.delta_g1).reshape(-1), np.asarray(nxt.delta_g1).reshape(-1)), d2):
+        return "InconsistentDeltaChange"
+    if not same_ratio(curve, merge_pairs_affine(curve, 1, nxt.h_query, prev.h_query, rho), d2):
+        return "InconsistentHChange"
+    if not same_ratio(curve, merge_pairs_affine(curve, 1, nxt.l_query, prev.l_query, rho), d2):
+        return "InconsistentLChange"
+    return ""
 
 
 class Accumulator:

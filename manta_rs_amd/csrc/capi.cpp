@@ -529,6 +529,13 @@ MG_API int mg_groth16_verify_batch(const mg_vk *vk, uint64_t k, const uint64_t *
     return vk->v->verify_batch(k, inputs_mont, proof_points, rand128, ok);
     MG_CATCH
 }
+MG_API int mg_pairing_check(mg_curve_t curve, const uint64_t *g1_affine, const uint64_t *g2_affine, size_t n, int *ok) {
+    MG_TRY
+    PairingEngine *pe = get_pairing_engine((int)curve);
+    if (!pe) return MG_ERROR_INVALID_ARGUMENT;
+    return pe->product_is_one((const u32 *)g1_affine, (const u32 *)g2_affine, n, ok);
+    MG_CATCH
+}
 MG_API int mg_proof_decode(mg_curve_t curve, const uint8_t *proof_bytes, uint64_t *points_out) {
     MG_TRY
     return proof_decode((int)curve, proof_bytes, points_out);

@@ -161,6 +161,25 @@ template <class K> class PairingEngineT : public PairingEngine {
         }
         return MG_OK;
     }
+
+    int product_is_one(const u32 *p_affine_host, const u32 *q_affine_host, size_t n, int *ok) override {
+        if (!p_affine_host || !q_affine_host || !n || !ok) return MG_ERR_ARG;
+        *ok = 0;
+        std::vector<const u32 *> cp(n, nullptr);
+        std::vector<unsigned char> skip(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            u32 any = 0;
+            for (int k = 0; k < 2 * P::F2W; ++k) any |= q_affine_host[i * 2 * P::F2W + k];
+            skip[i] = any == 0;
+        }
+        std::vector<u32> out(P::F12W);
+        const int rc = pairing_product(p_affine_host, cp.data(), q_affine_host, skip.data(), n, true, out.data());
+        if (rc) return rc;
+        bool one = true;
+        for (int k = 0; k < P::F12W; ++k) one = one && out[k] == (k < P::N ? K::Fq::R[k] : 0u);
+        *ok = one ? 1 : 0;
+        return MG_OK;
+    }
 };
 
 } // namespace mg

@@ -20,6 +20,9 @@ class PairingEngine {
     // skip[i] != 0 leaves pair i out (its G2 point was infinity)
     virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                                 const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) = 0;
+    // *ok = (prod_i e(P_i, Q_i) == 1): all points host affine Montgomery words, every Q_i prepared on the fly; a pair with an
+    // infinity member (all-zero words) contributes 1
+    virtual int product_is_one(const u32 *p_affine_host, const u32 *q_affine_host, size_t n, int *ok) = 0;
 };
 PairingEngine *make_pairing_engine_bn254();
 PairingEngine *make_pairing_engine_bls381();

@@ -271,5 +271,6 @@ extern "C" {
         rand128: *const u64,
         ok: *mut c_int,
     ) -> c_int;
+    pub fn mg_pairing_check(curve: mg_curve_t, g1_affine: *const u64, g2_affine: *const u64, n: usize, ok: *mut c_int) -> c_int;
     pub fn mg_proof_decode(curve: mg_curve_t, proof_bytes: *const u8, points_out: *mut u64) -> c_int;
 }

@@ -102,3 +102,43 @@ def test_ceremony_initialize_contribute_prove_verify(gpu, curve):
     assert proof == O.groth16_prove(c, want2, rs[0], rs[1])
     assert gpu.groth16_verify(gpu.VerifyingContext(curve, pk2), c.z[1:c.P], proof) is True
     assert gpu.groth16_verify(gpu.VerifyingContext(curve, pk), c.z[1:c.P], proof) is False
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_verify_transform_checks_on_a_contribution(gpu, curve):
+    """mpc.rs:487-508 `verify_transform`: the same-ratio checks between the key before and after `contribute` -- delta_g1
+    against delta_g2, and one random linear combination each of the whole h and l queries (`merge_pairs_affine`: two MSMs
+    over the same scalars) -- all on the GPU (`mg_msm`, `mg_pairing_check`). A consistent contribution passes; a key whose
+    h / l / delta_g1 was scaled by something else is rejected with the reference's error variant."""
+    r = synth.FR_MODULUS[curve]
+    c = synth.make_circuit(curve, 120, 90, 5, seed=82)
+    pk = O.groth16_setup(c, H.toxic(curve, seed=21))
+    delta = 0x1234567890abcdef1234567
+    nxt = ceremony.contribute(curve, pk, delta)
+    G1 = O.generator(curve, 1)
+    lim = lambda ks: synth.ints_to_limbs([k % r for k in ks], 4)
+    ratio = (O.g_mul(curve, 1, G1, lim([77])[0]), O.g_mul(curve, 1, G1, lim([77 * delta])[0]))  # what a RatioProof certifies
+    rho = [pow(5, i + 1, r) for i in range(max(pk.h_query.shape[0], pk.l_query.shape[0]))]
+    assert ceremony.check_transform(curve, pk, nxt, ratio) == ""          # OS randomness, like the reference
+    # merge_pairs_affine against the oracle's MSM on the same scalars
+    L, R = ceremony.merge_pairs_affine(curve, 1, nxt.h_query, pk.h_query, rho[:pk.h_query.shape[0]])
+    can = synth.ints_to_limbs(rho[:pk.h_query.shape[0]], 4)
+    assert (L == O.msm(curve, 1, nxt.h_query, can)).all() and (R == O.msm(curve, 1, pk.h_query, can)).all()
+    # wrong ratio, then one field at a time scaled by a different scalar
+    bad_ratio = (ratio[0], O.g_mul(curve, 1, G1, lim([78 * delta])[0]))
+    assert ceremony.check_transform(curve, pk, nxt, bad_ratio) == "InconsistentDeltaChange"
+    import copy
+    for field, err in (("delta_g1", "InconsistentDeltaChange"), ("h_query", "InconsistentHChange"), ("l_query", "InconsistentLChange")):
+        t = copy.copy(nxt)
+        pts = np.asarray(getattr(nxt, field)).reshape(-1, gpu.affine_limbs(curve, 1)).copy()
+        pts[-1] = O.g_mul(curve, 1, pts[-1], lim([3])[0])  # one entry off
+        setattr(t, field, pts if field != "delta_g1" else pts.reshape(-1))
+        assert ceremony.check_transform(curve, pk, t, ratio) == err, field
+    # same_ratio itself: e(a P, Q) == e(P, a Q), infinity pairs contribute 1
+    G2 = O.generator(curve, 2)
+    a = 0xabcdef12345
+    aP, aQ = O.g_mul(curve, 1, G1, lim([a])[0]), O.g_mul(curve, 2, G2, lim([a])[0])
+    assert ceremony.same_ratio(curve, (G1, aP), (G2, aQ)) is True
+    assert ceremony.same_ratio(curve, (G1, aP), (G2, O.g_mul(curve, 2, G2, lim([a + 1])[0]))) is False
+    assert gpu.pairing_check(curve, np.stack([G1, np.zeros_like(G1)]), np.stack([np.zeros_like(G2), G2])) is True
+    assert gpu.pairing_check(curve, G1.reshape(1, -1), G2.reshape(1, -1)) is False
