@@ -9,6 +9,7 @@ manta-trusted-setup's hot loops, every group operation through the C ABI (`mg_ec
     merge_pairs_affine          util.rs:314-332                           one random linear combination of two point vectors (2 MSMs)
     same_ratio                  manta-crypto/src/arkworks/pairing.rs:88-109   e(a0, b1) == e(a1, b0) as one pairing product (`mg_pairing_check`)
     check_transform             groth16/mpc.rs:487-508                    the verifier's consistency checks of one contribution
+    power_pairs / check_powers  util.rs:333-346, groth16/kzg.rs:508-521   consecutive powers differ by one ratio (kzg verifier)
 
 Scalars are Python integers (the ceremony's RNG stays with the caller); points are [n, limbs] uint64 affine Montgomery
 arrays, infinity = zeros -- the C ABI's format. Not used by the prover; a ceremony is a one-off, which is why SURVEY.md
@@ -91,6 +92,19 @@ def same_ratio(curve, lhs, rhs) -> bool:
                              np.stack([np.asarray(b1, dtype=np.uint64).reshape(-1), np.asarray(b0, dtype=np.uint64).reshape(-1)]))
 
 
+def same(curve, lhs, rhs) -> bool:
+    """pairing.rs `PairingEngineExt::same((a, b), (c, d))`: e(a, b) == e(c, d), as e(a, b) e(-c, d) == 1."""
+    (a, b), (c, d) = lhs, rhs
+    return api.pairing_check(curve, np.stack([np.asarray(a, dtype=np.uint64).reshape(-1), g1_neg(curve, c)]),
+                             np.stack([np.asarray(b, dtype=np.uint64).reshape(-1), np.asarray(d, dtype=np.uint64).reshape(-1)]))
+
+
+def power_pairs(curve, group, points, rho=None):
+    """util.rs:333-346 `power_pairs`: one random linear combination of all but the last and of all but the first point."""
+    points = np.asarray(points, dtype=np.uint64)
+    return merge_pairs_affine(curve, group, points[:-1], points[1:], rho)
+
+
 def check_transform(curve, prev, nxt, ratio=None, rho=None) -> str:
     """mpc.rs:487-508, the consistency checks of `verify_transform` between two states of the key (the ratio proof's own
     verification -- a hash to the curve -- stays with the caller, who passes its (ratio_0, ratio_1) pair or None):
@@ -129,6 +143,22 @@ class Accumulator:
         self.alpha_tau_powers_g1 = batch_mul_pointwise(curve, 1, self.alpha_tau_powers_g1, [t * alpha % r for t in tp[:n2]])
         self.beta_tau_powers_g1 = batch_mul_pointwise(curve, 1, self.beta_tau_powers_g1, [t * beta % r for t in tp[:n2]])
         self.beta_g2 = batch_mul_fixed_scalar(curve, 2, self.beta_g2, beta)
+
+
+    def check_powers(self) -> str:
+        """kzg.rs:508-521, the power checks of the accumulator's `verify_transform`: every vector is a sequence of consecutive
+        powers of one tau (merged by `power_pairs`, compared with the first two G2 / G1 powers). "" or the error variant."""
+        c = self.curve
+        lhs, rhs = power_pairs(c, 2, self.tau_powers_g2)
+        if not same(c, (self.tau_powers_g1[0], rhs), (self.tau_powers_g1[1], lhs)):
+            return "TauG1Powers"
+        t2 = (self.tau_powers_g2[1], self.tau_powers_g2[0])
+        for vec, err in ((self.tau_powers_g1, "TauG2Powers"), (self.alpha_tau_powers_g1, "AlphaG1Powers"),
+                         (self.beta_tau_powers_g1, "BetaG1Powers")):
+            lhs, rhs = power_pairs(c, 1, vec)
+            if not same(c, (lhs, t2[0]), (rhs, t2[1])):
+                return err
+        return ""
 
 
 def lagrange_basis(curve, group, powers, D) -> np.ndarray:

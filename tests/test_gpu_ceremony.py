@@ -81,6 +81,11 @@ def test_ceremony_initialize_contribute_prove_verify(gpu, curve):
     t1, a1, b1 = 0x777777777777777888, 0x999999999999999aaa, 0xbbbbbbbbbbbbbbbccc
     acc.update(t1, a1, b1)                                   # kzg.rs:444-468
     tau, alpha, beta = t0 * t1 % r, a0 * a1 % r, b0 * b1 % r
+    assert acc.check_powers() == ""                          # kzg.rs:508-521 on the GPU (MSMs + pairing products)
+    keep = acc.alpha_tau_powers_g1.copy()
+    acc.alpha_tau_powers_g1[D // 2] = acc.tau_powers_g1[D // 2]
+    assert acc.check_powers() == "AlphaG1Powers"
+    acc.alpha_tau_powers_g1 = keep
     assert (acc.tau_powers_g1[5] == O.g_mul(curve, 1, G1, lim([pow(tau, 5, r)])[0])).all()
     assert (acc.alpha_tau_powers_g1[3] == O.g_mul(curve, 1, G1, lim([alpha * pow(tau, 3, r)])[0])).all()
     assert (acc.tau_powers_g2[D - 1] == O.g_mul(curve, 2, G2, lim([pow(tau, D - 1, r)])[0])).all()
