@@ -132,12 +132,14 @@ class MsmInstance:
     on the GPU by the library's fixed-base multiply), uniform scalars, both resident in HBM. The closed form
     sum_i k_i (S0 + i S1) mod r gives the expected global point from one scalar multiplication."""
 
-    def __init__(self, env, n_total, window_bits, seed):
+    def __init__(self, env, n_total, window_bits, seed, curve=CURVE):
         from manta_rs_amd import api, synth, distributed
         self.env, self.api = env, api
+        CURVE = self.curve = curve  # noqa: N806 (shadows the module default on purpose)
         p, q = synth.FR_MODULUS[CURVE], synth.FQ_MODULUS[CURVE]
         self.p = p
-        self.G = synth.to_mont(list(BLS_G1), q, 6).reshape(-1)
+        self.G = synth.to_mont(list(BLS_G1 if curve == 1 else (1, 2)), q, synth.FQ_LIMBS[curve]).reshape(-1)
+        self.launch_kw = {}
         lo, hi = distributed.shard_range(n_total, env.rank, env.world)
         self.n = hi - lo
         self.ks = [(S0 + i * S1) % p for i in range(lo, hi)]
@@ -154,7 +156,7 @@ class MsmInstance:
         part = sum(k * b for k, b in zip(self.synth.limbs_to_ints(self.scalars), self.ks))
         t = self.env.sum_ints_mod(part, self.p)
         d_one = self.api.DeviceBuffer.from_numpy(self.synth.ints_to_limbs([t], 4))
-        return self.api.fixed_base_mul(CURVE, 1, self.G, d_one, 1).to_numpy()
+        return self.api.fixed_base_mul(self.curve, 1, self.G, d_one, 1).to_numpy()
 
     def run(self, steps, depth, acc_ms=None):
         """`depth` MSMs in flight (each on its own HIP stream + workspace): the serial tail of step i (bucket reduce,
@@ -167,7 +169,7 @@ class MsmInstance:
                 acc_ms.append(self.api.last_accumulate_ms())  # HIP events around the accumulate kernel, on its stream
             return out
         for _ in range(steps):
-            pending.append(self.msm.launch(self.d_sc, self.n))
+            pending.append(self.msm.launch(self.d_sc, self.n, **self.launch_kw))
             if len(pending) == depth:
                 res = finish_one()
         while pending:
@@ -223,6 +225,28 @@ def msm_bench(args, env):
                  "bases_hbm_bytes": pb.device_bytes()}
         inst.bases, inst.msm = keep
         pb.close()
+    # ---- SURVEY.md 8(d) config 2, the rest of it: witness-like scalars (40 % zeros, 25 % ones, 10 % < 2^64, 25 % uniform)
+    # on the same bases through the zero-digit compaction path, and the BN254 instantiation at the same size
+    other = None
+    if env.world == 1 and not args.quick:
+        from manta_rs_amd import api, synth
+        keep = inst.scalars, inst.d_sc
+        inst.scalars = synth.msm_scalars(CURVE, n, "W", seed=0x4D414E57)
+        inst.d_sc, inst.launch_kw = api.DeviceBuffer.from_numpy(inst.scalars), {"sparse": True}
+        assert (inst.run(1, 1) == inst.expected()).all(), "witness-like MSM does not match the closed form"
+        dt_w1, _ = inst.timed(lat_steps, 1)
+        dt_w3, _ = inst.timed(lat_steps, DEPTH)
+        (inst.scalars, inst.d_sc), inst.launch_kw = keep, {}
+        bn = MsmInstance(env, n, WINDOW_BITS, seed=0x4D414E42, curve=0)
+        assert (bn.run(1, 1) == bn.expected()).all(), "BN254 MSM does not match the closed form"
+        dt_b1, _ = bn.timed(lat_steps, 1)
+        dt_b3, _ = bn.timed(lat_steps, DEPTH)
+        other = {"witness_like_scalars": {"latency_mode_Mscalar_s": round(n * lat_steps / dt_w1 / 1e6, 2),
+                                          "pipelined_Mscalar_s": round(n * lat_steps / dt_w3 / 1e6, 2)},
+                 "bn254_g1_uniform": {"latency_mode_Mscalar_s": round(n * lat_steps / dt_b1 / 1e6, 2),
+                                      "pipelined_Mscalar_s": round(n * lat_steps / dt_b3 / 1e6, 2), "algorithmic_bytes_per_scalar": 96}}
+        bn.bases.close()
+        del bn
     line["config"] = {
         "workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
         "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS, "msms_in_flight": DEPTH,
@@ -231,6 +255,7 @@ def msm_bench(args, env):
                 "BLS12-381 key needs 5 such tables, ~10 GB of the 288 GB)" % DEPTH,
         "latency_mode": {"Mscalar_s": round(env.world * n * lat_steps / dt_lat / 1e6, 2), "ms_per_msm": round(dt_lat / lat_steps * 1e3, 4)},
         "plain_bases": plain,
+        "other_inputs_same_size": other,
         "sharding": "contiguous base/scalar ranges, all_gather of partial points (RCCL) + N-term host sum" if env.world > 1 else "none"}
 
     roofline = cpu = None
