@@ -145,3 +145,22 @@ def test_gpu_batch_verification(gpu, curve, k):
     zero[k - 1] = 0
     with pytest.raises(gpu.MantaGpuError):
         gpu.groth16_verify_batch(vctx, inputs, proofs, zero)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_valid_pairing_ratio_like_the_reference(gpu, curve):
+    """manta-crypto/src/arkworks/pairing.rs:295-330 `{bls12_381,bn254}_has_valid_pairing_ratio`: for random g1, g2 and
+    scalar, E::same((g1, g2 * scalar), (g1 * scalar, g2)) holds -- on the GPU (`mg_pairing_check`), for several draws,
+    and fails as soon as one of the four points is off."""
+    from manta_rs_amd import ceremony
+    r = synth.FR_MODULUS[curve]
+    rng = synth.XorShift(0x5EED0 + curve)
+    G1, G2 = O.generator(curve, 1), O.generator(curve, 2)
+    lim = lambda k: synth.ints_to_limbs([k % r], 4)[0]
+    for _ in range(3):
+        g1, g2 = O.g_mul(curve, 1, G1, lim(rng.field(r))), O.g_mul(curve, 2, G2, lim(rng.field(r)))  # random group elements
+        k = rng.field(r)
+        g1k, g2k = O.g_mul(curve, 1, g1, lim(k)), O.g_mul(curve, 2, g2, lim(k))
+        assert ceremony.same(curve, (g1, g2k), (g1k, g2)) is True
+        assert ceremony.same(curve, (g1, g2k), (O.g_mul(curve, 1, g1, lim(k + 1)), g2)) is False
+        assert ceremony.same(curve, (g1, g2), (g1k, g2)) is False
