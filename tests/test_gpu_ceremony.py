@@ -147,3 +147,29 @@ def test_verify_transform_checks_on_a_contribution(gpu, curve):
     assert ceremony.same_ratio(curve, (G1, aP), (G2, O.g_mul(curve, 2, G2, lim([a + 1])[0]))) is False
     assert gpu.pairing_check(curve, np.stack([G1, np.zeros_like(G1)]), np.stack([np.zeros_like(G2), G2])) is True
     assert gpu.pairing_check(curve, G1.reshape(1, -1), G2.reshape(1, -1)) is False
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_trusted_setup_phase_two_is_valid_like_the_reference(gpu, curve):
+    """manta-trusted-setup/src/groth16/test/mod.rs:258-286 `trusted_setup_phase_two_is_valid`: five rounds of
+    contribute -> verify_transform on a small circuit, then a proof under the final key verifies (and not under the
+    initial one). Every bulk group operation, the merged-query checks and both pairings-based verifications run on the
+    GPU; the hash-to-group ratio proof is replaced by the pair it certifies."""
+    r = synth.FR_MODULUS[curve]
+    c = synth.make_circuit(curve, 13, 10, 2, seed=83)
+    first = state = O.groth16_setup(c, H.toxic(curve, seed=22))
+    G1 = O.generator(curve, 1)
+    lim = lambda k: synth.ints_to_limbs([k % r], 4)[0]
+    rng = synth.XorShift(0xCE4E0 + curve)
+    for rnd in range(5):
+        prev, delta, t = state, rng.field(r), rng.field(r)
+        state = ceremony.contribute(curve, prev, delta)
+        ratio = (O.g_mul(curve, 1, G1, lim(t)), O.g_mul(curve, 1, G1, lim(t * delta)))
+        assert ceremony.check_transform(curve, prev, state, ratio) == "", rnd
+    assert ceremony.check_transform(curve, first, state) == ""      # verify_transform_all's end-to-end checks, mpc.rs:543-559
+    ctx = gpu.ProvingContext(curve, state)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    rs = H.rand_fr_mont(curve, 2, seed=99)
+    proof = gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+    assert gpu.groth16_verify(gpu.VerifyingContext(curve, state), c.z[1:c.P], proof) is True
+    assert gpu.groth16_verify(gpu.VerifyingContext(curve, first), c.z[1:c.P], proof) is False
