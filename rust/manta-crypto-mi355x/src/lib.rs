@@ -467,6 +467,23 @@ impl<E: Mi355xCurve> GpuVerifyingContext<E> {
     }
 }
 
+/// `PairingEngineExt::has_same` / `same` (`manta-crypto/src/arkworks/pairing.rs:76-98`) on the GPU: `e(lhs.0, lhs.1) ==
+/// e(rhs.0, rhs.1)`, evaluated as the single product `e(lhs.0, lhs.1) e(-rhs.0, rhs.1) == 1` (`mg_pairing_check`). The
+/// trusted-setup verifier calls this on random linear combinations of whole queries (`mpc.rs:487-508`, `kzg.rs:503-521`).
+pub fn same<E: Mi355xCurve>(lhs: (E::G1Affine, E::G2Affine), rhs: (E::G1Affine, E::G2Affine)) -> Result<bool, Error> {
+    let g1 = flatten_g1::<E>(&[lhs.0, -rhs.0]);
+    let g2 = flatten_g2::<E>(&[lhs.1, rhs.1]);
+    let mut ok = 0;
+    // SAFETY: two G1 and two G2 points in the C ABI's affine Montgomery layout
+    check(unsafe { sys::mg_pairing_check(E::CURVE, g1.as_ptr(), g2.as_ptr(), 2, &mut ok) })?;
+    Ok(ok == 1)
+}
+
+/// `PairingEngineExt::same_ratio` (`pairing.rs:101-109`): `e(lhs.0, rhs.1) == e(lhs.1, rhs.0)`.
+pub fn same_ratio<E: Mi355xCurve>(lhs: (E::G1Affine, E::G1Affine), rhs: (E::G2Affine, E::G2Affine)) -> Result<bool, Error> {
+    same::<E>((lhs.0, rhs.1), (lhs.1, rhs.0))
+}
+
 /// `mg_init(device)`: bind the calling thread (and contexts created from it) to one GPU. One process per GPU is the
 /// deployment the benches assume; one process driving several GPUs uses the `devices` argument of
 /// [`GpuProvingContext::new`] instead.
