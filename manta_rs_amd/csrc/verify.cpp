@@ -11,7 +11,7 @@
 // Batch verification (the throughput companion of mg_groth16_prove_batch; ledger use manta-pay/src/simulation/ledger/
 // mod.rs:626-651): for caller-drawn 128-bit r_i,
 //     prod_i ML(r_i A_i, B_i) . ML(sum_i r_i PI_i, -gamma) . ML(sum_i r_i C_i, -delta) . ML(-(sum_i r_i) alpha, beta)  -> 1
-// i.e. k + 3 Miller loops (one lane each), two small MSMs and ONE final exponentiation for k proofs.
+// i.e. k + 3 Miller loops (one wavefront each, pairing_coop.h), two small MSMs and ONE final exponentiation for k proofs.
 #include "verify.h"
 #include "host_ec.h"
 #include "params_gen.h"
