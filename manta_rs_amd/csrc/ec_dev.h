@@ -167,20 +167,21 @@ template <class F> struct XYZZ {
         if constexpr (F::EXT) madd_call(q, neg);
         else madd_body(q, neg);
     }
-    // the mixed addition for THROUGHPUT-bound callers (>= 2 wavefronts per SIMD: the bucket-accumulate kernel): where the
-    // field has it, the single-chain coding of the products
+    // the mixed addition for THROUGHPUT-bound callers (>= 2 wavefronts per SIMD: the bucket-accumulate kernel): the
+    // single-chain coding of the products (fpr_dev.h mad_chain_*: every multiply-add of a column in ONE dependent chain,
+    // several links per asm block). Measured inside the 2^20 BLS12-381 accumulate launch, same box, three alternations:
+    // 2.56 ms against 2.63 ms for the compiler's two-chain coding (-3 %; MSM 363 against 355 Mscalar/s). A first version with
+    // one asm statement per multiply-add LOST 7 %: the compiler pads every asm statement with an s_nop (~3 400 per loop
+    // body). BN254's 9-limb kernel gains the same 3 % (1.55 against 1.60 ms per batched launch). MG_ACC_TWO_CHAINS restores
+    // the C coding for re-measurement.
     MG_DEV void madd_throughput(const Affine<F> &q, bool neg) {
         if constexpr (!F::EXT && F::LAZY) {
-            if constexpr (F::LAZY_LIMBS) {
-#ifdef MG_ACC_CHAIN // A/B build switch. Measured on MI355X inside the real kernel: SLOWER (2.69 ms against 2.52 ms for the 2^20
-                    // BLS12-381 accumulate launch) although the product alone gains 5 % in isolation -- hipcc pads the
-                    // dependent v_mad_u64_u32 chains with ~3400 s_nop per loop body. Kept for re-measurement only.
-                madd_lazy<true>(q, neg);
+#ifdef MG_ACC_TWO_CHAINS
+            madd_lazy<false>(q, neg);
 #else
-                madd_lazy<false>(q, neg);
+            madd_lazy<true>(q, neg);
 #endif
-                return;
-            }
+            return;
         }
         madd(q, neg);
     }

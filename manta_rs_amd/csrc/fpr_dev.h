@@ -26,9 +26,41 @@ namespace mg {
 // acc += a*b as ONE v_mad_u64_u32 the compiler may not re-associate: all multiply-adds of a column then form a single
 // dependent chain (the C expression is split into an a*b chain and an m*p chain joined by a v_lshl_add_u64 per column:
 // 28 more instructions per 14-limb product). Faster by 3.5-5.4 % at >= 2 wavefronts per SIMD, 35 % slower at one
-// (profiles/r02_ubench4_fma_vs_int.txt) -- so only the throughput-bound accumulate kernel asks for it (CH = true).
+// (profiles/r02_ubench4_fma_vs_int.txt) -- so only the throughput-bound accumulate kernel asks for it (CH = true), and
+// there it pays only with SEVERAL links per asm block (below): -3 % kernel time on both curves.
 MG_DEV void mad_chain_vv(u64 &acc, u32 a, u32 b) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc"); }
 MG_DEV void mad_chain_vs(u64 &acc, u32 a, u32 k) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(k) : "vcc"); }
+// Several links of the chain in ONE asm block: the compiler puts an s_nop after every asm statement (it cannot see inside),
+// which at one statement per multiply-add cost more than the single chain saved (~3 400 per loop body).
+MG_DEV void mad_chain_pair(u64 &acc, u32 a, u32 b, u32 m, u32 k) { // a*b + m*k
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(a), "v"(b), "v"(m), "s"(k) : "vcc");
+}
+MG_DEV void mad_chain_pair2(u64 &acc, u32 a0, u32 b0, u32 m0, u32 k0, u32 a1, u32 b1, u32 m1, u32 k1) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\tv_mad_u64_u32 %0, vcc, %7, %8, %0"
+        : "+v"(acc)
+        : "v"(a0), "v"(b0), "v"(m0), "s"(k0), "v"(a1), "v"(b1), "v"(m1), "s"(k1)
+        : "vcc");
+}
+MG_DEV void mad_chain_vv2(u64 &acc, u32 a0, u32 b0, u32 a1, u32 b1) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(a0), "v"(b0), "v"(a1), "v"(b1) : "vcc");
+}
+MG_DEV void mad_chain_vs2(u64 &acc, u32 m0, u32 k0, u32 m1, u32 k1) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(m0), "s"(k0), "v"(m1), "s"(k1) : "vcc");
+}
+MG_DEV void mad_chain_triple(u64 &acc, u32 a, u32 b, u32 c, u32 d, u32 m, u32 k) { // a*b + c*d + m*k
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0"
+        : "+v"(acc)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(m), "s"(k)
+        : "vcc");
+}
+MG_DEV void mad_chain_triple2(u64 &acc, u32 a0, u32 b0, u32 c0, u32 d0, u32 m0, u32 k0, u32 a1, u32 b1, u32 c1, u32 d1, u32 m1, u32 k1) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\tv_mad_u64_u32 %0, vcc, %9, %10, %0\n\tv_mad_u64_u32 %0, vcc, %11, %12, %0"
+        : "+v"(acc)
+        : "v"(a0), "v"(b0), "v"(c0), "v"(d0), "v"(m0), "s"(k0), "v"(a1), "v"(b1), "v"(c1), "v"(d1), "v"(m1), "s"(k1)
+        : "vcc");
+}
 
 template <class C> struct FpR {
     static constexpr int K = C::RR_K, LB = C::RR_LB;
@@ -245,10 +277,9 @@ template <class C> struct FpR {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
 #pragma unroll
-            for (int i = 0; i < k; ++i) {
-                mad_chain_vv(acc, a.v[i], b.v[k - i]);
-                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
-            }
+            for (int i = 0; i + 1 < k; i += 2)
+                mad_chain_pair2(acc, a.v[i], b.v[k - i], m[i], C::RR_P[k - i], a.v[i + 1], b.v[k - i - 1], m[i + 1], C::RR_P[k - i - 1]);
+            if (k & 1) mad_chain_pair(acc, a.v[k - 1], b.v[1], m[k - 1], C::RR_P[1]);
             mad_chain_vv(acc, a.v[k], b.v[0]);
             m[k] = ((u32)acc * C::RR_INV) & MASK;
             mad_chain_vs(acc, m[k], C::RR_P[0]);
@@ -256,11 +287,13 @@ template <class C> struct FpR {
         }
 #pragma unroll
         for (int k = K; k < 2 * K - 1; ++k) {
+            const int lo = k - K + 1, n = K - lo; // pairs i = lo .. K-1
 #pragma unroll
-            for (int i = k - K + 1; i < K; ++i) {
-                mad_chain_vv(acc, a.v[i], b.v[k - i]);
-                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+            for (int q = 0; q + 1 < n; q += 2) {
+                const int i = lo + q;
+                mad_chain_pair2(acc, a.v[i], b.v[k - i], m[i], C::RR_P[k - i], a.v[i + 1], b.v[k - i - 1], m[i + 1], C::RR_P[k - i - 1]);
             }
+            if (n & 1) mad_chain_pair(acc, a.v[K - 1], b.v[k - K + 1], m[K - 1], C::RR_P[k - K + 1]);
             t.v[k - K] = (u32)acc & MASK;
             acc >>= LB;
         }
@@ -276,18 +309,17 @@ template <class C> struct FpR {
         for (int i = 0; i < K; ++i) a2[i] = a.v[i] << 1;
 #pragma unroll
         for (int k = 0; k < 2 * K - 1; ++k) {
+            // cross products a_i a_j (i < j, i + j = k) against the doubled operand, two per asm block
+            const int ilo = k < K ? 0 : k - K + 1, ihi = (k - 1) / 2; // i = ilo .. ihi with i < k - i
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const int j = k - i;
-                if (j < 0 || j >= K) continue;
-                if (i < j) mad_chain_vv(acc, a2[i], a.v[j]);
-                if (i == j) mad_chain_vv(acc, a.v[i], a.v[i]);
-                if (k < K) {
-                    if (i < k) mad_chain_vs(acc, m[i], C::RR_P[k - i]);
-                } else {
-                    mad_chain_vs(acc, m[i], C::RR_P[k - i]);
-                }
-            }
+            for (int i = ilo; i + 1 <= ihi; i += 2) mad_chain_vv2(acc, a2[i], a.v[k - i], a2[i + 1], a.v[k - i - 1]);
+            if (k >= 1 && ((ihi - ilo + 1) & 1) && ihi >= ilo) mad_chain_vv(acc, a2[ihi], a.v[k - ihi]);
+            if (!(k & 1)) mad_chain_vv(acc, a.v[k / 2], a.v[k / 2]);
+            // the m_i p_{k-i} terms already known, two per block
+            const int mlo = k < K ? 0 : k - K + 1, mhi = k < K ? k - 1 : K - 1;
+#pragma unroll
+            for (int i = mlo; i + 1 <= mhi; i += 2) mad_chain_vs2(acc, m[i], C::RR_P[k - i], m[i + 1], C::RR_P[k - i - 1]);
+            if (mhi >= mlo && ((mhi - mlo + 1) & 1)) mad_chain_vs(acc, m[mhi], C::RR_P[k - mhi]);
             if (k < K) {
                 m[k] = ((u32)acc * C::RR_INV) & MASK;
                 mad_chain_vs(acc, m[k], C::RR_P[0]);
@@ -307,11 +339,10 @@ template <class C> struct FpR {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
 #pragma unroll
-            for (int i = 0; i < k; ++i) {
-                mad_chain_vv(acc, a.v[i], b.v[k - i]);
-                mad_chain_vv(acc, c.v[i], d.v[k - i]);
-                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
-            }
+            for (int i = 0; i + 1 < k; i += 2)
+                mad_chain_triple2(acc, a.v[i], b.v[k - i], c.v[i], d.v[k - i], m[i], C::RR_P[k - i], a.v[i + 1], b.v[k - i - 1],
+                                  c.v[i + 1], d.v[k - i - 1], m[i + 1], C::RR_P[k - i - 1]);
+            if (k & 1) mad_chain_triple(acc, a.v[k - 1], b.v[1], c.v[k - 1], d.v[1], m[k - 1], C::RR_P[1]);
             mad_chain_vv(acc, a.v[k], b.v[0]);
             mad_chain_vv(acc, c.v[k], d.v[0]);
             m[k] = ((u32)acc * C::RR_INV) & MASK;
@@ -320,12 +351,14 @@ template <class C> struct FpR {
         }
 #pragma unroll
         for (int k = K; k < 2 * K - 1; ++k) {
+            const int lo = k - K + 1, n = K - lo;
 #pragma unroll
-            for (int i = k - K + 1; i < K; ++i) {
-                mad_chain_vv(acc, a.v[i], b.v[k - i]);
-                mad_chain_vv(acc, c.v[i], d.v[k - i]);
-                mad_chain_vs(acc, m[i], C::RR_P[k - i]);
+            for (int q = 0; q + 1 < n; q += 2) {
+                const int i = lo + q;
+                mad_chain_triple2(acc, a.v[i], b.v[k - i], c.v[i], d.v[k - i], m[i], C::RR_P[k - i], a.v[i + 1], b.v[k - i - 1],
+                                  c.v[i + 1], d.v[k - i - 1], m[i + 1], C::RR_P[k - i - 1]);
             }
+            if (n & 1) mad_chain_triple(acc, a.v[K - 1], b.v[k - K + 1], c.v[K - 1], d.v[k - K + 1], m[K - 1], C::RR_P[k - K + 1]);
             t.v[k - K] = (u32)acc & MASK;
             acc >>= LB;
         }
