@@ -226,7 +226,9 @@ int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len,
 int mg_ctx_set_r1cs(mg_ctx *ctx, const mg_csr *a, const mg_csr *b, const mg_csr *c, uint64_t num_constraints);
 /* One proof. z = instance || witness (V x 4 u64 Montgomery), r, s = the two blinding scalars drawn by
  * the shim with the reference's own RNG in create_random_proof's order (Montgomery).
- * proof_out: 128 B (BN254) / 192 B (BLS12-381). */
+ * proof_out: 128 B (BN254) / 192 B (BLS12-381). Re-entrant on one context: calls that arrive while two passes are on
+ * the GPU are grouped into ONE batched pass by the next caller (the reference's simulation drives a context from six
+ * threads, manta-pay/src/bin/simulation.rs:36-38); the bytes of a proof do not depend on the grouping. */
 int mg_groth16_prove(const mg_ctx *ctx, const uint64_t *z_mont, const uint64_t r_mont[4], const uint64_t s_mont[4],
                      uint8_t *proof_out);
 /* k proofs of the context's circuit (throughput mode: a wallet / ledger simulation proving many transfers

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <shared_mutex>
 #include <thread>
@@ -62,6 +63,7 @@ struct ProveWs {
     hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
     bool graphs_ready = false;
     u32 k = 1; // proofs per pass (the slot's buffers and its captured graph are sized for exactly this batch)
+    std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
     int eager_runs = 0;
@@ -155,7 +157,7 @@ class ProverImpl : public Prover {
     std::map<u32, std::vector<ProveWs *>> ws_free_; // idle proof slots, by batch size
     size_t idle_slots_ = 0;
     u64 lru_tick_ = 0;
-    static constexpr size_t MAX_IDLE_SLOTS = 6; // per context: beyond it the least recently used idle slot is destroyed
+    static constexpr size_t MAX_IDLE_SLOTS = 12; // (six batch sizes of coalesced calls x two passes in flight) per context: beyond it the least recently used idle slot is destroyed
 
     ~ProverImpl() override {
         for (ProverImpl *q : peers_) delete q;
@@ -483,7 +485,11 @@ class ProverImpl : public Prover {
     int upload_z(ProveWs *w, const uint64_t *z) {
         int rc = reserve_witness_map(w);
         if (rc) return rc;
-        MG_HIP(hipMemcpyAsync(w->z.p, z, (size_t)w->k * V_ * 32, hipMemcpyHostToDevice, w->stream));
+        if (w->z_parts.size() == w->k) { // coalesced single calls: one copy per assignment, from where it lies
+            for (u32 q = 0; q < w->k; ++q)
+                MG_HIP(hipMemcpyAsync((char *)w->z.p + (size_t)q * V_ * 32, w->z_parts[q], (size_t)V_ * 32, hipMemcpyHostToDevice, w->stream));
+        } else
+            MG_HIP(hipMemcpyAsync(w->z.p, z, (size_t)w->k * V_ * 32, hipMemcpyHostToDevice, w->stream));
         MG_HIP(hipEventRecord(w->z_ready, w->stream));
         return MG_OK;
     }
@@ -662,8 +668,79 @@ class ProverImpl : public Prover {
         return ok;
     }
 
+    // ---- one proof. Concurrent callers on one context are COALESCED: while COALESCE_INFLIGHT passes are on the GPU, further
+    // calls queue up, and the next caller to find a pass slot free takes everything queued (up to BATCH_CHUNK) as ONE batched
+    // pass -- the wallet / ledger simulation of the reference drives one ProvingContext from six threads
+    // (manta-pay/src/bin/simulation.rs:36-38, simulation/mod.rs:75-79), each proving one transfer at a time; measured on
+    // MI355X, PrivateTransfer shape, single calls from 1 / 2 / 3 / 4 / 6 threads without coalescing: 964 / 1 254 / 1 130 /
+    // 1 108 / 1 068 proofs/s (the passes only share the GPU's queues), against ~3 900 for explicit batches. A lone caller
+    // is never delayed (it leads a pass of one at once); batch sizes are rounded up to a power of two by repeating the first
+    // request (slots and captured graphs exist per batch size), the surplus proofs are dropped. Proof bytes do not depend
+    // on how calls were grouped. Sharded contexts and MANTA_COALESCE=0 take the direct path.
+    struct Req {
+        const uint64_t *z, *r, *s;
+        uint8_t *out;
+        int rc = MG_OK;
+        bool done = false;
+    };
+    std::mutex cq_mu_;
+    std::condition_variable cq_cv_;
+    std::deque<Req *> cq_;
+    int cq_inflight_ = 0;
+    static int coalesce_inflight() {
+        static const int n = [] {
+            const char *e = std::getenv("MANTA_COALESCE");
+            const int v = e ? std::atoi(e) : 2;
+            return v >= 0 && v <= 4 ? v : 2;
+        }();
+        return n;
+    }
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
-        return prove_batch(1, z, r, s, proof_out);
+        if (!z || !r || !s || !proof_out) return MG_ERR_ARG;
+        if (coalesce_inflight() == 0 || !peers_.empty()) return prove_pass(1, z, r, s, proof_out);
+        Req me{z, r, s, proof_out};
+        std::unique_lock<std::mutex> lk(cq_mu_);
+        cq_.push_back(&me);
+        for (;;) {
+            if (me.done) return me.rc;
+            if (cq_inflight_ < coalesce_inflight() && !cq_.empty()) { // lead a pass: everything queued, oldest first
+                std::vector<Req *> batch;
+                while (!cq_.empty() && batch.size() < BATCH_CHUNK) {
+                    batch.push_back(cq_.front());
+                    cq_.pop_front();
+                }
+                ++cq_inflight_;
+                lk.unlock();
+                const int rc = prove_gathered(batch);
+                lk.lock();
+                for (Req *q : batch) q->rc = rc, q->done = true;
+                --cq_inflight_;
+                cq_cv_.notify_all();
+                continue;
+            }
+            cq_cv_.wait(lk);
+        }
+    }
+    // one pass over the requests of `batch` (padded to a power of two with copies of the first one)
+    int prove_gathered(const std::vector<Req *> &batch) {
+        const size_t k = batch.size();
+        if (k == 1) return prove_pass(1, batch[0]->z, batch[0]->r, batch[0]->s, batch[0]->out);
+        size_t kp = 1;
+        while (kp < k) kp <<= 1;
+        const size_t pbytes = 2 * (size_t)g1_->point_bytes(true) + (size_t)g2_->point_bytes(true);
+        std::vector<const uint64_t *> zl(kp);
+        std::vector<uint64_t> rr(kp * 4), ss(kp * 4);
+        std::vector<uint8_t> out(kp * pbytes);
+        for (size_t q = 0; q < kp; ++q) {
+            const Req *src = batch[q < k ? q : 0];
+            zl[q] = src->z;
+            std::memcpy(&rr[q * 4], src->r, 32);
+            std::memcpy(&ss[q * 4], src->s, 32);
+        }
+        const int rc = prove_pass(kp, nullptr, rr.data(), ss.data(), out.data(), zl.data());
+        if (!rc)
+            for (size_t q = 0; q < k; ++q) std::memcpy(batch[q]->out, &out[q * pbytes], pbytes);
+        return rc;
     }
 
     // k proofs of this circuit. Up to BATCH_CHUNK of them are ONE pass of the GPU pipeline (k = 1: a single proof): the
@@ -729,7 +806,8 @@ class ProverImpl : public Prover {
         }
         gate_cv_.notify_one();
     }
-    int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) {
+    int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out,
+                   const uint64_t *const *z_list = nullptr) {
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
         locks.emplace_back(shape_mu_);
@@ -741,7 +819,7 @@ class ProverImpl : public Prover {
         int rc = MG_OK;
         for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
-        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out);
+        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list);
         return finish_pass(p, rc, &pp);
     }
 
@@ -762,7 +840,9 @@ class ProverImpl : public Prover {
     }
 
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
-    int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out) {
+    // (z_list: the k assignments as separate buffers -- coalesced single calls -- gathered into the slot's staging copy)
+    int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out,
+                    const uint64_t *const *z_list = nullptr) {
         MG_HIP(hipSetDevice(dev_));
         p.k = k, p.r = r, p.s = s, p.out = out;
         ProveWs *w = p.w = ws_acquire(k);
@@ -772,7 +852,35 @@ class ProverImpl : public Prover {
         // the assignment is uploaded from where it is if the caller keeps it in page-locked memory
         // (mg_host_alloc), else through the slot's pinned staging copy
         const uint64_t *z_src = z;
-        if (!is_page_locked(z)) {
+        w->z_parts.clear();
+        bool stage = !z_list && !is_page_locked(z);
+        if (z_list) { // page-locked assignments are uploaded in place, the others through their part of the staging copy
+            w->z_parts.assign(z_list, z_list + k);
+            std::vector<char> pageable(k, 0);
+            for (u32 q = 0; q < k; ++q) {
+                bool seen = false;
+                for (u32 t = 0; t < q && !seen; ++t)
+                    if (z_list[t] == z_list[q]) pageable[q] = pageable[t], seen = true; // (padding repeats request 0)
+                if (!seen) pageable[q] = !is_page_locked(z_list[q]);
+                stage = stage || pageable[q];
+            }
+            if (stage) {
+                if (w->h_z_cap < zbytes) {
+                    if (w->h_z) hipHostFree(w->h_z);
+                    w->h_z = nullptr;
+                    w->h_z_cap = 0;
+                    if (hipHostMalloc(&w->h_z, zbytes, hipHostMallocDefault) != hipSuccess) return MG_ERR_OOM;
+                    w->h_z_cap = zbytes;
+                }
+                for (u32 q = 0; q < k; ++q)
+                    if (pageable[q]) {
+                        std::memcpy((char *)w->h_z + (size_t)q * V_ * 32, z_list[q], (size_t)V_ * 32);
+                        w->z_parts[q] = (const uint64_t *)((char *)w->h_z + (size_t)q * V_ * 32);
+                    }
+            }
+            stage = false;
+        }
+        if (stage) {
             if (w->h_z_cap < zbytes) {
                 if (w->h_z) hipHostFree(w->h_z);
                 w->h_z = nullptr;

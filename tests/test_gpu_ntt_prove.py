@@ -284,6 +284,41 @@ def test_prove_batch_longer_than_a_pass_is_streamed(gpu):
         assert single[q] == O.groth16_prove(zs[q], pk, rs[q], rs[k + q]), q
 
 
+def test_concurrent_single_proofs_are_coalesced_and_stay_byte_identical(gpu):
+    """Six host threads proving one transfer at a time on ONE context (the reference's simulation does exactly this,
+    manta-pay/src/bin/simulation.rs:36-38): the library groups whatever calls are waiting into batched passes (sizes
+    rounded up to a power of two). Every proof must still be the bytes of the oracle for its own (z, r, s), whichever
+    calls it shared a pass with; one member has r = 0."""
+    import threading
+    curve = 0
+    c0 = synth.make_circuit(curve, 300, 260, 4, seed=62)
+    pk = O.groth16_setup(c0, H.toxic(curve, seed=16))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c0))
+    n_threads, per = 6, 12
+    n = n_threads * per
+    zs = [synth.reassign(c0, seed=400 + q) for q in range(n)]
+    rs = H.rand_fr_mont(curve, 2 * n, seed=82).copy()
+    rs[5] = 0
+    want = [O.groth16_prove(zs[q], pk, rs[q], rs[n + q]) for q in range(n)]
+    got = [None] * n
+    errs = []
+
+    def worker(t):
+        try:
+            for j in range(per):
+                q = t * per + j
+                got[q] = gpu.Groth16.prove_with_randomness(ctx, zs[q].z, rs[q], rs[n + q])
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    for rep in range(3):  # slots of every batch size go through eager, eager, capture, replay
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errs, errs
+        assert got == want, rep
+
+
 def test_prove_batch_real_shape_with_r_zero_member(gpu):
     """ToPrivate-shape circuit, batch of 4 with one member's r = 0 (that member skips g1_b like create_proof)."""
     curve = 0
