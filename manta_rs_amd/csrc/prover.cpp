@@ -943,6 +943,23 @@ class ProverImpl : public Prover {
         p.w = nullptr;
     }
 
+    // The host side of a pass is ~0.15 ms per proof (two 254-bit scalar multiplications in one doubling chain, four table
+    // multiplications, three serialisations with a field inversion each): nothing next to a single proof, but 5 ms of a
+    // 32-proof pass whose GPU side is 8.6 ms. Batches of eight or more spread it over a few library threads.
+    template <class Fn> static void for_each_proof(u32 k, Fn &&fn) {
+        const u32 nt = k >= 8 ? (k >= 16 ? 4u : 2u) : 1u;
+        if (nt == 1) {
+            for (u32 q = 0; q < k; ++q) fn(q);
+            return;
+        }
+        std::vector<std::thread> th;
+        for (u32 t = 1; t < nt; ++t)
+            th.emplace_back([&, t] {
+                for (u32 q = t; q < k; q += nt) fn(q);
+            });
+        for (u32 q = 0; q < k; q += nt) fn(q);
+        for (auto &x : th) x.join();
+    }
     int finish_pass(Pass &p, int rc, std::vector<Pass> *peer_passes = nullptr) {
         ProveWs *w = p.w;
         if (!w || rc) {
@@ -961,7 +978,7 @@ class ProverImpl : public Prover {
         };
         std::vector<Blind> bl(k);
         if (!rc) {
-            for (u32 q = 0; q < k; ++q) {
+            for_each_proof(k, [&](u32 q) {
                 Blind &b = bl[q];
                 u64 rs_m[4];
                 fr_->fr_to_canonical(r + 4 * q, b.rc4);
@@ -972,7 +989,7 @@ class ProverImpl : public Prover {
                 g1_->hp_table_mul(delta1_tab_, b.sc4, &b.t_sd);
                 g1_->hp_table_mul(delta1_tab_, b.rs4, &b.t_rsd);
                 g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
-            }
+            });
         }
         std::vector<HostPoint> res((size_t)5 * k), tmp; // res[i * k + q]: MSM i of proof q
         auto collect = [&](hipStream_t, bool part_a) { // wait for one part on every shard and fold its MSMs
@@ -996,7 +1013,7 @@ class ProverImpl : public Prover {
         // ---- part A is back: the G1 side of the assembly runs while the G2 MSM finishes
         collect(w->stream, true); // every G1 MSM stream has been joined into it
         if (!rc) {
-            for (u32 q = 0; q < k; ++q) {
+            for_each_proof(k, [&](u32 q) {
                 Blind &b = bl[q];
                 const uint64_t *rq = r + 4 * q;
                 const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
@@ -1019,7 +1036,7 @@ class ProverImpl : public Prover {
                 uint8_t *out = p.out + (size_t)q * (2 * b1 + b2);
                 g1_->hp_serialize(&g_a, out, true);
                 g1_->hp_serialize(&g_c, out + b1 + b2, true);
-            }
+            });
         }
         // ---- part B: the G2 element
         collect(msm_stream(w, 2), false);
@@ -1032,12 +1049,12 @@ class ProverImpl : public Prover {
                 pg.w = nullptr;
             }
         if (rc) return rc;
-        for (u32 q = 0; q < k; ++q) {
+        for_each_proof(k, [&](u32 q) {
             HostPoint g2_b = res[2 * (size_t)k + q];
             g2_->hp_add(&g2_b, &b20_beta_);
             g2_->hp_add(&g2_b, &bl[q].t_sd2);
             g2_->hp_serialize(&g2_b, p.out + (size_t)q * (2 * b1 + b2) + b1, true);
-        }
+        });
         return MG_OK;
     }
 };
