@@ -945,9 +945,9 @@ class ProverImpl : public Prover {
 
     // The host side of a pass is ~0.15 ms per proof (two 254-bit scalar multiplications in one doubling chain, four table
     // multiplications, three serialisations with a field inversion each): nothing next to a single proof, but 5 ms of a
-    // 32-proof pass whose GPU side is 8.6 ms. Batches of eight or more spread it over a few library threads.
+    // 32-proof pass whose GPU side is 8.6 ms. Batches spread it over up to four library threads.
     template <class Fn> static void for_each_proof(u32 k, Fn &&fn) {
-        const u32 nt = k >= 8 ? (k >= 16 ? 4u : 2u) : 1u;
+        const u32 nt = k >= 4 ? 4u : k; // (a thread start is ~30 us against ~150 us of work per proof)
         if (nt == 1) {
             for (u32 q = 0; q < k; ++q) fn(q);
             return;
