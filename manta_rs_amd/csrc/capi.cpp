@@ -183,6 +183,7 @@ static void job_abandon(mg_msm_job *job) {
     for (JobShard &j : job->sh) {
         hipSetDevice(j.device);
         hipStreamSynchronize(j.ws->stream);
+        if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
         j.ws->pending = 0;
         j.eng->ws_release(j.ws);
         if (j.d_tmp) hipFree(j.d_tmp);
@@ -264,6 +265,8 @@ MG_API int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine) {
         int rc2 = j.eng->msm_finish(j.ws, &hp);
         if (rc2) {
             hipStreamSynchronize(j.ws->stream);
+                if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
+        if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
             j.ws->pending = 0;
         } else {
             e0->hp_add(&total, &hp);

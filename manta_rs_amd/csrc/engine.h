@@ -13,6 +13,17 @@ namespace mg {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// Wave issue priority of everything that is NOT the bucket-accumulate kernel. A SIMD's arbiter serves the oldest wavefront
+// first; next to the two resident accumulate wavefronts of a neighbouring MSM (VALU busy 91 %) a younger wavefront of a
+// sort / merge / reduce kernel got one issue slot in ten -- traced on MI355X with three MSMs in flight: radix_scatter 1 232 us
+// instead of 110, tile_reduce_coop 1 842 instead of 110. These kernels are short chains with little total work, so they go
+// first (s_setprio 3) and the accumulate kernel of the other MSM fills every slot they leave.
+#ifdef MG_NO_PRIO
+#define MG_PRIO_HIGH() ((void)0)
+#else
+#define MG_PRIO_HIGH() __builtin_amdgcn_s_setprio(3)
+#endif
+
 enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_HIP = 2, MG_ERR_OOM = 3, MG_ERR_DOMAIN = 4, MG_ERR_STATE = 5 };
 
 #define MG_HIP(expr)                                                                                              \
@@ -74,10 +85,19 @@ struct BaseSet {
 struct MsmWorkspace {
     DevBuf keys_in, keys_out, vals_in, vals_out, sort_tmp, buckets, pkeys[2], ppts[2], redA, redS, misc;
     DevBuf count; // number of (key, value) pairs the digit kernel produced (zero digits are compacted away)
+    // work-efficient front levels of the bucket reduce (msm_impl.h serial_reduce): per-lane (A, S) arrays and the
+    // temporaries of the plain sums; `extra` = one staged point per (front level, window segment)
+    DevBuf front, extra;
+    static constexpr int MAX_EXTRA = 8;
+    u32 tail_shift = 0, n_extra = 0, extra_shift[MAX_EXTRA] = {}; // window = 2^tail_shift * tail + sum_e 2^shift_e * extra_e
+    size_t extra_off_pts = 0;                                       // where the extras start in h_stage (points)
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
     hipStream_t run_on = nullptr; // when set, msm_launch enqueues on this stream instead of the workspace's own
+    // stand-alone MSMs: the plain sums of the bucket reduce's front levels run here, beside the weighted chain
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
     bool timed = false;

@@ -33,6 +33,24 @@
 
 namespace mg {
 
+// A/B switch: cap the registers of the tail kernels (merge, bucket reduce) so that they fit next to the two resident
+// wavefronts of an accumulate kernel of a neighbouring MSM (160 VGPRs each: 192 are left per SIMD lane)
+#ifdef MG_TAIL_WAVES
+#define MG_TAIL_ATTR __attribute__((amdgpu_waves_per_eu(MG_TAIL_WAVES, MG_TAIL_WAVES)))
+#define MG_SERIAL_ATTR MG_TAIL_ATTR
+#ifdef MG_TAIL_COOP_SLIM
+#define MG_TAIL_COOP_ATTR MG_TAIL_ATTR
+#else
+#define MG_TAIL_COOP_ATTR
+#endif
+#else
+#define MG_TAIL_ATTR
+#define MG_TAIL_COOP_ATTR
+// serial_reduce holds three points (acc, sum, the loaded item): 266 VGPRs left alone = one wavefront per SIMD; capped at
+// 256 (30 spilled) two fit, and the big first level (2^19 buckets at c = 20) runs at the issue rate of two wavefronts
+#define MG_SERIAL_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
+#endif
+
 // --------------------------------------------------------------------------------------------
 // K5: digits
 // --------------------------------------------------------------------------------------------
@@ -51,6 +69,7 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
                                                      const u32 *__restrict__ map, u32 n_scalars,
                                                      size_t scalar_stride, u32 seg_keys, u32 *__restrict__ count) {
+    MG_PRIO_HIGH();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     // blockIdx.y = scalar vector of a batch: its own scalars, its own range of bucket keys; the bases (and so
     // the values) are shared
@@ -243,9 +262,10 @@ __global__ __launch_bounds__(256) void gather_only_chunks(const u32 *__restrict_
 // and last runs become the next level's two entries. 64*G entries -> 2 per wave.
 // --------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void merge_partials(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
+__global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                       u32 invalid, int final_level, u32 *__restrict__ buckets,
                                                       u32 *__restrict__ okeys, u32 *__restrict__ opts, u32 n_waves) {
+    MG_PRIO_HIGH();
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -335,9 +355,10 @@ __global__ __launch_bounds__(256) void merge_partials(u32 *__restrict__ pkeys, u
 // its four wavefronts hold identical copies of the lanes' state and share every addition. Same contract as
 // merge_partials; used for the levels with few logical waves, which are nothing but dependent additions.
 template <class F>
-__global__ __launch_bounds__(256) void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
+__global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                            u32 invalid, int final_level, u32 *__restrict__ buckets,
                                                            u32 *__restrict__ okeys, u32 *__restrict__ opts) {
+    MG_PRIO_HIGH();
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x; // logical wave
@@ -436,9 +457,10 @@ __global__ __launch_bounds__(256) void merge_partials_coop(u32 *__restrict__ pke
 //   A = sum_j X_j,  S = sum_j (j+1) X_j  -- via suffix scan (acc_j = sum_{i>=j} X_i) then sum of acc_j.
 // --------------------------------------------------------------------------------------------
 template <class F>
-__global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/,
+__global__ __launch_bounds__(256) MG_TAIL_ATTR void tile_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                    u32 item_off, u32 n_items, u32 tiles_per_seg, u32 n_waves,
                                                    u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
+    MG_PRIO_HIGH();
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= n_waves) return;
@@ -477,13 +499,77 @@ __global__ __launch_bounds__(256) void tile_reduce(const u32 *__restrict__ in, u
     }
 }
 
+// --------------------------------------------------------------------------------------------
+// K8 front level (work-efficient): every LANE walks S consecutive items from the top with a running sum,
+//   A = sum_i X_i,   Sx = sum_i (i+1) X_i   (i = 0 .. S-1 inside the lane's stretch)
+// -- 2 (S-1) additions for S items where the wavefront scan of tile_reduce spends 12 per item. With lane t covering
+// items tS .. tS+S-1:  sum_k (k+1) X_k = sum_t Sx_t + S * sum_{t>=1} t A_t, i.e. a plain sum of the Sx_t plus S times the
+// SAME weighted sum over the A_t (t >= 1), S times shorter: levels of this kernel shrink a window of 2^19 buckets (c = 20)
+// to a few thousand items for the scan kernels below, and make wide windows affordable (2^20 BLS12-381 G1: the c = 20
+// accumulate kernel is 20 % shorter than the c = 16 one, and the scan-only reduce gave all of it back).
+// outS == nullptr: plain partial sums (one addition per item), used for the sums of the Sx arrays.
+// --------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) MG_SERIAL_ATTR void serial_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/, u32 item_off,
+                                                     u32 n_items, u32 S, u32 lanes_per_seg, u32 n_lanes,
+                                                     u32 *__restrict__ outA, u32 *__restrict__ outS) {
+    MG_PRIO_HIGH();
+    constexpr size_t XW = XYZZ<F>::WORDS;
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_lanes) return;
+    const u32 seg = g / lanes_per_seg, l = g % lanes_per_seg;
+    const u32 i0 = l * S;
+    u32 i1 = i0 + S;
+    if (i1 > n_items) i1 = n_items;
+    const u32 *base = in + ((size_t)seg * seg_stride + item_off) * XW;
+    XYZZ<F> acc = XYZZ<F>::inf(), sum = XYZZ<F>::inf();
+    for (u32 i = i1; i-- > i0;) {
+        const XYZZ<F> x = XYZZ<F>::load(base + (size_t)i * XW);
+        acc.add(x);
+        if (outS) sum.add(acc);
+    }
+    acc.store(outA + (size_t)g * XW);
+    if (outS) sum.store(outS + (size_t)g * XW);
+}
+
+// serial_reduce with cooperative additions (CoopAdd, ec_dev.h): one 64-lane logical wave per 256-thread workgroup, whose four
+// wavefronts hold identical copies and share every addition (4 product-times instead of 14). For the levels with few lanes --
+// from the second level on the front levels are chains of 2 (S-1) dependent additions and nothing else.
+template <class F>
+__global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void serial_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/, u32 item_off,
+                                                          u32 n_items, u32 S, u32 lanes_per_seg, u32 n_lanes,
+                                                          u32 *__restrict__ outA, u32 *__restrict__ outS) {
+    MG_PRIO_HIGH();
+    __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
+    constexpr size_t XW = XYZZ<F>::WORDS;
+    const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
+    const u32 g = blockIdx.x * 64 + lane;
+    const bool live = g < n_lanes;
+    const u32 seg = live ? g / lanes_per_seg : 0, l = live ? g % lanes_per_seg : 0;
+    const u32 i0 = l * S;
+    const u32 *base = in + ((size_t)seg * seg_stride + item_off) * XW;
+    XYZZ<F> acc = XYZZ<F>::inf(), sum = XYZZ<F>::inf();
+    for (u32 j = S; j-- > 0;) { // uniform trip count: the additions contain barriers
+        const u32 i = i0 + j;
+        XYZZ<F> x = XYZZ<F>::inf();
+        if (live && i < n_items) x = XYZZ<F>::load(base + (size_t)i * XW);
+        CoopAdd<F>::add(acc, x, lds, pw, lane);
+        if (outS) CoopAdd<F>::add(sum, acc, lds, pw, lane);
+    }
+    if (live && pw == 0) {
+        acc.store(outA + (size_t)g * XW);
+        if (outS) sum.store(outS + (size_t)g * XW);
+    }
+}
+
 // The same with the additions spread over the four wavefronts of the workgroup (CoopAdd, ec_dev.h): one tile per
 // workgroup, every wave holds the same 64 items. For the few-tile reduces of proof-sized MSMs, where the kernel is
 // nothing but a chain of dependent additions.
 template <class F>
-__global__ __launch_bounds__(256) void tile_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/,
+__global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void tile_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                         u32 item_off, u32 n_items, u32 tiles_per_seg,
                                                         u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
+    MG_PRIO_HIGH();
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     const u32 tile_id = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -530,8 +616,9 @@ __global__ __launch_bounds__(256) void tile_reduce_coop(const u32 *__restrict__ 
 // Together with the level-0 tile_reduce that is 12 + 2*log2(T0) dependent additions (20 for B = 1024)
 // instead of 36 over three launches -- on a latency-bound tail the depth is what matters.
 template <class F>
-__global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
+__global__ __launch_bounds__(128) MG_TAIL_ATTR void reduce_level1(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
                                                      u32 *__restrict__ out_std) {
+    MG_PRIO_HIGH();
     constexpr int XW = XYZZ<F>::WORDS;
     constexpr int SW = XYZZ<typename F::Std>::WORDS;
     const u32 seg = blockIdx.x;
@@ -559,8 +646,9 @@ __global__ __launch_bounds__(128) void reduce_level1(const u32 *__restrict__ A0,
 // reduce_level1 with cooperative additions: two 256-thread workgroups per window (blockIdx.x & 1: 0 = the X part,
 // 1 = the sum of the S_t), each spreading its additions over its four wavefronts.
 template <class F>
-__global__ __launch_bounds__(256) void reduce_level1_coop(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
+__global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void reduce_level1_coop(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
                                                           u32 *__restrict__ out_std) {
+    MG_PRIO_HIGH();
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr int XW = XYZZ<F>::WORDS;
     constexpr int SW = XYZZ<typename F::Std>::WORDS;
@@ -1117,6 +1205,41 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         return M < ((size_t)8 << 20) ? 16u : 4u;
     }
 
+    // front levels of the bucket reduce (serial_reduce): 2^lgS0 items per lane while a level has >= 2^18 items, 2^lgS below
+    // (MANTA_RED_S0 / MANTA_RED_S; MANTA_RED_S=0, the default: scan kernels only), applied while a window segment has at
+    // least min_items items (MANTA_RED_MIN); 2^lgSP items per lane in the plain sums of the Sx arrays (MANTA_RED_SP), which
+    // run on a side stream next to the weighted chain unless MANTA_RED_SIDE=0.
+    // OFF by default -- measured on MI355X, 2^20 BLS12-381 G1 (profiles/r03_window_and_tail_study.txt): with MANTA_RED_S=3 one
+    // MSM at a time gets 5 % faster at c = 16 (3.66 -> 3.48 ms) and c = 20 becomes usable (3.83 ms against 5.2 ms with the scan
+    // kernels alone), but with three MSMs in flight -- the headline -- nothing is gained at c = 16 (343 against 348 Mscalar/s
+    // inline, 315 with the side stream: two more streams on the runtime's four hardware queues) and c = 20 stays behind
+    // (300-340): the accumulate kernel of c = 20 is 19 % shorter, and its reduce is eight more dependent launches of 70-220 us
+    // that cannot share a SIMD with the two resident accumulate wavefronts of the neighbouring MSMs (216-298 VGPRs each
+    // against the 192 those leave free), so they queue behind whole accumulate kernels.
+    struct RedKnobs {
+        int lgS0, lgS, lgSP;
+        u32 min_items;
+        bool side;
+    };
+    static const RedKnobs &red_knobs() {
+        static const RedKnobs k = [] {
+            RedKnobs r{2, 0, 3, 16384u, true};
+            auto env = [](const char *n, int lo, int hi, int dflt) {
+                const char *e = getenv(n);
+                if (!e) return dflt;
+                const int v = atoi(e);
+                return v < lo ? lo : (v > hi ? hi : v);
+            };
+            r.lgS0 = env("MANTA_RED_S0", 1, 8, r.lgS0);
+            r.lgS = env("MANTA_RED_S", 0, 8, r.lgS);
+            r.lgSP = env("MANTA_RED_SP", 1, 8, r.lgSP);
+            r.min_items = (u32)env("MANTA_RED_MIN", 128, 1 << 30, (int)r.min_items);
+            r.side = env("MANTA_RED_SIDE", 0, 1, 1) != 0;
+            return r;
+        }();
+        return k;
+    }
+
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, int scalar_mode, int c_override,
                    MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) override {
@@ -1206,31 +1329,113 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         // ---- bucket reduce
         const u32 segs = batch * (u32)pl.Wb;
-        const u32 T0 = cdiv(pl.B, 64);
+        // what the scan kernels below reduce: (array, points per segment, first item, items); the front levels replace
+        // the bucket array by their A arrays
+        const u32 *rin = ws->buckets.as<u32>();
+        u32 rstride = pl.B, roff = 0, rn = pl.B, tail_shift = 0, n_extra = 0;
+        u32 extra_shift[MsmWorkspace::MAX_EXTRA] = {};
+        hipStream_t side = nullptr; // plain sums of the front levels run beside the weighted chain (stand-alone MSMs)
+        {
+            const RedKnobs &rk = red_knobs();
+            if (rk.lgS > 0 && rn >= rk.min_items) {
+                if (!ws->capturing && !ws->run_on && rk.side) {
+                    if (!ws->side_stream) {
+                        MG_HIP(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking));
+                        MG_HIP(hipEventCreateWithFlags(&ws->side_fork, hipEventDisableTiming));
+                        MG_HIP(hipEventCreateWithFlags(&ws->side_join, hipEventDisableTiming));
+                    }
+                    side = ws->side_stream;
+                }
+                // one level: lanes of 2^lg items; cooperative additions when the level has few lanes
+                auto level = [&](hipStream_t st, const u32 *in, u32 stride, u32 off, u32 n, int lg, u32 lanes, u32 *A, u32 *Sx) {
+                    const size_t nl = (size_t)segs * lanes;
+                    if (cdiv(nl, 64) <= coop_waves())
+                        hipLaunchKernelGGL((serial_reduce_coop<F>), dim3(cdiv(nl, 64)), dim3(256), 0, st, in, stride, off, n, 1u << lg,
+                                           lanes, (u32)nl, A, Sx);
+                    else
+                        hipLaunchKernelGGL((serial_reduce<F>), dim3(cdiv(nl, 256)), dim3(256), 0, st, in, stride, off, n, 1u << lg,
+                                           lanes, (u32)nl, A, Sx);
+                };
+                // two passes over the same loop: sizes first (one reservation), then the launches
+                for (int pass = 0; pass < 2; ++pass) {
+                    size_t used = 0; // points
+                    auto take = [&](size_t pts) {
+                        u32 *p = pass ? ws->front.as<u32>() + used * XW : nullptr;
+                        used += pts;
+                        return p;
+                    };
+                    const u32 *in = ws->buckets.as<u32>();
+                    u32 stride = pl.B, off = 0, n = pl.B, shift = 0, ne = 0;
+                    while (n >= rk.min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
+                        // the big first levels are throughput-bound: short stretches = enough lanes for two wavefronts per SIMD;
+                        // below that a level is a latency chain either way and longer stretches save a level
+                        const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : rk.lgS;
+                        const u32 lanes = cdiv(n, 1u << lg);
+                        u32 *A = take((size_t)segs * lanes), *Sx = take((size_t)segs * lanes);
+                        if (pass) level(s, in, stride, off, n, lg, lanes, A, Sx);
+                        // plain sum of the Sx_t: serial partial sums until one tile per segment is left, then one wavefront
+                        hipStream_t ps = side ? side : s;
+                        if (pass && side) {
+                            MG_HIP(hipEventRecord(ws->side_fork, s));
+                            MG_HIP(hipStreamWaitEvent(side, ws->side_fork, 0));
+                        }
+                        const u32 *pin = Sx;
+                        u32 pcnt = lanes;
+                        while (pcnt > 64) {
+                            int plg = rk.lgSP;
+                            while (plg > 1 && (pcnt >> plg) < 32 && pcnt > 64u << 1) --plg; // do not shrink below a tile
+                            const u32 pl2 = cdiv(pcnt, 1u << plg);
+                            u32 *t = take((size_t)segs * pl2);
+                            if (pass) level(ps, pin, pcnt, 0u, pcnt, plg, pl2, t, (u32 *)nullptr);
+                            pin = t;
+                            pcnt = pl2;
+                        }
+                        if (pass) {
+                            u32 *dst = ws->extra.as<u32>() + (size_t)ne * segs * XW_IO;
+                            if (coop_tiles(segs))
+                                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, ps, pin, pcnt, 0u, pcnt, 1u, dst,
+                                                   (u32 *)nullptr, 1);
+                            else
+                                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, ps, pin, pcnt, 0u, pcnt,
+                                                   1u, segs, dst, (u32 *)nullptr, 1);
+                        }
+                        extra_shift[ne++] = shift;
+                        shift += lg;
+                        in = A, stride = lanes, off = 1, n = lanes - 1;
+                    }
+                    if (!pass) {
+                        if ((rc = ws->front.reserve(used * XW * 4)) ||
+                            (rc = ws->extra.reserve((size_t)MsmWorkspace::MAX_EXTRA * segs * XW_IO * 4)))
+                            return rc;
+                    } else {
+                        rin = in, rstride = stride, roff = off, rn = n, tail_shift = shift, n_extra = ne;
+                    }
+                }
+            }
+        }
+        const u32 T0 = cdiv(rn, 64);
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
         constexpr int XWM = XW > XW_IO ? XW : XW_IO;
         if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
             if (coop_tiles(segs))
-                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, s, ws->buckets.as<u32>(), pl.B, 0u, pl.B, 1u,
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, s, rin, rstride, roff, rn, 1u,
                                    ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             else
-                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                                   pl.B, 0u, pl.B, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, rin, rstride, roff, rn, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             stage_pts = segs;
-            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 <= 64) { // two launches: tiles, then (X, sumS) per window
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
                 (rc = ws->misc.reserve((size_t)segs * 2 * XW_IO * 4)))
                 return rc;
             if (coop_tiles(segs * T0))
-                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs * T0), dim3(256), 0, s, ws->buckets.as<u32>(), pl.B, 0u, pl.B,
+                hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs * T0), dim3(256), 0, s, rin, rstride, roff, rn,
                                    T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
             else
-                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                                   pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
+                hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, rin, rstride, roff, rn, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
             if (coop_tiles(segs * 2))
                 hipLaunchKernelGGL((reduce_level1_coop<F>), dim3(segs * 2), dim3(256), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(),
                                    T0, ws->misc.as<u32>());
@@ -1238,14 +1443,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 hipLaunchKernelGGL((reduce_level1<F>), dim3(segs), dim3(128), 0, s, ws->redA.as<u32>(), ws->redS.as<u32>(), T0,
                                    ws->misc.as<u32>());
             stage_pts = (size_t)segs * 2;
-            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
             T1 = 0xffffffffu; // marks the (X, sumS) layout for msm_finish
         } else {
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
                 return rc;
-            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, ws->buckets.as<u32>(),
-                               pl.B, 0u, pl.B, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
+            hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * T0, 4)), dim3(256), 0, s, rin, rstride, roff, rn, T0, segs * T0, ws->redA.as<u32>(), ws->redS.as<u32>(), 0);
             T1 = cdiv(T0 - 1, 64); // level 1 over A0[1..T0-1]
             nP = cdiv(T0, 64);     // plain sums of S0[0..T0-1]
             if ((rc = ws->misc.reserve((size_t)segs * (2 * T1 + nP) * XW_IO * 4))) return rc;
@@ -1265,9 +1469,20 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs * nP, 4)), dim3(256), 0, s,
                                    ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr, 1);
             stage_pts = (size_t)segs * (2 * T1 + nP);
-            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
+        if (n_extra && side) { // the plain sums ran on the side stream: join
+            MG_HIP(hipEventRecord(ws->side_join, side));
+            MG_HIP(hipStreamWaitEvent(s, ws->side_join, 0));
+        }
+        if (n_extra)
+            MG_HIP(hipMemcpyAsync((u32 *)ws->h_stage + stage_pts * XW_IO, ws->extra.p, (size_t)n_extra * segs * XW_IO * 4,
+                                  hipMemcpyDeviceToHost, s));
+        ws->tail_shift = tail_shift;
+        ws->n_extra = n_extra;
+        for (u32 e = 0; e < n_extra; ++e) ws->extra_shift[e] = extra_shift[e];
+        ws->extra_off_pts = stage_pts;
         if (!ws->capturing) MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());
         ws->plan = pl;
@@ -1328,6 +1543,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 HP sumP = HP::inf();
                 for (u32 u = 0; u < nP; ++u) sumP = HP::add(sumP, HP::from_xyzz_words(P0 + (size_t)u * XW_IO));
                 win = HP::add(sumP, HP::mul_pow2(X, 6));
+            }
+            if (ws->tail_shift) win = HP::mul_pow2(win, ws->tail_shift); // front levels: window = 2^shift * tail + extras
+            for (u32 e = 0; e < ws->n_extra; ++e) {
+                const HP x = HP::from_xyzz_words(st + (ws->extra_off_pts + (size_t)e * segs + (size_t)w) * XW_IO);
+                win = HP::add(win, ws->extra_shift[e] ? HP::mul_pow2(x, ws->extra_shift[e]) : x);
             }
             if (w != (int)((q + 1) * Wb) - 1) total = HP::mul_pow2(total, (unsigned)pl.c);
             total = HP::add(total, win);

@@ -98,12 +98,15 @@ void stream_pool_put(hipStream_t s) {
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
-                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count};
+                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (done) hipEventDestroy(done);
     if (t0) hipEventDestroy(t0);
     if (t1) hipEventDestroy(t1);
+    if (side_fork) hipEventDestroy(side_fork);
+    if (side_join) hipEventDestroy(side_join);
+    if (side_stream) hipStreamDestroy(side_stream);
     if (stream) hipStreamDestroy(stream);
 }
 

@@ -27,6 +27,7 @@ static constexpr int SORT_ITEMS = 16;
 // beyond the count contribute zero histograms and no elements)
 __global__ __launch_bounds__(256) void radix_hist(const u32 *__restrict__ keys, u32 M, int shift, u32 ntiles,
                                                   u32 *__restrict__ hist, const u32 *__restrict__ count) {
+    MG_PRIO_HIGH();
     if (count) M = *count;
     if ((size_t)blockIdx.x * SORT_TILE >= M) { // a tile past the last element: an all-zero histogram column
         hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = 0;
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void radix_hist(const u32 *__restrict__ keys, 
 
 // exclusive scan of every digit row hist[d][0..ntiles) in place (one workgroup per digit) + the row total
 __global__ __launch_bounds__(256) void radix_scan_rows(u32 *__restrict__ hist, u32 ntiles, u32 *__restrict__ totals) {
+    MG_PRIO_HIGH();
     __shared__ u32 part[256];
     u32 *row = hist + (size_t)blockIdx.x * ntiles;
     const u32 per = (ntiles + 255) / 256;
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(256) void radix_scan_rows(u32 *__restrict__ hist, u
 }
 // exclusive scan of the 256 row totals in place
 __global__ __launch_bounds__(256) void radix_scan_totals(u32 *__restrict__ totals) {
+    MG_PRIO_HIGH();
     __shared__ u32 part[256];
     const u32 mine = totals[threadIdx.x];
     part[threadIdx.x] = mine;
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void radix_scatter(const u32 *__restrict__ key
                                                      u32 *__restrict__ keys_out, u32 *__restrict__ vals_out, u32 M,
                                                      int shift, u32 ntiles, const u32 *__restrict__ hist,
                                                      const u32 *__restrict__ totals, const u32 *__restrict__ count) {
+    MG_PRIO_HIGH();
     if (count) M = *count;
     if ((size_t)blockIdx.x * SORT_TILE >= M) return; // a tile past the last element
     __shared__ u32 wcount[4][256]; // per-wave running digit counts, then per-wave tile-local offsets

@@ -1,11 +1,15 @@
 """GPU parity: Pippenger MSM (HIP, through the C ABI) vs the CPU oracle, bit-exact.
 Mirrors how ark-groth16 calls VariableBaseMSM::multi_scalar_mul."""
+import os
+
 import numpy as np
 import pytest
 
 import helpers as H
 import oracle_lib as O
 from manta_rs_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -156,3 +160,46 @@ def test_msm_sparse_hint_compacts_zero_digits(gpu, curve, group, pre):
     sc = cases["W"][:m]
     got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(sc), m, sparse=True).finish()
     assert (got == O.msm(curve, group, pts[:m], sc, algo=1)).all()
+
+
+_FRONT_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np
+import oracle_lib as O
+from manta_rs_amd import api as gpu, synth
+gpu.init(0)
+curve, n = {curve}, 1 << 15
+p = synth.FR_MODULUS[curve]
+s0, s1 = 0x1234567, 0x89abcdef1
+ks = synth.ints_to_limbs([(s0 + i * s1) % p for i in range(n)], 4)
+G = O.generator(curve, {group})
+dpts = gpu.fixed_base_mul(curve, {group}, G, gpu.DeviceBuffer.from_numpy(ks), n)
+for dist in ("U", "W"):
+    sc = synth.msm_scalars(curve, n, dist, seed=77)
+    t = sum(k * ((s0 + i * s1) % p) for i, k in enumerate(synth.limbs_to_ints(sc))) % p
+    want = O.g_mul(curve, {group}, G, synth.ints_to_limbs([t], 4)[0])
+    for pre in {pres}:
+        b = gpu.Bases(curve, {group}, (dpts.ptr, n), precompute_window_bits=pre, on_device=True)
+        got = gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(sc), n, sparse=(dist == "W")).finish()
+        assert (got == want).all(), (dist, pre)
+        b.close()
+print("front levels ok")
+'''
+
+
+@pytest.mark.parametrize("curve,group,pres,env", [
+    (1, 1, (16, 20), {"MANTA_RED_S": "3"}),                                              # one / two-three front levels, side stream
+    (1, 1, (14, 18), {"MANTA_RED_S": "2", "MANTA_RED_MIN": "1024", "MANTA_RED_SIDE": "0", "MANTA_RED_SP": "2"}),  # many levels, inline
+    (0, 1, (16,), {"MANTA_RED_S": "3", "MANTA_RED_S0": "3"}),
+    (0, 2, (15,), {"MANTA_RED_S": "3", "MANTA_RED_MIN": "2048"}),                        # G2: the additions are calls
+])
+def test_msm_reduce_front_levels(gpu, curve, group, pres, env):
+    """The optional work-efficient front levels of the bucket reduce (serial_reduce / serial_reduce_coop, msm_impl.h; off by
+    default, knobs are read once per process, hence the child process): closed-form check at n = 2^15 for window widths
+    whose bucket windows are long enough to take one to several levels, uniform and witness-like scalars."""
+    import subprocess
+    import sys
+    code = _FRONT_SCRIPT.format(root=ROOT, curve=curve, group=group, pres=pres)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "front levels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
