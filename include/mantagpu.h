@@ -107,6 +107,17 @@ int mg_msm_launch(const mg_bases *bases, const uint64_t *d_scalars, size_t n, in
 int mg_msm_launch_sharded(const mg_bases *bases, const uint64_t *const *d_scalars_per_shard, int scalar_flags,
                           int window_bits, mg_msm_job **job);
 int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine_mont); /* waits, folds, adds the shards' partial points, frees the job */
+/* The result of a job left on the DEVICE instead of the host: the window sums are folded by one more small kernel behind
+ * the MSM (bases with precomputed multiples only, else MG_ERROR_STATE: plain bases end in a 255-doubling Horner chain,
+ * a host job) and the point -- X | Y | ZZ | ZZZ in arkworks' Montgomery limbs, x = X/ZZ, y = Y/ZZZ, ZZ = 0 for infinity;
+ * mg_xyzz_limbs() u64 -- is written to d_out_xyzz. `stream` (a hipStream_t; NULL = the default stream) is made to wait for it, so a
+ * consumer on another stream -- the RCCL all_gather of the range-sharded MSM (partial points gathered
+ * from device memory) -- needs no host synchronisation between launch and collective. The job is still released with
+ * mg_msm_finish (out_affine_mont may be NULL). Single-shard jobs only. */
+int mg_msm_result_to_device(mg_msm_job *job, uint64_t *d_out_xyzz, void *stream);
+size_t mg_xyzz_limbs(mg_curve_t curve, int group); /* u64 per XYZZ point: 16 / 24 (G1), 32 / 48 (G2) */
+/* sum of n XYZZ points (host memory, the layout above) -> one affine point: the N-term sum after the all_gather */
+int mg_xyzz_sum(mg_curve_t curve, int group, const uint64_t *xyzz, size_t n, uint64_t *out_affine_mont);
 /* sum of the registered points themselves (multi-GPU partial-point reduction, tests) */
 int mg_points_sum(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, uint64_t *out_affine_mont);
 /* [k_i] * base for n canonical scalars in HBM -> n affine points in HBM (fixed-base batch multiply:
@@ -216,6 +227,25 @@ int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
 int mg_ctx_create_sharded(mg_curve_t curve, const mg_pk_view *pk, const int *devices, int n_devices, mg_ctx **out);
 int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, size_t len, const int *devices,
                                      int n_devices, mg_ctx **out);
+/* One process per GPU (what `python -m torch.distributed.run` starts; BASELINE configs[3] "MSM sharded across 8 x MI355X via
+ * RCCL/xGMI"; caller: manta-accounting/src/transfer/mod.rs:695-715 -> groth16.rs:589-600): THIS process holds shard
+ * `shard` of `n_shards` -- the same contiguous slices mg_ctx_create_sharded gives device g -- on the current device.
+ *   mg_groth16_partials_launch: uploads z (every rank has the whole assignment and recomputes the witness map), runs the five
+ *     MSMs over this shard's slices and leaves, per proof, the five partial results a | b_g1 | b_g2 | l | h folded on the
+ *     device in slots of mg_partials_slot_limbs() u64 (XYZZ points as in mg_msm_result_to_device, G1 ones padded) at
+ *     d_out[k][5][slot]; `stream` (hipStream_t, e.g. the stream RCCL runs on) waits for them. k <= 32. No host sync.
+ *   mg_groth16_partials_finish: returns the pass's slot once the consumer has read d_out.
+ *   mg_groth16_assemble: parts = n_parts gathered copies of [k][5][slot] in HOST memory (one fused all_gather of <= 1.9 KB
+ *     per rank and proof); adds them and finishes the proofs exactly like mg_groth16_prove -- bytes identical to the
+ *     single-GPU context's. Host-only work: any rank (or all) may call it. */
+int mg_ctx_create_shard(mg_curve_t curve, const mg_pk_view *pk, int shard, int n_shards, mg_ctx **out);
+typedef struct mg_partials_job mg_partials_job;
+size_t mg_partials_slot_limbs(const mg_ctx *ctx);
+int mg_groth16_partials_launch(const mg_ctx *ctx, uint64_t k, const uint64_t *z_mont, uint64_t *d_out, void *stream,
+                               mg_partials_job **job);
+int mg_groth16_partials_finish(mg_partials_job *job);
+int mg_groth16_assemble(const mg_ctx *ctx, uint64_t k, int n_parts, const uint64_t *parts, const uint64_t *r_mont,
+                        const uint64_t *s_mont, uint8_t *proofs_out);
 /* Same, from the key's wire format: arkworks 0.3 `ProvingKey::serialize_unchecked` bytes (uncompressed points,
  * no curve checks) exactly as `ProvingContext::decode` reads them (manta-crypto/src/arkworks/groth16.rs:268-288)
  * and `generate_parameters` / manta-parameters ship them (data/pay/proving/ *.lfs). */

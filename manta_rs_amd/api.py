@@ -47,6 +47,8 @@ def _load():
     lib.mg_last_accumulate_ms.restype = ctypes.c_float
     lib.mg_vk_encoded_size.restype = ctypes.c_size_t
     lib.mg_vk_num_inputs.restype = ctypes.c_uint64
+    lib.mg_xyzz_limbs.restype = ctypes.c_size_t
+    lib.mg_partials_slot_limbs.restype = ctypes.c_size_t
     return lib
 
 
@@ -63,6 +65,8 @@ EXPORTS = [
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
     "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
+    "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
+    "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble",
 ]
 
 
@@ -77,6 +81,17 @@ def _p(a):
 
 def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _addr(x):
+    """a device / stream address given as int, ctypes.c_void_p or DeviceBuffer -> c_void_p"""
+    if x is None:
+        return None
+    if isinstance(x, ctypes.c_void_p):
+        return x
+    if hasattr(x, "ptr"):
+        return _addr(x.ptr)
+    return _vp(int(x))
 
 
 def init(device=0):
@@ -201,6 +216,7 @@ class Bases:
             _chk(LIB.mg_bases_create(curve, group, _p(pts), _sz(self.n), 0, int(precompute_window_bits),
                                      ctypes.byref(h)), "mg_bases_create")
         self.handle = h
+        self.precompute_window_bits = int(precompute_window_bits)
 
     def device_bytes(self):
         return LIB.mg_bases_device_bytes(self.handle)
@@ -236,6 +252,17 @@ class MsmJob:
         self.handle = None
         return out
 
+    def result_to_device(self, d_out_ptr, stream=None):
+        """`mg_msm_result_to_device`: the window sums are folded on the GPU and the XYZZ result is written to device memory
+        at d_out_ptr (xyzz_limbs u64); `stream` (raw hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream; None or
+        0 = the default stream) is made to wait for it. No host synchronisation. The job must still be released with release()."""
+        _chk(LIB.mg_msm_result_to_device(self.handle, _addr(d_out_ptr), _addr(stream)), "mg_msm_result_to_device")
+
+    def release(self):
+        """waits for the job and frees it without converting the result (its consumer took it on the device)"""
+        _chk(LIB.mg_msm_finish(self.handle, None), "mg_msm_finish")
+        self.handle = None
+
 
 class VariableBaseMSM:
     """Mirror of ark_ec::msm::VariableBaseMSM (ark-ec 0.3.0; call sites in ark-groth16 create_proof,
@@ -269,6 +296,18 @@ class VariableBaseMSM:
         _chk(LIB.mg_msm_launch_sharded(bases.handle, arr, int(bool(scalars_mont)) | (2 if sparse else 0), int(window_bits),
                                        ctypes.byref(h)), "mg_msm_launch_sharded")
         return MsmJob(bases, h)
+
+
+def xyzz_limbs(curve, group) -> int:
+    return int(LIB.mg_xyzz_limbs(curve, group))
+
+
+def xyzz_sum(curve, group, xyzz) -> np.ndarray:
+    """sum of XYZZ points (arkworks Montgomery limbs X | Y | ZZ | ZZZ, ZZ = 0: infinity) -> one affine point"""
+    pts = _u64(xyzz).reshape(-1, xyzz_limbs(curve, group))
+    out = np.zeros(affine_limbs(curve, group), dtype=np.uint64)
+    _chk(LIB.mg_xyzz_sum(curve, group, _p(pts), _sz(pts.shape[0]), _p(out)), "mg_xyzz_sum")
+    return out
 
 
 def points_sum(curve, group, points):
@@ -435,17 +474,21 @@ class ProvingContext:
     """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
     device-resident proving key; created once, shared by every proof of the shape."""
 
-    def __init__(self, curve, pk, devices=None):
+    def __init__(self, curve, pk, devices=None, shard=None):
         """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
         b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P.
         devices: list of HIP device indices -> every MSM of a proof is range-sharded over them
-        (`mg_ctx_create_sharded`); None -> the current device."""
+        (`mg_ctx_create_sharded`); None -> the current device.
+        shard = (g, G): this PROCESS holds slice g of G of every query on the current device (`mg_ctx_create_shard`,
+        one process per GPU; see distributed.ShardedProver)."""
         self.curve = curve
         self._keep = [_u64(getattr(pk, k)) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2",
                                                      "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
         v = _PkView(pk.V, pk.P, self._keep[8].shape[0], *[_p(a) for a in self._keep])
         h = _vp()
-        if devices is None:
+        if shard is not None:
+            _chk(LIB.mg_ctx_create_shard(curve, ctypes.byref(v), int(shard[0]), int(shard[1]), ctypes.byref(h)), "mg_ctx_create_shard")
+        elif devices is None:
             _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")
         else:
             dv = (ctypes.c_int * len(devices))(*devices)
@@ -508,6 +551,38 @@ class ProvingContext:
     @property
     def domain_size(self):
         return LIB.mg_ctx_domain_size(self.handle)
+
+    # ---- process-per-GPU sharding: partial results on the device, gathered by a collective, assembled on the host
+    @property
+    def partials_slot_limbs(self):
+        return int(LIB.mg_partials_slot_limbs(self.handle))
+
+    def partials_launch(self, zs, k, d_out_ptr, stream=None):
+        """`mg_groth16_partials_launch`: this shard's five partial MSM results of k proofs -> device memory at d_out_ptr
+        ([k][5][slot] u64); `stream` waits for them. Returns a handle for partials_finish()."""
+        zs = self._check_assignment(zs, k)
+        h = _vp()
+        _chk(LIB.mg_groth16_partials_launch(self.handle, ctypes.c_uint64(k), _p(zs), _addr(d_out_ptr), _addr(stream),
+                                            ctypes.byref(h)), "mg_groth16_partials_launch")
+        return h
+
+    @staticmethod
+    def partials_finish(job):
+        _chk(LIB.mg_groth16_partials_finish(job), "mg_groth16_partials_finish")
+
+    def assemble(self, parts, rs, ss) -> list:
+        """`mg_groth16_assemble`: parts [n_parts][k][5][slot] u64 (the gathered partial results), rs / ss k blinding
+        scalars each -> k proofs (bytes)."""
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(-1, 4)
+        ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
+        k = rs.shape[0]
+        slot = self.partials_slot_limbs
+        parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, k, 5, slot)
+        n = PROOF_BYTES[self.curve]
+        out = ctypes.create_string_buffer(n * k)
+        _chk(LIB.mg_groth16_assemble(self.handle, ctypes.c_uint64(k), int(parts.shape[0]), _p(parts), _p(rs), _p(ss), out),
+             "mg_groth16_assemble")
+        return [out.raw[i * n:(i + 1) * n] for i in range(k)]
 
     def witness_map(self, z):
         h = np.zeros((self.domain_size, 4), dtype=np.uint64)

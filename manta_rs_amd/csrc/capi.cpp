@@ -280,6 +280,38 @@ MG_API int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine) {
     return rc;
     MG_CATCH
 }
+MG_API int mg_msm_result_to_device(mg_msm_job *job, uint64_t *d_out_xyzz, void *stream) {
+    MG_TRY
+    if (!job || job->sh.size() != 1 || !d_out_xyzz) return MG_ERROR_INVALID_ARGUMENT;
+    JobShard &j = job->sh[0];
+    DeviceGuard guard;
+    MG_HIP(hipSetDevice(j.device));
+    int rc = j.eng->msm_fold_device(j.ws, (u32 *)d_out_xyzz, (size_t)j.eng->xyzz_words());
+    if (rc) return rc;
+    hipStream_t ms = j.ws->run_on ? j.ws->run_on : j.ws->stream;
+    MG_HIP(hipEventRecord(j.ws->done, ms)); // mg_msm_finish waits for this event: now it covers the fold as well
+    if ((hipStream_t)stream != ms) MG_HIP(hipStreamWaitEvent((hipStream_t)stream, j.ws->done, 0)); // NULL = the default stream
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API size_t mg_xyzz_limbs(mg_curve_t curve, int group) {
+    GroupEngine *e = get_engine((int)curve, group);
+    return e ? (size_t)e->xyzz_words() / 2 : 0;
+}
+MG_API int mg_xyzz_sum(mg_curve_t curve, int group, const uint64_t *xyzz, size_t n, uint64_t *out_affine) {
+    MG_TRY
+    GroupEngine *e = get_engine((int)curve, group);
+    if (!e || !xyzz || !out_affine) return MG_ERROR_INVALID_ARGUMENT;
+    HostPoint acc, t;
+    e->hp_set_inf(&acc);
+    for (size_t i = 0; i < n; ++i) {
+        e->hp_from_xyzz(&t, (const u32 *)xyzz + i * (size_t)e->xyzz_words());
+        e->hp_add(&acc, &t);
+    }
+    e->hp_to_affine(&acc, (u32 *)out_affine);
+    return MG_SUCCESS;
+    MG_CATCH
+}
 MG_API int mg_msm(const mg_bases *b, const uint64_t *scalars, size_t n, uint64_t *out_affine) {
     MG_TRY
     if (!b || !scalars || !out_affine || b->sh.empty()) return MG_ERROR_INVALID_ARGUMENT;
@@ -409,6 +441,47 @@ MG_API int mg_ctx_create_sharded(mg_curve_t curve, const mg_pk_view *pk, const i
     if (rc) return rc;
     *out = new mg_ctx{p};
     return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_ctx_create_shard(mg_curve_t curve, const mg_pk_view *pk, int shard, int n_shards, mg_ctx **out) {
+    MG_TRY
+    if (!out || shard < 0 || n_shards < 1) return MG_ERROR_INVALID_ARGUMENT;
+    Prover *p = nullptr;
+    int rc = prover_create_shard((int)curve, pk, (u32)shard, (u32)n_shards, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+struct mg_partials_job {
+    Prover *p;
+    void *job;
+};
+MG_API size_t mg_partials_slot_limbs(const mg_ctx *ctx) { return ctx ? ctx->p->slot_words() / 2 : 0; }
+MG_API int mg_groth16_partials_launch(const mg_ctx *ctx, uint64_t k, const uint64_t *z, uint64_t *d_out, void *stream,
+                                      mg_partials_job **job) {
+    MG_TRY
+    if (!ctx || !job) return MG_ERROR_INVALID_ARGUMENT;
+    void *j = nullptr;
+    int rc = ctx->p->partials_launch(k, z, d_out, stream, &j);
+    if (rc) return rc;
+    *job = new mg_partials_job{ctx->p, j};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_groth16_partials_finish(mg_partials_job *job) {
+    MG_TRY
+    if (!job) return MG_ERROR_INVALID_ARGUMENT;
+    int rc = job->p->partials_finish(job->job);
+    delete job;
+    return rc;
+    MG_CATCH
+}
+MG_API int mg_groth16_assemble(const mg_ctx *ctx, uint64_t k, int n_parts, const uint64_t *parts, const uint64_t *r,
+                               const uint64_t *s, uint8_t *proofs_out) {
+    MG_TRY
+    if (!ctx || n_parts < 1) return MG_ERROR_INVALID_ARGUMENT;
+    return ctx->p->assemble(k, (u32)n_parts, parts, r, s, proofs_out);
     MG_CATCH
 }
 MG_API int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, size_t len, const int *devices,

@@ -91,6 +91,8 @@ struct MsmWorkspace {
     static constexpr int MAX_EXTRA = 8;
     u32 tail_shift = 0, n_extra = 0, extra_shift[MAX_EXTRA] = {}; // window = 2^tail_shift * tail + sum_e 2^shift_e * extra_e
     size_t extra_off_pts = 0;                                       // where the extras start in h_stage (points)
+    const u32 *d_tail = nullptr; // device copy of what msm_launch staged for the host fold (arkworks-format XYZZ points)
+    DevBuf folded;               // msm_fold_device: one arkworks-format XYZZ point per batch member
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
@@ -150,9 +152,19 @@ class GroupEngine {
     // already_synced: the caller has synchronised with the work itself (hipGraph replay of a whole proof)
     virtual int msm_finish(MsmWorkspace *ws, HostPoint *out, bool already_synced = false) = 0;
 
+    // The host fold of msm_finish done on the DEVICE instead (bases with precomputed multiples only: one bucket window, no
+    // Horner doublings): enqueues one small kernel behind the MSM on its stream and leaves ws->batch arkworks-format XYZZ
+    // points, out_stride_words u32 apart, at d_out (device memory) -- for consumers that live on the device, i.e. the
+    // partial-point exchange of the sharded paths (RCCL all_gather straight from HBM, no host bounce). The workspace is
+    // still handed back through msm_finish / msm_discard.
+    virtual int msm_fold_device(MsmWorkspace *ws, u32 *d_out, size_t out_stride_words, hipStream_t on = nullptr) = 0;
+    // an MSM whose result was taken on the device: wait for its stream, clear `pending`
+    virtual int msm_discard(MsmWorkspace *ws) = 0;
+
     // host-point helpers (type-erased)
     virtual void hp_set_inf(HostPoint *p) const = 0;
     virtual void hp_from_affine(HostPoint *p, const u32 *affine_words) const = 0;
+    virtual void hp_from_xyzz(HostPoint *p, const u32 *xyzz_words) const = 0; // arkworks-format X | Y | ZZ | ZZZ (ZZ = 0: infinity)
     virtual void hp_add(HostPoint *acc, const HostPoint *o) const = 0;
     virtual void hp_neg(HostPoint *p) const = 0;
     virtual void hp_mul(HostPoint *p, const u64 *k4) const = 0; // p = [k]p, k canonical 4x u64

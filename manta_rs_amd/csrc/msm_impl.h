@@ -677,6 +677,61 @@ __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void reduce_level1_coop(cons
     if (threadIdx.x == 0) acc.store_std(out_std + ((size_t)seg * 2 + part) * SW);
 }
 
+// --------------------------------------------------------------------------------------------
+// K9 on the device: the fold msm_finish does on the host, for one bucket window per scalar vector (bases with precomputed
+// multiples). One wavefront per vector; every lane computes the same chain (a dozen additions and doublings), lane 0 stores.
+// Layouts (arkworks-format XYZZ points, as staged for the host): kind 0 = the window sum itself; kind 1 = (X, sumS) pairs,
+// window = sumS + 2^6 X; kind 2 = A1[T1] | S1[T1] | P0[nP] blocks over all vectors, X = sum S1 + 2^6 sum_u u A1[u],
+// window = sum P0 + 2^6 X. Front levels: window = 2^tail_shift * that + sum_e 2^shift_e * extra_e.
+// --------------------------------------------------------------------------------------------
+struct FoldDesc {
+    const u32 *tail, *extra;
+    u32 kind, T1, nP, segs, n_extra, tail_shift;
+    u32 extra_shift[8];
+};
+template <class F>
+__global__ __launch_bounds__(64) void fold_windows(FoldDesc d, u32 *__restrict__ out, size_t out_stride) {
+    MG_PRIO_HIGH();
+    typedef typename F::Std S;
+    constexpr int SW = XYZZ<S>::WORDS;
+    const u32 q = blockIdx.x;
+    auto ld = [](const u32 *p) {
+        const XYZZ<S> s = XYZZ<S>::load(p);
+        if (s.is_inf()) return XYZZ<F>::inf();
+        return XYZZ<F>{F::from_std(s.x), F::from_std(s.y), F::from_std(s.zz), F::from_std(s.zzz)};
+    };
+    auto pow2 = [](XYZZ<F> p, u32 k) {
+        for (u32 i = 0; i < k; ++i) p = XYZZ<F>::dbl(p);
+        return p;
+    };
+    XYZZ<F> win = XYZZ<F>::inf();
+    if (d.kind == 0) {
+        win = ld(d.tail + (size_t)q * SW);
+    } else if (d.kind == 1) {
+        win = pow2(ld(d.tail + ((size_t)q * 2 + 0) * SW), 6);
+        win.add(ld(d.tail + ((size_t)q * 2 + 1) * SW));
+    } else {
+        const u32 *A1 = d.tail + (size_t)q * d.T1 * SW;
+        const u32 *S1 = d.tail + ((size_t)d.segs * d.T1 + (size_t)q * d.T1) * SW;
+        const u32 *P0 = d.tail + ((size_t)d.segs * 2 * d.T1 + (size_t)q * d.nP) * SW;
+        XYZZ<F> sumS = XYZZ<F>::inf(), run = XYZZ<F>::inf(), uA = XYZZ<F>::inf();
+        for (int u = (int)d.T1 - 1; u >= 0; --u) {
+            sumS.add(ld(S1 + (size_t)u * SW));
+            if (u >= 1) {
+                run.add(ld(A1 + (size_t)u * SW));
+                uA.add(run);
+            }
+        }
+        XYZZ<F> X = pow2(uA, 6);
+        X.add(sumS);
+        win = pow2(X, 6);
+        for (u32 u = 0; u < d.nP; ++u) win.add(ld(P0 + (size_t)u * SW));
+    }
+    if (d.tail_shift) win = pow2(win, d.tail_shift);
+    for (u32 e = 0; e < d.n_extra; ++e) win.add(pow2(ld(d.extra + ((size_t)e * d.segs + q) * SW), d.extra_shift[e]));
+    if (threadIdx.x == 0) win.store_std(out + (size_t)q * out_stride);
+}
+
 // arkworks-format affine bases -> internal representation (identity copy when the two coincide)
 template <class F>
 __global__ __launch_bounds__(256) void bases_to_internal(const u32 *__restrict__ in, size_t n, u32 *__restrict__ out,
@@ -1002,6 +1057,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     static const HP &hp(const HostPoint *p) { return *reinterpret_cast<const HP *>(p); }
     void hp_set_inf(HostPoint *p) const override { hp(p) = HP::inf(); }
     void hp_from_affine(HostPoint *p, const u32 *w) const override { hp(p) = HP::from_affine_words(w); }
+    void hp_from_xyzz(HostPoint *p, const u32 *w) const override { hp(p) = HP::from_xyzz_words(w); }
     void hp_add(HostPoint *a, const HostPoint *o) const override { hp(a) = HP::add(hp(a), hp(o)); }
     void hp_neg(HostPoint *p) const override { hp(p) = hp(p).neg(); }
     void hp_mul(HostPoint *p, const u64 *k4) const override { hp(p) = HP::mul(hp(p), k4, 4); }
@@ -1426,6 +1482,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 hipLaunchKernelGGL((tile_reduce<F>), dim3(cdiv((size_t)segs, 4)), dim3(256), 0, s, rin, rstride, roff, rn, 1u, segs, ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             stage_pts = segs;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
+            ws->d_tail = ws->redS.as<u32>();
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 <= 64) { // two launches: tiles, then (X, sumS) per window
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
@@ -1444,6 +1501,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                                    ws->misc.as<u32>());
             stage_pts = (size_t)segs * 2;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
+            ws->d_tail = ws->misc.as<u32>();
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
             T1 = 0xffffffffu; // marks the (X, sumS) layout for msm_finish
         } else {
@@ -1470,6 +1528,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                                    ws->redS.as<u32>(), T0, 0u, T0, nP, segs * nP, P0, (u32 *)nullptr, 1);
             stage_pts = (size_t)segs * (2 * T1 + nP);
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
+            ws->d_tail = ws->misc.as<u32>();
             MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
         if (n_extra && side) { // the plain sums ran on the side stream: join
@@ -1554,6 +1613,29 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         hp(out + q) = total;
         }
+        return MG_OK;
+    }
+
+    // ---------------------------------------------------------------- finish on the device
+    int msm_fold_device(MsmWorkspace *ws, u32 *d_out, size_t out_stride_words, hipStream_t on = nullptr) override {
+        if (!ws || !ws->pending || !d_out || !ws->d_tail) return MG_ERR_STATE;
+        const MsmPlan &pl = ws->plan;
+        if (pl.Wb != 1) return MG_ERR_STATE; // plain bases keep the host fold (up to 255 Horner doublings: a host job)
+        FoldDesc d{};
+        d.tail = ws->d_tail;
+        d.extra = ws->extra.as<u32>();
+        d.kind = ws->T1 == 0xffffffffu ? 1u : (ws->T1 == 0 ? 0u : 2u);
+        d.T1 = ws->T1, d.nP = ws->nP, d.segs = ws->batch, d.n_extra = ws->n_extra, d.tail_shift = ws->tail_shift;
+        for (u32 e = 0; e < ws->n_extra; ++e) d.extra_shift[e] = ws->extra_shift[e];
+        hipStream_t s = on ? on : (ws->run_on ? ws->run_on : ws->stream);
+        hipLaunchKernelGGL((fold_windows<F>), dim3(ws->batch), dim3(64), 0, s, d, d_out, out_stride_words);
+        MG_HIP(hipGetLastError());
+        return MG_OK;
+    }
+    int msm_discard(MsmWorkspace *ws) override {
+        if (!ws) return MG_ERR_STATE;
+        ws->pending = 0;
+        MG_HIP(hipStreamSynchronize(ws->run_on ? ws->run_on : ws->stream));
         return MG_OK;
     }
 

@@ -960,6 +960,146 @@ class ProverImpl : public Prover {
         for (u32 q = 0; q < k; q += nt) fn(q);
         for (auto &x : th) x.join();
     }
+
+    // ---- the host side of a pass, shared by the single-process paths (finish_pass) and the process-per-GPU one (assemble)
+    struct Blind {
+        u64 rc4[4], sc4[4], rs4[4];
+        HostPoint t_rd, t_sd, t_rsd, t_sd2;
+    };
+    // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2: fixed-base (64 table additions each)
+    void compute_blinds(u32 k, const uint64_t *r, const uint64_t *s, Blind *bl) const {
+        for_each_proof(k, [&](u32 q) {
+            Blind &b = bl[q];
+            u64 rs_m[4];
+            fr_->fr_to_canonical(r + 4 * q, b.rc4);
+            fr_->fr_to_canonical(s + 4 * q, b.sc4);
+            fr_->fr_mul(r + 4 * q, s + 4 * q, rs_m);
+            fr_->fr_to_canonical(rs_m, b.rs4);
+            g1_->hp_table_mul(delta1_tab_, b.rc4, &b.t_rd);
+            g1_->hp_table_mul(delta1_tab_, b.sc4, &b.t_sd);
+            g1_->hp_table_mul(delta1_tab_, b.rs4, &b.t_rsd);
+            g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
+        });
+    }
+    // res[i * k + q] = MSM i (a, b_g1, b_g2, l, h) of proof q; writes A and C of every proof
+    void assemble_g1(u32 k, const HostPoint *res, Blind *bl, const uint64_t *r, uint8_t *proofs_out) const {
+        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
+        for_each_proof(k, [&](u32 q) {
+            Blind &b = bl[q];
+            const uint64_t *rq = r + 4 * q;
+            const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
+            HostPoint g_a = res[0 * (size_t)k + q];
+            g1_->hp_add(&g_a, &a0_alpha_);
+            g1_->hp_add(&g_a, &b.t_rd);
+            HostPoint g1_b;
+            g1_->hp_set_inf(&g1_b);
+            if (!r_zero) {
+                g1_b = res[1 * (size_t)k + q];
+                g1_->hp_add(&g1_b, &b10_beta_);
+                g1_->hp_add(&g1_b, &b.t_sd);
+            }
+            HostPoint g_c;
+            g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
+            g1_->hp_neg(&b.t_rsd);
+            g1_->hp_add(&g_c, &b.t_rsd);
+            g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
+            g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
+            uint8_t *out = proofs_out + (size_t)q * (2 * b1 + b2);
+            g1_->hp_serialize(&g_a, out, true);
+            g1_->hp_serialize(&g_c, out + b1 + b2, true);
+        });
+    }
+    void assemble_g2(u32 k, const HostPoint *res, const Blind *bl, uint8_t *proofs_out) const {
+        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
+        for_each_proof(k, [&](u32 q) {
+            HostPoint g2_b = res[2 * (size_t)k + q];
+            g2_->hp_add(&g2_b, &b20_beta_);
+            g2_->hp_add(&g2_b, &bl[q].t_sd2);
+            g2_->hp_serialize(&g2_b, proofs_out + (size_t)q * (2 * b1 + b2) + b1, true);
+        });
+    }
+
+    // ---- process-per-GPU sharding (manta_rs_amd/distributed.py ShardedProver): this context is
+    // shard g of G in its own process. partials_launch runs the pass on this shard's slices and leaves the five partial MSM
+    // results of every proof on the DEVICE, folded there (msm_fold_device), as arkworks-format XYZZ points in slots of
+    // slot_words() u32 -- [q][a, b_g1, b_g2, l, h] -- and makes `consumer` (the stream of the collective) wait for them: no
+    // host synchronisation between launch and all_gather. assemble() adds the n_parts gathered copies and finishes the proofs.
+    struct PartialJob {
+        Pass p;
+        std::shared_lock<std::shared_mutex> shape_lock; // held until partials_finish: set_r1cs waits for the pass
+    };
+    size_t slot_words() const override { return (size_t)g2_->xyzz_words(); }
+    int partials_launch(u64 k64, const uint64_t *z, uint64_t *d_out, void *consumer, void **job_out) override {
+        if (k64 == 0 || k64 > BATCH_CHUNK || !z || !d_out || !job_out || !peers_.empty()) return MG_ERR_ARG;
+        std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
+        if (!have_r1cs_) return MG_ERR_STATE;
+        PartialJob *job = new PartialJob();
+        job->shape_lock = std::move(shape_lock);
+        int rc = launch_pass(job->p, (u32)k64, z, nullptr, nullptr, nullptr);
+        ProveWs *w = job->p.w;
+        if (rc || !w) {
+            if (w) abandon_pass(job->p);
+            delete job;
+            return rc ? rc : MG_ERR_HIP;
+        }
+        const size_t sw = slot_words();
+        // the fold of MSM i goes behind it: on its own stream, or -- when the pass was replayed from the two graphs of the
+        // "single" mode -- on the stream its graph was launched on (the G1 MSMs are joined inside that graph)
+        const bool replayed = w->graphs_ready && w->g_all && w->g_g2;
+        auto fold_stream = [&](int i) { return replayed ? (i == 2 ? msm_stream(w, 2) : w->stream) : msm_stream(w, i); };
+        for (int i = 0; i < 5 && !rc; ++i)
+            rc = w->me[i]->msm_fold_device(w->mw[i], (u32 *)d_out + (size_t)i * sw, 5 * sw, fold_stream(i));
+        hipStream_t cs = (hipStream_t)consumer;
+        if (!rc) {
+            hipError_t e = hipSuccess;
+            for (int i = 0; i < 5 && e == hipSuccess; ++i) {
+                hipStream_t ms = fold_stream(i);
+                e = hipEventRecord(w->mw[i]->done, ms);
+                if (e == hipSuccess && cs != ms) e = hipStreamWaitEvent(cs, w->mw[i]->done, 0);
+            }
+            if (e != hipSuccess) {
+                set_last_hip_error(e, "partials_launch: events", __FILE__, __LINE__);
+                rc = MG_ERR_HIP;
+            }
+        }
+        if (rc) {
+            abandon_pass(job->p);
+            delete job;
+            return rc;
+        }
+        *job_out = job;
+        return MG_OK;
+    }
+    int partials_finish(void *job_in) override {
+        PartialJob *job = static_cast<PartialJob *>(job_in);
+        if (!job) return MG_ERR_ARG;
+        abandon_pass(job->p); // waits for the slot's streams and returns it (nothing is folded on the host)
+        delete job;
+        return MG_OK;
+    }
+    int assemble(u64 k64, u32 n_parts, const uint64_t *parts, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
+        if (k64 == 0 || k64 > 1024 || n_parts == 0 || !parts || !r || !s || !proofs_out) return MG_ERR_ARG;
+        const u32 k = (u32)k64;
+        const size_t sw = slot_words();
+        std::vector<HostPoint> res((size_t)5 * k);
+        for (int i = 0; i < 5; ++i) {
+            GroupEngine *ge = i == 2 ? g2_ : g1_;
+            for (u32 q = 0; q < k; ++q) {
+                HostPoint &acc = res[(size_t)i * k + q], t;
+                ge->hp_set_inf(&acc);
+                for (u32 g = 0; g < n_parts; ++g) {
+                    ge->hp_from_xyzz(&t, (const u32 *)parts + (((size_t)g * k + q) * 5 + (size_t)i) * sw);
+                    ge->hp_add(&acc, &t);
+                }
+            }
+        }
+        std::vector<Blind> bl(k);
+        compute_blinds(k, r, s, bl.data());
+        assemble_g1(k, res.data(), bl.data(), r, proofs_out);
+        assemble_g2(k, res.data(), bl.data(), proofs_out);
+        return MG_OK;
+    }
+
     int finish_pass(Pass &p, int rc, std::vector<Pass> *peer_passes = nullptr) {
         ProveWs *w = p.w;
         if (!w || rc) {
@@ -971,26 +1111,8 @@ class ProverImpl : public Prover {
         const u32 k = p.k;
         const uint64_t *r = p.r, *s = p.s;
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms
-        // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2 are fixed-base (64 table additions each)
-        struct Blind {
-            u64 rc4[4], sc4[4], rs4[4];
-            HostPoint t_rd, t_sd, t_rsd, t_sd2;
-        };
         std::vector<Blind> bl(k);
-        if (!rc) {
-            for_each_proof(k, [&](u32 q) {
-                Blind &b = bl[q];
-                u64 rs_m[4];
-                fr_->fr_to_canonical(r + 4 * q, b.rc4);
-                fr_->fr_to_canonical(s + 4 * q, b.sc4);
-                fr_->fr_mul(r + 4 * q, s + 4 * q, rs_m);
-                fr_->fr_to_canonical(rs_m, b.rs4);
-                g1_->hp_table_mul(delta1_tab_, b.rc4, &b.t_rd);
-                g1_->hp_table_mul(delta1_tab_, b.sc4, &b.t_sd);
-                g1_->hp_table_mul(delta1_tab_, b.rs4, &b.t_rsd);
-                g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
-            });
-        }
+        if (!rc) compute_blinds(k, r, s, bl.data());
         std::vector<HostPoint> res((size_t)5 * k), tmp; // res[i * k + q]: MSM i of proof q
         auto collect = [&](hipStream_t, bool part_a) { // wait for one part on every shard and fold its MSMs
             int rc2 = collect_part(p, part_a, res.data());
@@ -1009,35 +1131,9 @@ class ProverImpl : public Prover {
                 hipSetDevice(dev_);
             }
         };
-        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
         // ---- part A is back: the G1 side of the assembly runs while the G2 MSM finishes
         collect(w->stream, true); // every G1 MSM stream has been joined into it
-        if (!rc) {
-            for_each_proof(k, [&](u32 q) {
-                Blind &b = bl[q];
-                const uint64_t *rq = r + 4 * q;
-                const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
-                HostPoint g_a = res[0 * (size_t)k + q];
-                g1_->hp_add(&g_a, &a0_alpha_);
-                g1_->hp_add(&g_a, &b.t_rd);
-                HostPoint g1_b;
-                g1_->hp_set_inf(&g1_b);
-                if (!r_zero) {
-                    g1_b = res[1 * (size_t)k + q];
-                    g1_->hp_add(&g1_b, &b10_beta_);
-                    g1_->hp_add(&g1_b, &b.t_sd);
-                }
-                HostPoint g_c;
-                g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
-                g1_->hp_neg(&b.t_rsd);
-                g1_->hp_add(&g_c, &b.t_rsd);
-                g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
-                g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
-                uint8_t *out = p.out + (size_t)q * (2 * b1 + b2);
-                g1_->hp_serialize(&g_a, out, true);
-                g1_->hp_serialize(&g_c, out + b1 + b2, true);
-            });
-        }
+        if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
         // ---- part B: the G2 element
         collect(msm_stream(w, 2), false);
         ws_release(w);
@@ -1049,12 +1145,7 @@ class ProverImpl : public Prover {
                 pg.w = nullptr;
             }
         if (rc) return rc;
-        for_each_proof(k, [&](u32 q) {
-            HostPoint g2_b = res[2 * (size_t)k + q];
-            g2_->hp_add(&g2_b, &b20_beta_);
-            g2_->hp_add(&g2_b, &bl[q].t_sd2);
-            g2_->hp_serialize(&g2_b, p.out + (size_t)q * (2 * b1 + b2) + b1, true);
-        });
+        assemble_g2(k, res.data(), bl.data(), p.out);
         return MG_OK;
     }
 };
@@ -1065,6 +1156,22 @@ int prover_create(int curve, const mg_pk_view *pk, Prover **out) {
     int dev = 0;
     MG_HIP(hipGetDevice(&dev));
     return prover_create_sharded(curve, pk, &dev, 1, out);
+}
+
+// One shard of a context in ITS OWN process (one process per GPU): slice `shard` of `n_shards` of every query on the current
+// device, no peers -- the partial results meet through partials_launch / assemble and a collective (distributed.py).
+int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out) {
+    if (!pk || !out || n_shards == 0 || shard >= n_shards || n_shards > 64) return MG_ERR_ARG;
+    int dev = 0;
+    MG_HIP(hipGetDevice(&dev));
+    ProverImpl *p = new ProverImpl();
+    const int rc = p->init(curve, pk, dev, shard, n_shards);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return MG_OK;
 }
 
 // One context over a list of devices: shard g owns the g-th contiguous slice of every query on devices[g] (a

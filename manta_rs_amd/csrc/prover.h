@@ -64,10 +64,16 @@ class Prover {
     virtual u64 n_vars() const = 0;
     virtual u64 n_inputs() const = 0;
     virtual u32 n_shards() const = 0;
+    // process-per-GPU sharding (prover_create_shard): see prover.cpp
+    virtual int partials_launch(u64 k, const uint64_t *z, uint64_t *d_out, void *consumer_stream, void **job) = 0;
+    virtual int partials_finish(void *job) = 0;
+    virtual int assemble(u64 k, u32 n_parts, const uint64_t *parts, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) = 0;
+    virtual size_t slot_words() const = 0;
 };
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);
 // every MSM of a proof range-sharded over the listed devices; devices may repeat
 int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out);
+int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out);
 // arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
 int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices = nullptr,
                              int n_devices = 0);

@@ -1,15 +1,25 @@
-"""One process per GPU: the exchange step of the range-sharded MSM over torch.distributed (backend "nccl" = RCCL over
-xGMI on the GPU node, "gloo" in CPU tests).
+"""One process per GPU: the exchange step of the range-sharded MSM and of the range-sharded PROOF over torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU node, "gloo" in CPU tests and for two ranks on one device).
 
-SURVEY.md section 8(e): an MSM shards by contiguous base/scalar range; every rank runs a full Pippenger pass over its
-slice and is left with ONE partial point (64-192 B affine). RCCL has no user-defined reduction, so the exchange is an
-all_gather of the N partial points followed by an N-term sum on every rank (`mg_points_sum`, host) -- 8 x 96 B on the
-wire per 2^20-term BLS12-381 MSM, one hop on the fully connected xGMI mesh. Nothing else of the path needs a
-collective: NTT / witness map and whole proofs are replicas (a 2^20 transform is sub-millisecond on one GPU).
+SURVEY.md section 8(e) / 7.1 C1: an MSM shards by contiguous base/scalar range; every rank runs a full Pippenger pass over
+its slice and is left with ONE partial point. RCCL has no user-defined reduction, so the exchange is an all_gather of the N
+partial points followed by an N-term sum on every rank. A proof has five MSMs: its exchange is ONE fused all_gather of the
+five partial points per rank (<= 1.9 KB), then the usual host assembly (BASELINE configs[3]; caller
+manta-accounting/src/transfer/mod.rs:695-715 -> manta-crypto/src/arkworks/groth16.rs:589-600). Nothing else of the path
+needs a collective: NTT / witness map are recomputed per rank (1.1 MB of z against 2 MB of h), whole proofs are replicas.
 
-The in-process counterpart -- one host process driving several GPUs, what a Rust host linking libmantagpu.so would
-use -- is `mg_bases_create_sharded` / `mg_ctx_create_sharded` (api.Bases(devices=...), api.ProvingContext(devices=...)),
-where the partial points meet in pinned host memory and no collective exists at all.
+Two transports, same library calls underneath:
+  * device path (backend nccl): the library folds the window sums on the GPU and writes the partial point(s) as XYZZ
+    coordinates straight into the collective's send buffer (`mg_msm_result_to_device`, `mg_groth16_partials_launch`), the
+    stream RCCL runs on is made to wait for them with an event, all_gather_into_tensor runs from device memory, and one
+    asynchronous copy brings the gathered points to pinned host memory. No host synchronisation between launch and collective;
+    the host waits once, when it needs the result.
+  * host path (backend gloo, or bases without precomputed multiples whose fold is a host job): the partial point comes back
+    through mg_msm_finish and is gathered from host memory.
+
+The in-process counterpart -- one host process driving several GPUs, what a Rust host linking libmantagpu.so would use -- is
+`mg_bases_create_sharded` / `mg_ctx_create_sharded` (api.Bases(devices=...), api.ProvingContext(devices=...)), where the
+partial points meet in pinned host memory and no collective exists at all.
 """
 from __future__ import annotations
 
@@ -20,73 +30,215 @@ from . import api
 
 def shard_range(n: int, rank: int, world: int):
     """Contiguous slice [lo, hi) of an n-term MSM owned by `rank` -- the same split the library uses for its
-    in-process shards (`mg_bases_create_sharded`)."""
+    in-process shards (`mg_bases_create_sharded`, `mg_ctx_create_shard`)."""
     return n * rank // world, n * (rank + 1) // world
 
 
-class PartialPointExchange:
-    """all_gather + sum of one partial point per rank. Buffers are allocated once (a pinned staging pair and, for the
-    nccl backend, two small device tensors): a step costs one H2D of <= 192 B, the collective, one D2H."""
+class _Slot:
+    """one set of exchange buffers: device send / recv tensors, pinned landing area, completion event"""
 
-    def __init__(self, curve: int, group: int, process_group=None, device=None):
+    def __init__(self, torch, words, world, dev):
+        self.send = torch.zeros(words, dtype=torch.int64, device=dev)
+        self.recv = torch.zeros(world * words, dtype=torch.int64, device=dev)
+        self.h_recv = torch.zeros(world * words, dtype=torch.int64).pin_memory()
+        self.done = torch.cuda.Event()
+        self.busy = False
+
+
+class PartialPointExchange:
+    """all_gather + sum of `words` u64 per rank (one partial point, or the five of a proof).
+
+    force_collective: run the collective even in a world of one -- that is how the RCCL branch is exercised on a 1-GPU box
+    (tests/test_gpu_multi.py); normally a single rank short-circuits.
+    ring: sets of buffers used round-robin, so that several MSMs / passes can be in flight (the library writes the next
+    partial point while the previous all_gather is still reading its send buffer)."""
+
+    def __init__(self, curve: int, group: int, process_group=None, device=None, force_collective=False, words=None, ring=8):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.curve, self.group = curve, group
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.limbs = api.affine_limbs(curve, group)
-        self.on_gpu = self.world > 1 and dist.get_backend(process_group) == "nccl"
-        if self.world > 1:
-            dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if self.on_gpu else "cpu"
-            self.send = torch.zeros(self.limbs, dtype=torch.int64, device=dev)
-            self.recv = torch.zeros(self.world * self.limbs, dtype=torch.int64, device=dev)
+        self.collective = dist.is_initialized() and (self.world > 1 or force_collective)
+        self.on_gpu = self.collective and dist.get_backend(process_group) == "nccl"
+        self.words = int(words) if words else api.xyzz_limbs(curve, group)  # device path: XYZZ points
+        self.slots, self.next = [], 0
+        if self.collective:
             if self.on_gpu:
-                self.h_send = torch.zeros(self.limbs, dtype=torch.int64).pin_memory()
-                self.h_recv = torch.zeros(self.world * self.limbs, dtype=torch.int64).pin_memory()
+                dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+                self.slots = [_Slot(torch, self.words, self.world, dev) for _ in range(ring)]
+            # host path buffers (affine points)
+            self.send = torch.zeros(self.limbs, dtype=torch.int64)
+            self.recv = torch.zeros(self.world * self.limbs, dtype=torch.int64)
 
+    # ------------------------------------------------------------------ host path
     def all_gather(self, local_point: np.ndarray) -> np.ndarray:
-        """-> [world, limbs] uint64: every rank's partial point."""
-        if self.world == 1:
+        """-> [world, limbs] uint64: every rank's partial point (affine), gathered from HOST memory."""
+        if not self.collective:
             return np.ascontiguousarray(local_point, dtype=np.uint64).reshape(1, -1)
         t = self.torch.from_numpy(np.ascontiguousarray(local_point, dtype=np.uint64).view(np.int64))
-        if self.on_gpu:
-            self.h_send.copy_(t)
-            self.send.copy_(self.h_send, non_blocking=True)
-            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.pg)  # RCCL over xGMI
-            self.h_recv.copy_(self.recv)  # D2H; synchronises with the collective
-            out = self.h_recv.numpy()
-        else:
-            self.send.copy_(t)
-            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.pg)
-            out = self.recv.numpy()
-        return out.view(np.uint64).reshape(self.world, self.limbs).copy()
+        if self.on_gpu:  # nccl cannot gather host tensors: bounce through a device slot (plain bases only take this road)
+            sl = self._acquire()
+            sl.send[:self.limbs].copy_(t, non_blocking=True)
+            self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)
+            out = sl.recv.cpu().numpy().view(np.uint64).reshape(self.world, self.words)[:, :self.limbs].copy()
+            sl.busy = False
+            return out
+        self.send.copy_(t)
+        self.dist.all_gather_into_tensor(self.recv, self.send, group=self.pg)
+        return self.recv.numpy().view(np.uint64).reshape(self.world, self.limbs).copy()
 
     def sum(self, local_point: np.ndarray) -> np.ndarray:
         """The global point: sum over ranks of their partial points (identical on every rank)."""
-        if self.world == 1:
+        if not self.collective:
             return np.ascontiguousarray(local_point, dtype=np.uint64)
         return api.points_sum(self.curve, self.group, self.all_gather(local_point))
 
+    # ------------------------------------------------------------------ device path
+    def _acquire(self) -> _Slot:
+        sl = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if sl.busy:
+            sl.done.synchronize()
+        sl.busy = True
+        return sl
+
+    def stream_handle(self) -> int:
+        """the raw hipStream_t the collective will be enqueued on (torch's current stream)"""
+        return int(self.torch.cuda.current_stream().cuda_stream)
+
+    def begin(self) -> _Slot:
+        """a free buffer set; the producer writes `words` u64 to slot.send (device memory) and makes stream_handle() wait"""
+        return self._acquire()
+
+    def gather_async(self, sl: _Slot):
+        """all_gather_into_tensor from device memory on the current stream + asynchronous copy to pinned memory"""
+        self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)  # RCCL over xGMI
+        sl.h_recv.copy_(sl.recv, non_blocking=True)
+        sl.done.record()
+
+    def wait(self, sl: _Slot) -> np.ndarray:
+        """-> [world, words] uint64, once the gather and the copy have completed (the only host wait of the step)"""
+        sl.done.synchronize()
+        out = sl.h_recv.numpy().view(np.uint64).reshape(self.world, self.words).copy()
+        sl.busy = False
+        return out
+
 
 class ShardedMsmJob:
-    def __init__(self, job, exchange):
-        self.job, self.exchange = job, exchange
+    def __init__(self, job, exchange, slot=None):
+        self.job, self.exchange, self.slot = job, exchange, slot
 
     def finish(self) -> np.ndarray:
-        return self.exchange.sum(self.job.finish())
+        ex = self.exchange
+        if self.slot is None:
+            return ex.sum(self.job.finish())
+        parts = ex.wait(self.slot)  # [world, xyzz limbs]
+        self.job.release()
+        return api.xyzz_sum(ex.curve, ex.group, parts)
 
 
 class ShardedMSM:
     """`VariableBaseMSM::multi_scalar_mul` over bases range-sharded across the ranks of a process group: this rank holds
     `local_bases` (its slice, registered with api.Bases on its GPU) and the matching slice of the scalars."""
 
-    def __init__(self, local_bases: api.Bases, process_group=None):
+    def __init__(self, local_bases: api.Bases, process_group=None, force_collective=False):
         self.bases = local_bases
-        self.exchange = PartialPointExchange(local_bases.curve, local_bases.group, process_group)
+        self.exchange = PartialPointExchange(local_bases.curve, local_bases.group, process_group, force_collective=force_collective)
+        # the device-side fold exists for bases with precomputed multiples (one bucket window, no Horner doublings)
+        self.device_path = self.exchange.on_gpu and getattr(local_bases, "precompute_window_bits", 0) > 0
 
     def launch(self, d_local_scalars, n_local, **kw) -> ShardedMsmJob:
-        return ShardedMsmJob(api.VariableBaseMSM.launch(self.bases, d_local_scalars, n_local, **kw), self.exchange)
+        job = api.VariableBaseMSM.launch(self.bases, d_local_scalars, n_local, **kw)
+        if not self.device_path:
+            return ShardedMsmJob(job, self.exchange)
+        ex = self.exchange
+        sl = ex.begin()
+        job.result_to_device(sl.send.data_ptr(), ex.stream_handle())  # fold on the GPU -> send buffer; the stream waits for it
+        ex.gather_async(sl)
+        return ShardedMsmJob(job, ex, sl)
 
     def multi_scalar_mul(self, local_scalars: np.ndarray) -> np.ndarray:
-        return self.exchange.sum(api.VariableBaseMSM.multi_scalar_mul(self.bases, local_scalars))
+        d = api.DeviceBuffer.from_numpy(np.ascontiguousarray(local_scalars, dtype=np.uint64))
+        return self.launch(d, local_scalars.shape[0]).finish()
+
+
+class ShardedProofJob:
+    def __init__(self, prover, k, rs, ss, slot=None, job=None, parts=None):
+        self.prover, self.k, self.rs, self.ss, self.slot, self.job, self.parts = prover, k, rs, ss, slot, job, parts
+
+    def finish(self) -> list:
+        p = self.prover
+        parts = self.parts
+        if parts is None:
+            parts = p.exchange.wait(self.slot)  # [world, k * 5 * slot limbs]
+            p.ctx.partials_finish(self.job)
+        return p.ctx.assemble(parts, self.rs, self.ss)
+
+
+class ShardedProver:
+    """`Groth16::prove` with every MSM of the proof range-sharded over the ranks of a process group, one process per GPU
+    (BASELINE configs[3]). Every rank gets the whole assignment, recomputes the witness map, runs its five partial MSMs
+    (`mg_ctx_create_shard` holds slice rank/world of every query) and contributes ONE fused all_gather of its five partial
+    points per proof; every rank then assembles the same proof bytes -- identical to the single-GPU context's.
+    max_batch: proofs per pass (<= 32); the exchange buffers are sized for it."""
+
+    def __init__(self, curve, pk, process_group=None, force_collective=False, max_batch=1, ctx=None):
+        import torch.distributed as dist
+        self.curve = curve
+        world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.ctx = ctx if ctx is not None else api.ProvingContext(curve, pk, shard=(rank, world))
+        self.slot = self.ctx.partials_slot_limbs
+        self.max_batch = int(max_batch)
+        self.exchange = PartialPointExchange(curve, 2, process_group, force_collective=force_collective,
+                                             words=self.max_batch * 5 * self.slot)
+        self._d_out = None  # host path: a device buffer of our own for the partial results
+
+    def set_r1cs(self, r1cs):
+        self.ctx.set_r1cs(r1cs)
+
+    def launch(self, zs, rs, ss) -> ShardedProofJob:
+        rs = np.ascontiguousarray(rs, dtype=np.uint64).reshape(-1, 4)
+        ss = np.ascontiguousarray(ss, dtype=np.uint64).reshape(-1, 4)
+        k = rs.shape[0]
+        if k < 1 or k > self.max_batch or ss.shape[0] != k:
+            raise ValueError("ShardedProver: between 1 and max_batch proofs per pass, one (r, s) pair each")
+        ex = self.exchange
+        if ex.on_gpu:  # device path: partial points -> send buffer -> RCCL, no host sync in between
+            sl = ex.begin()
+            job = self.ctx.partials_launch(zs, k, sl.send.data_ptr(), ex.stream_handle())
+            ex.gather_async(sl)
+            return ShardedProofJob(self, k, rs, ss, slot=sl, job=job)
+        # host path (gloo, or a single rank): the partial points come back through a device buffer of our own
+        words = k * 5 * self.slot
+        if self._d_out is None:
+            self._d_out = api.DeviceBuffer(self.max_batch * 5 * self.slot * 8)
+        job = self.ctx.partials_launch(zs, k, self._d_out.ptr, None)
+        self.ctx.partials_finish(job)  # waits for the pass
+        mine = self._d_out.to_numpy(shape=(self.max_batch * 5 * self.slot,))[:words]
+        return ShardedProofJob(self, k, rs, ss, parts=self.gather_host(mine, k))
+
+    def gather_host(self, mine: np.ndarray, k: int) -> np.ndarray:
+        """[world, k, 5, slot] from every rank's [k, 5, slot] (host memory; gloo)"""
+        ex = self.exchange
+        words = k * 5 * self.slot
+        mine = np.ascontiguousarray(mine, dtype=np.uint64).reshape(-1)[:words]
+        if not ex.collective:
+            return mine.reshape(1, k, 5, self.slot)
+        t = ex.torch.from_numpy(mine.view(np.int64).copy())
+        recv = ex.torch.zeros(ex.world * words, dtype=ex.torch.int64)
+        ex.dist.all_gather_into_tensor(recv, t, group=ex.pg)
+        return recv.numpy().view(np.uint64).reshape(ex.world, k, 5, self.slot).copy()
+
+    def prove(self, z, r, s) -> bytes:
+        return self.launch(z, r, s).finish()[0]
+
+    def prove_batch(self, zs, rs, ss) -> list:
+        return self.launch(zs, rs, ss).finish()
+
+    def close(self):
+        self.ctx.close()

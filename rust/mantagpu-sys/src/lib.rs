@@ -53,6 +53,10 @@ pub struct mg_ctx {
 pub struct mg_vk {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct mg_partials_job {
+    _private: [u8; 0],
+}
 
 /// `ark_groth16::ProvingKey<E>` as the library reads it (groth16.rs:216-245, field list :253-264).
 #[repr(C)]
@@ -154,6 +158,9 @@ extern "C" {
         job: *mut *mut mg_msm_job,
     ) -> c_int;
     pub fn mg_msm_finish(job: *mut mg_msm_job, out_affine_mont: *mut u64) -> c_int;
+    pub fn mg_msm_result_to_device(job: *mut mg_msm_job, d_out_xyzz: *mut u64, stream: *mut c_void) -> c_int;
+    pub fn mg_xyzz_limbs(curve: mg_curve_t, group: c_int) -> usize;
+    pub fn mg_xyzz_sum(curve: mg_curve_t, group: c_int, xyzz: *const u64, n: usize, out_affine_mont: *mut u64) -> c_int;
     pub fn mg_points_sum(curve: mg_curve_t, group: c_int, affine_mont: *const u64, n: usize, out_affine_mont: *mut u64) -> c_int;
     pub fn mg_fixed_base_mul(
         curve: mg_curve_t,
@@ -218,6 +225,26 @@ extern "C" {
         devices: *const c_int,
         n_devices: c_int,
         out: *mut *mut mg_ctx,
+    ) -> c_int;
+    pub fn mg_ctx_create_shard(curve: mg_curve_t, pk: *const mg_pk_view, shard: c_int, n_shards: c_int, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_partials_slot_limbs(ctx: *const mg_ctx) -> usize;
+    pub fn mg_groth16_partials_launch(
+        ctx: *const mg_ctx,
+        k: u64,
+        z_mont: *const u64,
+        d_out: *mut u64,
+        stream: *mut c_void,
+        job: *mut *mut mg_partials_job,
+    ) -> c_int;
+    pub fn mg_groth16_partials_finish(job: *mut mg_partials_job) -> c_int;
+    pub fn mg_groth16_assemble(
+        ctx: *const mg_ctx,
+        k: u64,
+        n_parts: c_int,
+        parts: *const u64,
+        r_mont: *const u64,
+        s_mont: *const u64,
+        proofs_out: *mut u8,
     ) -> c_int;
     pub fn mg_ctx_create_from_bytes(curve: mg_curve_t, bytes: *const u8, len: usize, out: *mut *mut mg_ctx) -> c_int;
     pub fn mg_ctx_create_from_bytes_sharded(

@@ -203,3 +203,27 @@ def test_msm_reduce_front_levels(gpu, curve, group, pres, env):
     code = _FRONT_SCRIPT.format(root=ROOT, curve=curve, group=group, pres=pres)
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "front levels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("curve,group,n,pre", [(0, 1, 300, 5), (0, 1, 4000, 9), (1, 1, 20000, 13), (1, 1, 1 << 15, 16), (0, 2, 900, 6),
+                                                (1, 2, 2500, 8)])
+def test_msm_result_folded_on_the_device(gpu, curve, group, n, pre):
+    """`mg_msm_result_to_device`: the host fold of mg_msm_finish done by one kernel behind the MSM -- every staging layout
+    (one tile per window, (X, sumS) pairs, the general two-level one) -- leaves an XYZZ point in device memory that
+    normalises to the same affine point; plain bases are refused (their Horner chain is a host job)."""
+    pts = H.random_points(curve, group, min(n, 1500), seed=51)
+    pts = np.concatenate([pts] * (-(-n // pts.shape[0])))[:n]
+    sc = synth.msm_scalars(curve, n, "W", seed=52)
+    b = gpu.Bases(curve, group, pts, precompute_window_bits=pre)
+    want = gpu.VariableBaseMSM.multi_scalar_mul(b, sc)
+    d = gpu.DeviceBuffer.from_numpy(sc)
+    out = gpu.DeviceBuffer(gpu.xyzz_limbs(curve, group) * 8)
+    job = gpu.VariableBaseMSM.launch(b, d, n, sparse=True)
+    job.result_to_device(out.ptr)
+    job.release()
+    got = gpu.xyzz_sum(curve, group, out.to_numpy(shape=(1, gpu.xyzz_limbs(curve, group))))
+    assert (got == want).all()
+    plain = gpu.VariableBaseMSM.launch(gpu.Bases(curve, group, pts), d, n)
+    with pytest.raises(gpu.MantaGpuError):
+        plain.result_to_device(out.ptr)
+    assert (plain.finish() == want).all()

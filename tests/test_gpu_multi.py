@@ -31,6 +31,8 @@ def test_two_ranks_on_one_gpu_weak_and_strong_scaling(gpu):
     ss = line["strong_scaling"]
     assert ss["n_2^20"]["n_per_gpu"] == 1 << 19 and ss["n_35174"]["n_per_gpu"] == 17587
     assert line["proofs"]["n_gpus"] == 2 and line["proofs"]["batched"]["proofs_per_s"] > 0
+    sp = line["sharded_proof"]  # BASELINE configs[3]: the proof with its MSMs split over the ranks (gloo exchange here)
+    assert sp["sequential"]["proofs_per_s"] > 0 and sp["batched"]["proofs_per_s"] > 0
 
 
 def test_world2_full_size_msm_only(gpu):
@@ -38,3 +40,115 @@ def test_world2_full_size_msm_only(gpu):
     line = _run({}, "--steps", "3", "--warmup", "1", "--quick", port="29542")
     assert line["metric"] == "G1 MSM Mscalar/s at 2^20" and line["n_gpus"] == 2
     assert line["roofline"]["kernel_ms"] > 0
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_lib as O, helpers as H
+from manta_rs_amd import api, synth, distributed
+torch.cuda.set_device(0)
+api.init(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+# ---- MSM: partial point folded on the GPU -> RCCL all_gather from device memory -> host sum
+for curve, group, n, pre in ((1, 1, 5000, 9), (0, 1, 3000, 13), (0, 2, 700, 6), (1, 1, 1 << 15, 16)):
+    pts = H.random_points(curve, group, min(n, 2000), seed=3)
+    reps = -(-n // pts.shape[0])
+    pts = np.concatenate([pts] * reps)[:n]           # repeated bases are fine (and exercise the P + P case)
+    sc = synth.msm_scalars(curve, n, "U", seed=4)
+    b = api.Bases(curve, group, pts, precompute_window_bits=pre)
+    want = api.VariableBaseMSM.multi_scalar_mul(b, sc)
+    m = distributed.ShardedMSM(b, force_collective=True)
+    assert m.exchange.on_gpu and m.device_path
+    d = api.DeviceBuffer.from_numpy(sc)
+    jobs = [m.launch(d, n) for _ in range(5)]        # several in flight: the buffer ring
+    for j in jobs:
+        assert (j.finish() == want).all(), (curve, group, n, pre)
+    # plain bases: the fold is a host job, the point is gathered through the device bounce
+    pb = api.Bases(curve, group, pts)
+    mp = distributed.ShardedMSM(pb, force_collective=True)
+    assert mp.exchange.on_gpu and not mp.device_path
+    assert (mp.launch(d, n).finish() == want).all()
+# ---- proof: five partial points per proof in ONE fused all_gather, assembled on the host
+curve = api.BN254
+c = synth.make_circuit(curve, 700, 500, 9, seed=11)
+pk = O.groth16_setup(c, H.toxic(curve))
+ctx = api.ProvingContext(curve, pk)
+r1cs = api.R1CS.from_circuit(c)
+ctx.set_r1cs(r1cs)
+rs = H.rand_fr_mont(curve, 8, seed=5)
+sp = distributed.ShardedProver(curve, pk, force_collective=True, max_batch=3)
+sp.set_r1cs(r1cs)
+assert sp.exchange.on_gpu
+for i in range(4):                                  # eager runs, then the captured graphs
+    want = api.Groth16.prove_with_randomness(ctx, c.z, rs[2 * i], rs[2 * i + 1])
+    assert sp.prove(c.z, rs[2 * i], rs[2 * i + 1]) == want, i
+assert O.groth16_verify(curve, pk, c.z[1:c.P], want) == 1
+zs = np.stack([c.z] * 3)
+got = sp.prove_batch(zs, rs[0:3], rs[3:6])
+assert got == api.Groth16.prove_batch(ctx, zs, rs[0:3], rs[3:6])
+dist.barrier()
+dist.destroy_process_group()
+print("rccl one-rank ok")
+'''
+
+
+def test_rccl_branch_with_a_one_rank_group(gpu):
+    """The RCCL branch of the exchange, executed on the 1-GPU box: a process group of ONE rank with backend nccl and the
+    world-of-one short-circuit disabled. MSM: fold on the device -> all_gather_into_tensor from device memory -> pinned copy
+    -> host sum, five jobs in flight; proof: distributed.ShardedProver, one fused gather of the five partial points, bytes
+    equal to the single-GPU context's (single proofs through eager and graph replay, and a batch of three)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK.format(root=ROOT)], capture_output=True, text=True, env=env,
+                         timeout=900, cwd=ROOT)
+    assert out.returncode == 0 and "rccl one-rank ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+_TWO_RANK_PROOF = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import oracle_lib as O, helpers as H
+from manta_rs_amd import api, synth, distributed
+api.init(0)
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+curve = api.BN254
+shape = os.environ.get("SHAPE")
+c = synth.make_shape(curve, shape) if shape else synth.make_circuit(curve, 900, 650, 11, seed=21)
+if shape:
+    from manta_rs_amd import keygen
+    rng = synth.XorShift(0x4D414E5441_0002)
+    pk = keygen.generate(c, [rng.field(synth.FR_MODULUS[curve]) for _ in range(5)])
+else:
+    pk = O.groth16_setup(c, H.toxic(curve))
+r1cs = api.R1CS.from_circuit(c)
+rs = H.rand_fr_mont(curve, 8, seed=6)
+sp = distributed.ShardedProver(curve, pk, max_batch=2)   # this rank: slice rank/world of every query
+sp.set_r1cs(r1cs)
+assert sp.ctx.num_shards == world and not sp.exchange.on_gpu
+ctx = api.ProvingContext(curve, pk)                      # the single-GPU reference, same device
+ctx.set_r1cs(r1cs)
+for i in range(3):
+    want = api.Groth16.prove_with_randomness(ctx, c.z, rs[2 * i], rs[2 * i + 1])
+    assert sp.prove(c.z, rs[2 * i], rs[2 * i + 1]) == want, i
+zs = np.stack([c.z] * 2)
+assert sp.prove_batch(zs, rs[0:2], rs[2:4]) == api.Groth16.prove_batch(ctx, zs, rs[0:2], rs[2:4])
+dist.barrier()
+print("rank", rank, "sharded proof ok")
+'''
+
+
+@pytest.mark.parametrize("shape", ["", "private_transfer"])
+def test_sharded_proof_two_ranks_on_one_gpu(gpu, shape):
+    """BASELINE configs[3] in its process-per-GPU form, two ranks pinned to device 0 (gloo: RCCL refuses two ranks on one
+    device): each holds half of every query, proves its five partial MSMs, the ten partial points are gathered in one
+    collective, both ranks assemble -- byte-identical to the single-GPU proof (small circuit and the PrivateTransfer shape)."""
+    script = _TWO_RANK_PROOF.format(root=ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SHAPE=shape)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29548", "--no-python", sys.executable, "-c", script],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0 and out.stdout.count("sharded proof ok") == 2, out.stdout[-3000:] + out.stderr[-3000:]

@@ -113,6 +113,58 @@ print("rank", rank, "ok")
     assert out.stdout.count("ok") == 2
 
 
+def test_sharded_proof_exchange_with_gloo_world2(tmp_path):
+    """The fused exchange of a sharded PROOF on CPU (distributed.ShardedProver.gather_host, gloo world 2): every rank
+    contributes [k][5][slot] partial points -- stood in for by oracle MSMs over its slices of five queries -- in ONE
+    all_gather; the gathered slots, summed per (proof, query), equal the five full MSMs. (The byte-identical-proof statement
+    needs the GPU library: tests/test_gpu_multi.py runs it with two ranks on one device and with a one-rank RCCL group.)"""
+    script = tmp_path / "w.py"
+    script.write_text(f'''
+import os, sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+import numpy as np, torch.distributed as dist
+import oracle_lib as O, helpers as H
+from manta_rs_amd import api, synth, distributed
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+curve, n, k = 0, 61, 2
+slot = api.xyzz_limbs(curve, 2)
+one = synth.to_mont([1], synth.FQ_MODULUS[curve], synth.FQ_LIMBS[curve]).reshape(-1)
+def xyzz(pt, group):                       # affine -> X | Y | ZZ | ZZZ with ZZ = ZZZ = 1, padded to the G2 slot
+    L = api.affine_limbs(curve, group) // 2
+    out = np.zeros(slot, dtype=np.uint64)
+    if pt.any():
+        out[:2 * L] = pt
+        out[2 * L:2 * L + len(one)] = one
+        out[3 * L:3 * L + len(one)] = one
+    return out
+groups = (1, 1, 2, 1, 1)                   # a, b_g1, b_g2, l, h
+queries = [H.random_points(curve, g, n, seed=30 + i) for i, g in enumerate(groups)]
+scalars = [[synth.msm_scalars(curve, n, "W", seed=40 + 5 * q + i) for i in range(5)] for q in range(k)]
+lo, hi = distributed.shard_range(n, rank, world)
+mine = np.stack([np.stack([xyzz(O.msm(curve, groups[i], queries[i][lo:hi], scalars[q][i][lo:hi]), groups[i]) for i in range(5)])
+                 for q in range(k)])
+class StubCtx:                              # what ShardedProver needs from a context when nothing runs on a GPU
+    partials_slot_limbs = slot
+sp = distributed.ShardedProver(curve, None, max_batch=k, ctx=StubCtx())
+parts = sp.gather_host(mine, k)
+assert parts.shape == (world, k, 5, slot) and (parts[rank] == mine).all()
+for q in range(k):
+    for i in range(5):
+        L = api.xyzz_limbs(curve, groups[i])
+        total = api.xyzz_sum(curve, groups[i], parts[:, q, i, :L])
+        assert (total == O.msm(curve, groups[i], queries[i], scalars[q][i])).all(), (q, i)
+dist.barrier()
+print("rank", rank, "ok")
+''')
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29534", str(script)],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
+
+
 def test_shard_ranges_tile_the_index_space():
     from manta_rs_amd import distributed
     for n in (1, 7, 35174, 1 << 20):
