@@ -43,7 +43,8 @@ enum {
     MG_ERROR_HIP = 2,
     MG_ERROR_OUT_OF_MEMORY = 3,
     MG_ERROR_DOMAIN_TOO_LARGE = 4, /* ark-relations SynthesisError::PolynomialDegreeTooLarge */
-    MG_ERROR_STATE = 5
+    MG_ERROR_STATE = 5,
+    MG_ERROR_CHECKSUM = 6 /* the BLAKE3 digest of the data does not match (mg_ctx_create_from_bytes_checked) */
 };
 
 typedef struct mg_bases mg_bases;     /* a static vector of curve points resident in HBM */
@@ -250,6 +251,13 @@ int mg_groth16_assemble(const mg_ctx *ctx, uint64_t k, int n_parts, const uint64
  * no curve checks) exactly as `ProvingContext::decode` reads them (manta-crypto/src/arkworks/groth16.rs:268-288)
  * and `generate_parameters` / manta-parameters ship them (data/pay/proving/ *.lfs). */
 int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out);
+/* The same behind manta-parameters' integrity check: `manta_parameters::verify(data, checksum)` = `blake3::hash(data) ==
+ * checksum` (manta-parameters/src/lib.rs:173-177; `Get::get` refuses a file whose digest differs from data.checkfile,
+ * lib.rs:150-170). checksum = the 32-byte BLAKE3 digest the caller expects (`HasChecksum::CHECKSUM`); a mismatch returns
+ * MG_ERROR_CHECKSUM and nothing is uploaded. mg_blake3 is the digest itself (host code, any length). */
+int mg_ctx_create_from_bytes_checked(mg_curve_t curve, const uint8_t *bytes, size_t len, const uint8_t checksum[32],
+                                     mg_ctx **out);
+int mg_blake3(const uint8_t *data, size_t len, uint8_t out32[32]);
 /* Once per circuit shape: the matrices of `cs.to_matrices()` (identical for every proof of a shape). Validated
  * in full before anything changes (row_ptr monotone from 0 to nnz, column indices < V); a rejected call leaves
  * the context as it was. */

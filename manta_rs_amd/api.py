@@ -66,7 +66,7 @@ EXPORTS = [
     "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
-    "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble",
+    "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
 ]
 
 
@@ -298,6 +298,13 @@ class VariableBaseMSM:
         return MsmJob(bases, h)
 
 
+def blake3(data: bytes) -> bytes:
+    """`blake3::hash` (manta-parameters' checksum, lib.rs:173-177), computed by the library's host code"""
+    out = ctypes.create_string_buffer(32)
+    _chk(LIB.mg_blake3(bytes(data), _sz(len(data)), out), "mg_blake3")
+    return out.raw
+
+
 def xyzz_limbs(curve, group) -> int:
     return int(LIB.mg_xyzz_limbs(curve, group))
 
@@ -498,15 +505,22 @@ class ProvingContext:
         self._r1cs_ref = None
 
     @classmethod
-    def decode(cls, curve, data: bytes, devices=None):
+    def decode(cls, curve, data: bytes, devices=None, checksum: bytes = None):
         """Mirror of `impl Decode for ProvingContext` (groth16.rs:268-288): arkworks `deserialize_unchecked`
-        bytes of the ProvingKey -- the format of manta-parameters' proving-key files."""
+        bytes of the ProvingKey -- the format of manta-parameters' proving-key files. checksum: the file's BLAKE3 digest as
+        manta-parameters' data.checkfile lists it (32 bytes); a mismatch raises before anything is uploaded
+        (`manta_parameters::verify`, manta-parameters/src/lib.rs:173-177)."""
         self = cls.__new__(cls)
         self.curve = curve
         self._keep = None
         self._r1cs_ref = None
         h = _vp()
-        if devices is None:
+        if checksum is not None and devices is None:
+            if len(checksum) != 32:
+                raise ValueError("a BLAKE3 digest is 32 bytes")
+            _chk(LIB.mg_ctx_create_from_bytes_checked(curve, bytes(data), _sz(len(data)), bytes(checksum), ctypes.byref(h)),
+                 "mg_ctx_create_from_bytes_checked")
+        elif devices is None:
             _chk(LIB.mg_ctx_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_ctx_create_from_bytes")
         else:
             dv = (ctypes.c_int * len(devices))(*devices)

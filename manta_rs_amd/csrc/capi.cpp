@@ -30,12 +30,6 @@ struct JobShard {
 struct mg_msm_job {
     std::vector<JobShard> sh;
 };
-// restores the caller's current device when a call that visits other devices returns
-struct DeviceGuard {
-    int prev = 0;
-    DeviceGuard() { hipGetDevice(&prev); }
-    ~DeviceGuard() { hipSetDevice(prev); }
-};
 
 #define MG_API extern "C" __attribute__((visibility("default")))
 #define MG_TRY try {
@@ -58,6 +52,7 @@ MG_API const char *mg_strerror(int status) {
     case MG_ERROR_OUT_OF_MEMORY: return "out of memory";
     case MG_ERROR_DOMAIN_TOO_LARGE: return "evaluation domain exceeds the field's two-adicity";
     case MG_ERROR_STATE: return "invalid state";
+    case MG_ERROR_CHECKSUM: return "BLAKE3 checksum mismatch";
     }
     return "unknown error";
 }
@@ -493,6 +488,28 @@ MG_API int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *byt
     if (rc) return rc;
     *out = new mg_ctx{p};
     return MG_SUCCESS;
+    MG_CATCH
+}
+namespace mg {
+void blake3_hash(const uint8_t *data, size_t len, uint8_t out[32]);
+}
+MG_API int mg_blake3(const uint8_t *data, size_t len, uint8_t out32[32]) {
+    MG_TRY
+    if ((!data && len) || !out32) return MG_ERROR_INVALID_ARGUMENT;
+    static const uint8_t none = 0;
+    blake3_hash(data ? data : &none, len, out32);
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out);
+MG_API int mg_ctx_create_from_bytes_checked(mg_curve_t curve, const uint8_t *bytes, size_t len, const uint8_t checksum[32],
+                                            mg_ctx **out) {
+    MG_TRY
+    if (!bytes || !checksum || !out) return MG_ERROR_INVALID_ARGUMENT;
+    uint8_t h[32];
+    blake3_hash(bytes, len, h);
+    if (std::memcmp(h, checksum, 32) != 0) return MG_ERROR_CHECKSUM;
+    return mg_ctx_create_from_bytes(curve, bytes, len, out);
     MG_CATCH
 }
 MG_API int mg_ctx_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_ctx **out) {

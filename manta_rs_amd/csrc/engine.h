@@ -48,6 +48,30 @@ hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 const char *last_error_string();
 
+// makes `dev` the current device for a scope and restores the caller's on the way out: a host thread that drives several
+// GPUs must not find its device changed by a call into the library
+struct DeviceScope {
+    int prev = 0;
+    bool switched = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (switched) hipSetDevice(prev);
+    }
+    DeviceScope(const DeviceScope &) = delete;
+    DeviceScope &operator=(const DeviceScope &) = delete;
+};
+
+// restores the caller's current device when a call that visits other devices returns
+struct DeviceGuard {
+    int prev = 0;
+    DeviceGuard() { hipGetDevice(&prev); }
+    ~DeviceGuard() { hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 // grow-only device buffer
 struct DevBuf {
     void *p = nullptr;
@@ -93,6 +117,7 @@ struct MsmWorkspace {
     size_t extra_off_pts = 0;                                       // where the extras start in h_stage (points)
     const u32 *d_tail = nullptr; // device copy of what msm_launch staged for the host fold (arkworks-format XYZZ points)
     DevBuf folded;               // msm_fold_device: one arkworks-format XYZZ point per batch member
+    DevBuf scratch;              // caller-side scalars uploaded for one launch (the verifier's small MSMs)
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;

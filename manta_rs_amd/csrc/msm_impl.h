@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__
     }
 }
 
-// Calibration twin of accumulate_chunks (tools/gather_calibration.py, MANTA_ACC_GATHER_ONLY=1; never on the product
-// path): the same lanes walk the same sorted (key, value) stream and gather the same base records, but instead of
+#ifdef MG_CALIBRATION
+// Calibration twin of accumulate_chunks -- compiled ONLY into -DMG_CALIBRATION builds (tools/gather_calibration.py builds
+// one with tools/build_variant.sh and selects it through MANTA_LIB; the shipped library has neither this kernel nor the
+// MANTA_ACC_GATHER_ONLY switch, so no environment variable can make it return wrong results): the same lanes walk the same sorted (key, value) stream and gather the same base records, but instead of
 // the mixed addition every loaded word is XORed into a register. Its duration is the memory side of the accumulate
 // kernel alone -- how long the random 128 B gathers from the window tables take when no field arithmetic competes --
 // and its PMC FETCH_SIZE calibrates the counter for this access pattern.
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void gather_only_chunks(const u32 *__restrict_
     pkeys[2 * t + 1] = invalid;
     if (x == 0x9e3779b9u) pkeys[2 * t] = invalid - 1; // keep the loads alive
 }
+#endif
 
 // --------------------------------------------------------------------------------------------
 // K7b: merge of partials. The partial array is a key-sorted sequence of (key, point) entries, two per
@@ -1352,12 +1355,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
         ws->timed = kernel_timing() && !ws->capturing;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
-        static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration runs only (wrong results)
+#ifdef MG_CALIBRATION
+        static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration build only (wrong results)
         if (gather_only)
             hipLaunchKernelGGL((gather_only_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                                ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->pkeys[0].as<u32>(), T,
                                (const u32 *)d_count);
         else
+#endif
         hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                            ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                            ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count);

@@ -1,6 +1,8 @@
 // Kernels and host orchestration of the pairing engine (pairing_dev.h), one instantiation per curve
 // (pairing_bn254.hip / pairing_bls381.hip). SURVEY.md row f-2.
 #pragma once
+#include <mutex>
+#include <vector>
 #include "engine.h"
 #include "pairing_coop.h"
 #include "verify.h"
@@ -124,17 +126,22 @@ template <class K> class PairingEngineT : public PairingEngine {
         const size_t pb = n * 2 * P::N * 4, qb = q_affine_host ? n * 2 * P::F2W * 4 : 0, cb = n * sizeof(u32 *);
         const size_t o_q = up(pb), o_c = o_q + up(qb), o_s = o_c + up(cb), in_bytes = o_s + up(n);
         const size_t o_f = in_bytes, o_g = o_f + up(n * P::F12W * 4), total = o_g + up((n / 8 + 2) * P::F12W * 4);
-        std::vector<unsigned char> stage(in_bytes, 0);
-        std::memcpy(stage.data(), p_affine_host, pb);
-        if (qb) std::memcpy(stage.data() + o_q, q_affine_host, qb);
-        std::memcpy(stage.data() + o_c, d_coeffs, cb);
-        if (skip) std::memcpy(stage.data() + o_s, skip, n);
-        unsigned char *d = nullptr;
-        hipError_t e = hipMalloc((void **)&d, total);
-        if (e == hipSuccess) e = hipMemcpy(d, stage.data(), in_bytes, hipMemcpyHostToDevice);
+        // pooled workspace (device block + pinned staging + a non-blocking stream of its own): no hipMalloc / hipFree per call --
+        // hipFree synchronises the whole device and would stall every proof in flight on this GPU -- and nothing on stream 0
+        Ws *w = ws_get(total, in_bytes > (size_t)P::F12W * 4 ? in_bytes : (size_t)P::F12W * 4);
+        if (!w) return MG_ERR_OOM;
+        unsigned char *stage = (unsigned char *)w->h;
+        std::memset(stage, 0, in_bytes);
+        std::memcpy(stage, p_affine_host, pb);
+        if (qb) std::memcpy(stage + o_q, q_affine_host, qb);
+        std::memcpy(stage + o_c, d_coeffs, cb);
+        if (skip) std::memcpy(stage + o_s, skip, n);
+        unsigned char *d = w->d;
+        hipStream_t st = w->s;
+        hipError_t e = hipMemcpyAsync(d, stage, in_bytes, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
             u32 *df = (u32 *)(d + o_f), *dg = (u32 *)(d + o_g);
-            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n), dim3(128), PW::miller_lds_bytes(), 0, (const u32 *)d,
+            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n), dim3(128), PW::miller_lds_bytes(), st, (const u32 *)d,
                                (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
                                n, df);
             // product tree: chunks of 8 per wavefront until one element is left
@@ -142,24 +149,78 @@ template <class K> class PairingEngineT : public PairingEngine {
             size_t m = n;
             while (m > 1) {
                 const size_t chunk = 8, outn = (m + chunk - 1) / chunk;
-                hipLaunchKernelGGL((f12_product_kernel<K>), dim3((unsigned)outn), dim3(64), PW::lds_bytes(2), 0, src, m, chunk, dst);
+                hipLaunchKernelGGL((f12_product_kernel<K>), dim3((unsigned)outn), dim3(64), PW::lds_bytes(2), st, src, m, chunk, dst);
                 u32 *t = src;
                 src = dst;
                 dst = t;
                 m = outn;
             }
             if (do_final_exp) {
-                hipLaunchKernelGGL((final_exp_kernel<K>), dim3(1), dim3(64), PW::lds_bytes(PW::FINAL_EXP_REGS), 0, src, dst);
+                hipLaunchKernelGGL((final_exp_kernel<K>), dim3(1), dim3(64), PW::lds_bytes(PW::FINAL_EXP_REGS), st, src, dst);
                 src = dst;
             }
-            e = hipMemcpy(out_f12_host, src, P::F12W * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(w->h, src, P::F12W * 4, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess) std::memcpy(out_f12_host, w->h, P::F12W * 4);
         }
-        if (d) hipFree(d);
+        ws_put(w);
         if (e != hipSuccess) {
             set_last_hip_error(e, "pairing product", __FILE__, __LINE__);
             return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
         }
         return MG_OK;
+    }
+
+    // ---- workspace pool (per engine = per device and curve)
+    struct Ws {
+        unsigned char *d = nullptr;
+        void *h = nullptr;
+        size_t dcap = 0, hcap = 0;
+        hipStream_t s = nullptr;
+    };
+    std::mutex ws_mu_;
+    std::vector<Ws *> ws_free_;
+    Ws *ws_get(size_t dbytes, size_t hbytes) {
+        Ws *w = nullptr;
+        {
+            std::lock_guard<std::mutex> g(ws_mu_);
+            if (!ws_free_.empty()) {
+                w = ws_free_.back();
+                ws_free_.pop_back();
+            }
+        }
+        if (!w) {
+            w = new Ws();
+            if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess) {
+                delete w;
+                return nullptr;
+            }
+        }
+        if (w->dcap < dbytes) {
+            if (w->d) hipFree(w->d);
+            w->d = nullptr, w->dcap = 0;
+            const size_t cap = dbytes + dbytes / 4 + 4096;
+            if (hipMalloc((void **)&w->d, cap) != hipSuccess) {
+                ws_put(w);
+                return nullptr;
+            }
+            w->dcap = cap;
+        }
+        if (w->hcap < hbytes) {
+            if (w->h) hipHostFree(w->h);
+            w->h = nullptr, w->hcap = 0;
+            const size_t cap = hbytes + hbytes / 4 + 4096;
+            if (hipHostMalloc(&w->h, cap, hipHostMallocDefault) != hipSuccess) {
+                ws_put(w);
+                return nullptr;
+            }
+            w->hcap = cap;
+        }
+        return w;
+    }
+    void ws_put(Ws *w) {
+        std::lock_guard<std::mutex> g(ws_mu_);
+        ws_free_.push_back(w);
     }
 
     int product_is_one(const u32 *p_affine_host, const u32 *q_affine_host, size_t n, int *ok) override {

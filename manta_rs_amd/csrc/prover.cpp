@@ -22,6 +22,7 @@
 #include <deque>
 #include <mutex>
 #include <shared_mutex>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 
@@ -295,23 +296,53 @@ class ProverImpl : public Prover {
         return MG_OK;
     }
 
-    // Replaces the circuit. All-or-nothing: the three matrices are validated, then uploaded into temporaries, the
-    // h-query tables for a new domain size are built, and only when everything has succeeded is the context
-    // switched over (a failure leaves the previous circuit, if any, fully usable). Exclusive against proofs in
-    // flight on other threads (shape_mu_): it waits for them, and they never see a half-replaced circuit.
+    // Replaces the circuit. All-or-nothing, on every shard at once (two phases): first every shard validates the three
+    // matrices, uploads them into temporaries and builds the h-query tables of a new domain size -- nothing that a proof can
+    // see changes, and a failure on any shard (say, out of memory on one device) frees the temporaries everywhere and leaves
+    // the previous circuit, if any, fully usable; then the exclusive locks of ALL shards are taken in the order in which a
+    // pass takes its shared ones (shard 0, then the peers) -- so no pass is in flight on any of them -- and every shard is
+    // switched over under them: a proof never runs with some shards on the new matrices and others on the old.
+    struct StagedR1cs {
+        DevCsr A, B, C;
+        BaseSet *h = nullptr, *h_wide = nullptr;
+        bool new_domain = false;
+        unsigned lg = 0;
+        u64 m = 0;
+    };
+    std::mutex set_mu_; // one set_r1cs at a time per context (shard 0's)
     int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) override {
         int rc = MG_OK, prev = 0;
         MG_HIP(hipGetDevice(&prev));
-        for (ProverImpl *q : peers_)
-            if ((rc = q->set_r1cs_shard(a, b, c, m))) break;
-        if (!rc) rc = set_r1cs_shard(a, b, c, m);
+        std::lock_guard<std::mutex> one_at_a_time(set_mu_);
+        std::vector<ProverImpl *> all{this};
+        all.insert(all.end(), peers_.begin(), peers_.end());
+        std::vector<StagedR1cs> st(all.size());
+        for (size_t g = 0; g < all.size() && !rc; ++g) rc = all[g]->stage_r1cs(a, b, c, m, st[g]);
+        if (rc) {
+            for (size_t g = 0; g < all.size(); ++g) all[g]->discard_staged(st[g]);
+            hipSetDevice(prev);
+            return rc;
+        }
+        {
+            std::vector<std::unique_lock<std::shared_mutex>> locks;
+            for (ProverImpl *q : all) locks.emplace_back(q->shape_mu_);
+            for (size_t g = 0; g < all.size(); ++g) all[g]->commit_staged(st[g]);
+        }
         hipSetDevice(prev);
-        return rc;
+        return MG_OK;
     }
     u64 n_vars() const override { return V_; }
     u64 n_inputs() const override { return P_; }
     u32 n_shards() const override { return n_shards_; }
-    int set_r1cs_shard(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) {
+    void discard_staged(StagedR1cs &st) {
+        hipSetDevice(dev_);
+        free_csr(st.A), free_csr(st.B), free_csr(st.C);
+        if (st.h) g1_->bases_destroy(st.h);
+        if (st.h_wide) g1_->bases_destroy(st.h_wide);
+        st.h = st.h_wide = nullptr;
+    }
+    // phase 1 on this shard: nothing visible to a proof is touched
+    int stage_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, StagedR1cs &st) {
         MG_HIP(hipSetDevice(dev_));
         if (m == 0 || m + P_ > ((u64)1 << 32)) return MG_ERR_ARG;
         unsigned lg = 0;
@@ -319,15 +350,11 @@ class ProverImpl : public Prover {
         if ((int)lg > fr_->two_adicity()) return MG_ERR_DOMAIN;
         int rc;
         if ((rc = validate_csr(a, m, V_)) || (rc = validate_csr(b, m, V_)) || (rc = validate_csr(c, m, V_))) return rc;
-        std::unique_lock<std::shared_mutex> shape_lock(shape_mu_);
-        DevCsr nA, nB, nC;
-        if ((rc = upload_csr(a, m, nA)) || (rc = upload_csr(b, m, nB)) || (rc = upload_csr(c, m, nC))) {
-            free_csr(nA), free_csr(nB), free_csr(nC);
-            return rc;
-        }
-        BaseSet *nh = nullptr, *nh_wide = nullptr;
-        const bool new_domain = !h_bs_ || lg != log_d_;
-        if (new_domain) { // (re)build the h-query base set for this domain
+        st.lg = lg;
+        st.m = m;
+        if ((rc = upload_csr(a, m, st.A)) || (rc = upload_csr(b, m, st.B)) || (rc = upload_csr(c, m, st.C))) return rc;
+        st.new_domain = !h_bs_ || lg != log_d_; // (h_bs_ / log_d_ only change under set_mu_, which the caller holds)
+        if (st.new_domain) { // (re)build the h-query base set for this domain
             const size_t D = (size_t)1 << lg, w1 = (size_t)g1_->affine_words();
             // this shard's slice [h_lo, h_hi) of the bit-reversed positions; entries beyond len(h_query) stay
             // infinity: h[D-1] = 0 anyway
@@ -347,35 +374,35 @@ class ProverImpl : public Prover {
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
             if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
-            rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &nh);
-            if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &nh_wide);
-            if (rc) {
-                if (nh) g1_->bases_destroy(nh);
-                if (nh_wide) g1_->bases_destroy(nh_wide);
-                free_csr(nA), free_csr(nB), free_csr(nC);
-                return rc;
-            }
+            rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &st.h);
+            if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &st.h_wide);
+            if (rc) return rc;
         }
-        // ---- commit
+        return MG_OK;
+    }
+    // phase 2 on this shard; the caller holds the exclusive shape lock of every shard
+    void commit_staged(StagedR1cs &st) {
+        hipSetDevice(dev_);
         std::lock_guard<std::mutex> g(mu_);
         free_csr(A_), free_csr(B_), free_csr(C_);
-        A_ = nA, B_ = nB, C_ = nC;
-        if (new_domain) {
+        A_ = st.A, B_ = st.B, C_ = st.C;
+        st.A = st.B = st.C = DevCsr();
+        if (st.new_domain) {
             if (h_bs_) g1_->bases_destroy(h_bs_);
             if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
-            h_bs_ = nh, h_bs_wide_ = nh_wide;
+            h_bs_ = st.h, h_bs_wide_ = st.h_wide;
+            st.h = st.h_wide = nullptr;
         }
         // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them (slots of
-        // another generation that are still in flight cannot exist -- the exclusive lock waited for them)
+        // another generation that are still in flight cannot exist -- the exclusive locks waited for them)
         for (auto &kv : ws_free_)
             for (ProveWs *w : kv.second) delete w;
         ws_free_.clear();
         idle_slots_ = 0;
         ++gen_;
-        m_ = m;
-        log_d_ = lg;
+        m_ = st.m;
+        log_d_ = st.lg;
         have_r1cs_ = true;
-        return MG_OK;
     }
 
     ProveWs *ws_acquire(u32 k = 1) {
@@ -506,6 +533,7 @@ class ProverImpl : public Prover {
     }
 
     int witness_map_host(const uint64_t *z, uint64_t *h_out) override {
+        DeviceGuard restore_callers_device;
         MG_HIP(hipSetDevice(dev_));
         std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
         if (!have_r1cs_) return MG_ERR_STATE;
@@ -711,7 +739,14 @@ class ProverImpl : public Prover {
                 }
                 ++cq_inflight_;
                 lk.unlock();
-                const int rc = prove_gathered(batch);
+                int rc; // nothing may escape here: the followers of this batch wait on cq_cv_ for their `done`
+                try {
+                    rc = prove_gathered(batch);
+                } catch (const std::bad_alloc &) {
+                    rc = MG_ERR_OOM;
+                } catch (...) {
+                    rc = MG_ERR_STATE;
+                }
                 lk.lock();
                 for (Req *q : batch) q->rc = rc, q->done = true;
                 --cq_inflight_;
@@ -770,23 +805,35 @@ class ProverImpl : public Prover {
         const size_t pbytes = 2 * (size_t)g1_->point_bytes(true) + (size_t)g2_->point_bytes(true); // compressed A, B, C
         std::atomic<u64> next{0};
         std::atomic<int> first_rc{MG_OK};
-        auto worker = [&] {
+        auto worker = [&]() noexcept {
             for (;;) {
                 const u64 c = next.fetch_add(1);
                 if (c >= chunks || first_rc.load() != MG_OK) return;
                 const u64 lo = c * per, n = std::min(per, k64 - lo);
                 stream_gate_acquire(); // at most `fl` streamed passes in flight per context, however many callers
-                const int rc = prove_pass(n, z + lo * V_ * 4, r + lo * 4, s + lo * 4, proofs_out + lo * pbytes);
+                int rc;
+                try {
+                    rc = prove_pass(n, z + lo * V_ * 4, r + lo * 4, s + lo * 4, proofs_out + lo * pbytes);
+                } catch (const std::bad_alloc &) {
+                    rc = MG_ERR_OOM;
+                } catch (...) {
+                    rc = MG_ERR_STATE;
+                }
                 stream_gate_release();
                 int ok = MG_OK;
                 if (rc) first_rc.compare_exchange_strong(ok, rc);
             }
         };
         const int nthreads = (int)std::min<u64>(fl, chunks);
-        std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
-        worker();
-        for (auto &t : th) t.join();
+        {
+            std::vector<std::thread> th;
+            JoinAll guard{th};
+            try {
+                for (int t = 1; t < nthreads; ++t) th.emplace_back(worker);
+            } catch (...) { // a helper thread could not be started: the caller works through the chunks alone
+            }
+            worker();
+        }
         return first_rc.load();
     }
     // two callers streaming a batch each would otherwise put six passes in flight, which is slower than three (measured:
@@ -808,6 +855,7 @@ class ProverImpl : public Prover {
     }
     int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out,
                    const uint64_t *const *z_list = nullptr) {
+        DeviceGuard restore_callers_device; // the pass visits every shard's device
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
         locks.emplace_back(shape_mu_);
@@ -946,19 +994,41 @@ class ProverImpl : public Prover {
     // The host side of a pass is ~0.15 ms per proof (two 254-bit scalar multiplications in one doubling chain, four table
     // multiplications, three serialisations with a field inversion each): nothing next to a single proof, but 5 ms of a
     // 32-proof pass whose GPU side is 8.6 ms. Batches spread it over up to four library threads.
+    // (exception-safe: a worker that throws -- bad_alloc -- is caught in its own thread, every thread is joined, and the
+    // failure is rethrown on the calling thread, where the C ABI turns it into a status code; a thread that cannot be
+    // started just leaves its share to the caller)
+    struct JoinAll {
+        std::vector<std::thread> &th;
+        ~JoinAll() {
+            for (auto &t : th)
+                if (t.joinable()) t.join();
+        }
+    };
     template <class Fn> static void for_each_proof(u32 k, Fn &&fn) {
         const u32 nt = k >= 4 ? 4u : k; // (a thread start is ~30 us against ~150 us of work per proof)
         if (nt == 1) {
             for (u32 q = 0; q < k; ++q) fn(q);
             return;
         }
-        std::vector<std::thread> th;
-        for (u32 t = 1; t < nt; ++t)
-            th.emplace_back([&, t] {
-                for (u32 q = t; q < k; q += nt) fn(q);
-            });
-        for (u32 q = 0; q < k; q += nt) fn(q);
-        for (auto &x : th) x.join();
+        std::atomic<bool> failed{false};
+        std::atomic<u32> next{0}; // proofs are handed out one at a time: threads that never started cost nothing
+        auto body = [&]() noexcept {
+            try {
+                for (u32 q; (q = next.fetch_add(1)) < k;) fn(q);
+            } catch (...) {
+                failed.store(true);
+            }
+        };
+        {
+            std::vector<std::thread> th;
+            JoinAll guard{th};
+            try {
+                for (u32 t = 1; t < nt; ++t) th.emplace_back(body);
+            } catch (...) { // std::system_error: fewer helpers
+            }
+            body();
+        }
+        if (failed.load()) throw std::runtime_error("prove: host assembly failed");
     }
 
     // ---- the host side of a pass, shared by the single-process paths (finish_pass) and the process-per-GPU one (assemble)
@@ -1031,6 +1101,7 @@ class ProverImpl : public Prover {
     size_t slot_words() const override { return (size_t)g2_->xyzz_words(); }
     int partials_launch(u64 k64, const uint64_t *z, uint64_t *d_out, void *consumer, void **job_out) override {
         if (k64 == 0 || k64 > BATCH_CHUNK || !z || !d_out || !job_out || !peers_.empty()) return MG_ERR_ARG;
+        DeviceGuard restore_callers_device;
         std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
         if (!have_r1cs_) return MG_ERR_STATE;
         PartialJob *job = new PartialJob();
@@ -1073,6 +1144,7 @@ class ProverImpl : public Prover {
     int partials_finish(void *job_in) override {
         PartialJob *job = static_cast<PartialJob *>(job_in);
         if (!job) return MG_ERR_ARG;
+        DeviceGuard restore_callers_device;
         abandon_pass(job->p); // waits for the slot's streams and returns it (nothing is folded on the host)
         delete job;
         return MG_OK;
@@ -1108,6 +1180,18 @@ class ProverImpl : public Prover {
             if (w) abandon_pass(p);
             return rc ? rc : MG_ERR_HIP;
         }
+        try {
+            return finish_pass_body(p, peer_passes);
+        } catch (...) { // bad_alloc in the host assembly: drain and return every slot of the pass, then report upwards
+            abandon_pass(p);
+            if (peer_passes)
+                for (size_t g = 0; g < peers_.size(); ++g) peers_[g]->abandon_pass((*peer_passes)[g]);
+            throw;
+        }
+    }
+    int finish_pass_body(Pass &p, std::vector<Pass> *peer_passes) {
+        ProveWs *w = p.w;
+        int rc = MG_OK;
         const u32 k = p.k;
         const uint64_t *r = p.r, *s = p.s;
         // ---- host work that does not depend on the MSMs runs while the GPU is busy: the blinding terms

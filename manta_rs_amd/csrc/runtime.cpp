@@ -98,7 +98,7 @@ void stream_pool_put(hipStream_t s) {
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
-                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded};
+                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (done) hipEventDestroy(done);

@@ -150,12 +150,15 @@ template <class Curve, class K> class VerifierT : public Verifier {
     // bit 6 = infinity, bit 7 = "y is the lexicographically larger root"); checked like `CanonicalDeserialize::deserialize`
     static bool g1_decompress(const uint8_t *in, u64 *out) {
         const uint8_t flags = in[FB - 1];
+        HF x, y;
+        // ark-serialize 0.3 reads the field element first (rejecting x >= p) and the flags with it: `SWFlags::from_u8` has no
+        // value for "both bits set", and an infinity encoding still has to carry a canonical x (its value is ignored)
+        if ((flags & 0xC0) == 0xC0) return false;
+        if (!read_fq<C>(in, 0xC0, x)) return false;
         if (flags & 0x40) {
             std::memset(out, 0, G1L * 8);
             return true;
         }
-        HF x, y;
-        if (!read_fq<C>(in, 0xC0, x)) return false;
         if (!hsqrt<C>(HF::add(HF::mul(HF::sqr(x), x), b1()), y)) return false;
         if (y.is_high() != ((flags & 0x80) != 0)) y = HF::neg(y);
         std::memcpy(out, x.v, N64 * 8);
@@ -167,12 +170,13 @@ template <class Curve, class K> class VerifierT : public Verifier {
     }
     static bool g2_decompress(const uint8_t *in, u64 *out) {
         const uint8_t flags = in[2 * FB - 1];
+        HF2 x, y;
+        if ((flags & 0xC0) == 0xC0) return false; // no such SWFlags value
+        if (!read_fq<C>(in, 0, x.c0) || !read_fq<C>(in + FB, 0xC0, x.c1)) return false; // canonical even when infinity is flagged
         if (flags & 0x40) {
             std::memset(out, 0, G2L * 8);
             return true;
         }
-        HF2 x, y;
-        if (!read_fq<C>(in, 0, x.c0) || !read_fq<C>(in + FB, 0xC0, x.c1)) return false;
         if (!hsqrt2<C>(HF2::add(HF2::mul(HF2::sqr(x), x), b2()), y)) return false;
         if (y.is_high() != ((flags & 0x80) != 0)) y = HF2::neg(y);
         std::memcpy(out, x.c0.v, N64 * 8);
@@ -303,23 +307,22 @@ template <class Curve, class K> class VerifierT : public Verifier {
 
     // sum_j scalars_j * gamma_abc_g1[j] on the GPU (scalars Montgomery Fr, n <= P)
     int abc_msm(const u64 *scalars_mont, size_t n, HostPoint *out) {
-        u32 *d = nullptr;
-        MG_HIP(hipMalloc((void **)&d, n * 32));
-        hipError_t e = hipMemcpy(d, scalars_mont, n * 32, hipMemcpyHostToDevice);
-        int rc = e == hipSuccess ? MG_OK : MG_ERR_HIP;
-        MsmWorkspace *ws = rc ? nullptr : g1_->ws_acquire();
-        if (!rc && !ws) rc = MG_ERR_HIP;
-        if (!rc) rc = g1_->msm_launch(abc_bs_, d, n, SCALARS_MONT, 0, ws);
+        MsmWorkspace *ws = g1_->ws_acquire();
+        if (!ws) return MG_ERR_HIP;
+        // the scalars ride in the workspace's own grow-only buffer, on its stream: no hipMalloc / hipFree per verification
+        // (hipFree synchronises the whole device -- every proof in flight on this GPU would wait for it)
+        int rc = ws->scratch.reserve(n * 32);
+        if (!rc && hipMemcpyAsync(ws->scratch.p, scalars_mont, n * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
+        if (!rc) rc = g1_->msm_launch(abc_bs_, ws->scratch.as<u32>(), n, SCALARS_MONT, 0, ws);
         if (!rc) rc = g1_->msm_finish(ws, out);
-        else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
-        if (ws) g1_->ws_release(ws);
-        hipFree(d);
+        else hipStreamSynchronize(ws->stream), ws->pending = 0;
+        g1_->ws_release(ws);
         return rc;
     }
 
     int verify(const u64 *inputs, const u64 *proof, int *ok) override {
         if ((!inputs && P_ > 1) || !proof || !ok) return MG_ERR_ARG;
-        MG_HIP(hipSetDevice(dev_));
+        DeviceScope on_device(dev_);
         *ok = 0;
         const u64 *A = proof, *B = proof + G1L, *Cc = proof + G1L + G2L;
         // prepared_inputs = abc[0] + sum_j input_j abc[j+1]: a P-term MSM with the scalar 1 in front
@@ -348,7 +351,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
 
     int verify_batch(u64 k, const u64 *inputs, const u64 *proofs, const u64 *rand128, int *ok) override {
         if (k == 0 || k > (1u << 20) || (!inputs && P_ > 1) || !proofs || !rand128 || !ok) return MG_ERR_ARG;
-        MG_HIP(hipSetDevice(dev_));
+        DeviceScope on_device(dev_);
         *ok = 0;
         const size_t PL = 2 * G1L + G2L; // limbs per proof
         // r_i as Montgomery Fr; s = sum r_i; comb_j = sum_i r_i x_ij
@@ -384,15 +387,13 @@ template <class Curve, class K> class VerifierT : public Verifier {
         {
             BaseSet *cb = nullptr;
             if ((rc = g1_->bases_create((const u32 *)cs.data(), k, false, 0, &cb))) return rc;
-            u32 *d = nullptr;
-            hipError_t e = hipMalloc((void **)&d, k * 32);
-            if (e == hipSuccess) e = hipMemcpy(d, r_can.data(), k * 32, hipMemcpyHostToDevice);
-            MsmWorkspace *ws = e == hipSuccess ? g1_->ws_acquire() : nullptr;
-            rc = ws ? g1_->msm_launch(cb, d, k, SCALARS_CANONICAL, 0, ws) : MG_ERR_HIP;
+            MsmWorkspace *ws = g1_->ws_acquire();
+            rc = ws ? ws->scratch.reserve(k * 32) : MG_ERR_HIP;
+            if (!rc && hipMemcpyAsync(ws->scratch.p, r_can.data(), k * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
+            if (!rc) rc = g1_->msm_launch(cb, ws->scratch.as<u32>(), k, SCALARS_CANONICAL, 0, ws);
             if (!rc) rc = g1_->msm_finish(ws, &csum);
             else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
             if (ws) g1_->ws_release(ws);
-            if (d) hipFree(d);
             g1_->bases_destroy(cb);
             if (rc) return rc;
         }

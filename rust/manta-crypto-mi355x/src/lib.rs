@@ -251,6 +251,18 @@ impl<E: Mi355xCurve> GpuProvingContext<E> {
         Ok(Self { ctx, shape: Mutex::new(None), _engine: PhantomData })
     }
 
+    /// [`from_bytes`](Self::from_bytes) behind manta-parameters' integrity check: `checksum` is the BLAKE3 digest the caller
+    /// expects (`HasChecksum::CHECKSUM`, `manta-parameters/src/lib.rs:188-212`); a key whose digest differs is refused
+    /// before anything is uploaded (`manta_parameters::verify`, `lib.rs:173-177`).
+    pub fn from_bytes_checked(bytes: &[u8], checksum: &[u8; 32]) -> Result<Self, Error> {
+        let mut ctx = ptr::null_mut();
+        // SAFETY: `bytes` and `checksum` outlive the call
+        check(unsafe {
+            sys::mg_ctx_create_from_bytes_checked(E::CURVE, bytes.as_ptr(), bytes.len(), checksum.as_ptr(), &mut ctx)
+        })?;
+        Ok(Self { ctx, shape: Mutex::new(None), _engine: PhantomData })
+    }
+
     /// Makes sure the matrices of `matrices` are the ones on the device (once per circuit shape: they are identical
     /// for every proof of a shape, so the usual case is a lock, a comparison of five integers, and out).
     fn ensure_matrices(&self, matrices: &ConstraintMatrices<E::Fr>) -> Result<(), Error> {

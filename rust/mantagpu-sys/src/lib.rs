@@ -17,6 +17,7 @@ pub const MG_ERROR_HIP: c_int = 2;
 pub const MG_ERROR_OUT_OF_MEMORY: c_int = 3;
 pub const MG_ERROR_DOMAIN_TOO_LARGE: c_int = 4;
 pub const MG_ERROR_STATE: c_int = 5;
+pub const MG_ERROR_CHECKSUM: c_int = 6;
 
 pub const MG_SCALARS_MONT: c_int = 1;
 pub const MG_SCALARS_SPARSE: c_int = 2;
@@ -247,6 +248,14 @@ extern "C" {
         proofs_out: *mut u8,
     ) -> c_int;
     pub fn mg_ctx_create_from_bytes(curve: mg_curve_t, bytes: *const u8, len: usize, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_ctx_create_from_bytes_checked(
+        curve: mg_curve_t,
+        bytes: *const u8,
+        len: usize,
+        checksum: *const u8,
+        out: *mut *mut mg_ctx,
+    ) -> c_int;
+    pub fn mg_blake3(data: *const u8, len: usize, out32: *mut u8) -> c_int;
     pub fn mg_ctx_create_from_bytes_sharded(
         curve: mg_curve_t,
         bytes: *const u8,

@@ -167,6 +167,14 @@ def test_proving_context_decode_wire_format(gpu, curve):
     bad[31 if curve == 0 else 47] = 0x3f                    # x coordinate >= p (non-canonical)
     with pytest.raises(gpu.MantaGpuError):
         gpu.ProvingContext.decode(curve, bytes(bad))
+    # manta-parameters' integrity check in front of the loader (`manta_parameters::verify`, lib.rs:173-177): the right
+    # BLAKE3 digest loads the key, a wrong one is refused with MG_ERROR_CHECKSUM before anything is uploaded
+    ok = gpu.ProvingContext.decode(curve, data, checksum=gpu.blake3(data))
+    ok.set_r1cs(r1cs)
+    assert gpu.Groth16.prove_with_randomness(ok, c.z, rs[0], rs[1]) == proof
+    with pytest.raises(gpu.MantaGpuError) as e:
+        gpu.ProvingContext.decode(curve, data, checksum=gpu.blake3(data[:-1]))
+    assert e.value.status == 6
 
 
 def test_error_codes_not_exceptions(gpu):

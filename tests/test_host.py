@@ -165,6 +165,54 @@ print("rank", rank, "ok")
     assert out.stdout.count("ok") == 2
 
 
+def test_proof_decode_rejects_what_ark_serialize_rejects():
+    """ark-serialize 0.3 `SWFlags::from_u8` has no value for "infinity AND positive-y" (both top bits of the last byte),
+    and `deserialize_with_flags` rejects a field element >= p even under the infinity flag: mg_proof_decode (host code, no
+    GPU needed) must refuse both, or proofs are malleable where the reference's are not."""
+    from manta_rs_amd import api
+    for curve, fb in ((0, 32), (1, 48)):
+        n = 4 * fb
+        inf = bytearray(n)
+        for end in (fb, 3 * fb, 4 * fb):
+            inf[end - 1] = 0x40
+        assert not api.proof_decode(curve, bytes(inf)).any()          # three points at infinity decode (to zeros)
+        for end in (fb, 3 * fb, 4 * fb):                                # a, b, c in turn
+            both = bytearray(inf)
+            both[end - 1] = 0xC0
+            with pytest.raises(api.MantaGpuError):
+                api.proof_decode(curve, bytes(both))
+            big = bytearray(inf)                                        # x = 2^(8 fb - 2) - 1 >= p under the infinity flag
+            for i in range(end - fb, end - 1):
+                big[i] = 0xFF
+            big[end - 1] = 0x7F
+            with pytest.raises(api.MantaGpuError):
+                api.proof_decode(curve, bytes(big))
+        c0_big = bytearray(inf)                                         # b's first Fq2 coefficient (no flag bits) >= p
+        for i in range(fb, 2 * fb):
+            c0_big[i] = 0xFF
+        with pytest.raises(api.MantaGpuError):
+            api.proof_decode(curve, bytes(c0_big))
+
+
+def test_rust_patch_has_no_panic_on_upload_failure():
+    """mantagpu.h promises status codes ("no exceptions, no abort") and the reference's `ProvingContext::new` cannot fail:
+    the patch to groth16.rs must not `.expect(...)` the upload -- it defers it to the first `prove`, whose `Result` carries
+    the failure as the module's opaque `Error`."""
+    patch = open(os.path.join(ROOT, "rust", "manta-crypto.patch")).read()
+    added = "\n".join(ln[1:] for ln in patch.splitlines() if ln.startswith("+") and not ln.startswith("+++"))
+    assert ".expect(" not in added and ".unwrap()" not in added and "panic!" not in added
+    assert "gpu: Arc::new(Mutex::new(None))" in added              # `new` uploads nothing
+    assert ".gpu()?" in added and "GpuProvingContext::new(&self.proving_key, None).map_err(|_| Error)?" in added
+
+
+def test_release_library_has_no_calibration_switch():
+    """The gather-only calibration twin of the accumulate kernel (wrong results by design) and the environment variable
+    that selected it exist only in -DMG_CALIBRATION builds: nothing in the shipped library reads MANTA_ACC_GATHER_ONLY."""
+    from manta_rs_amd import api
+    blob = open(api.LIB_PATH, "rb").read()
+    assert b"GATHER_ONLY" not in blob and b"gather_only_chunks" not in blob
+
+
 def test_shard_ranges_tile_the_index_space():
     from manta_rs_amd import distributed
     for n in (1, 7, 35174, 1 << 20):

@@ -144,3 +144,27 @@ def test_product_serialiser_reproduces_the_reference_vk_bytes(name):
         assert api.point_serialize(0, 1, pt, False)[:32] == b[:31] + bytes([b[31] & 0x3F])  # x without the flag bits
     # the host-side group law of the product on reference-held points: sum of gamma_abc = oracle's sum
     assert (api.points_sum(0, 1, np.stack(vk.abc)) == O.g_sum(0, 1, np.stack(vk.abc))).all()
+
+
+# BLAKE3 digests of the verifying-key files as the reference lists them (manta-parameters/data.checkfile:15-17,35-37; the
+# files themselves are tests/golden/*.dat) and of the empty input (the checkfile's digest of its zero-length parameter files)
+CHECKFILE = {
+    "testnet-private-transfer.dat": "6ab2557f70f5583779f7cbcd27e73e66f8fcb5704ab21792a4126e89cc15b793",
+    "testnet-to-private.dat": "5e2e618e067c9414fed3ca5b570f8f2b33c9a0a42b925dc723f6fdfdd7436c5c",
+    "testnet-to-public.dat": "d1467307aa8b51b26fb0247eede05cdb3a8d94a3db2a5939f5e181da6024a9a5",
+    "private-transfer.dat": "117d2789bd52fcc66b39f1526a876c23570ae39fcc67b27ba2846e9767e458e2",
+    "to-private.dat": "c9c8333f74f83c600c37f18f5c64538c99450a317c0ecb3eef9eb43ac58817b2",
+    "to-public.dat": "399e3b65fdc16e068472c429315964bd5a12683c3e67fdfe2b2aede92b164887",
+}
+
+
+def test_product_blake3_reproduces_the_reference_checkfile():
+    """`manta_parameters::verify` is `blake3::hash(data) == checksum` (manta-parameters/src/lib.rs:173-177). The library's
+    BLAKE3 (host code behind mg_ctx_create_from_bytes_checked; no GPU needed) must give the digests data.checkfile holds for
+    the six key files the repository carries -- 36 KB each: 36 chunks, i.e. the tree mode -- and for the empty input."""
+    from manta_rs_amd import api
+    assert api.blake3(b"").hex() == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    for name, want in CHECKFILE.items():
+        data = open(os.path.join(HERE, "golden", name), "rb").read()
+        assert api.blake3(data).hex() == want, name
+        assert api.blake3(data[:-1]).hex() != want

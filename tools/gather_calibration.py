@@ -1,7 +1,10 @@
 """Calibration of the accumulate kernel's memory side. Runs the 2^20 BLS12-381 G1 MSM of bench.py
 with the normal accumulate kernel and -- in a second process, MANTA_ACC_GATHER_ONLY=1 -- with its gather-only twin
 (same sorted stream, same 128 B base-record gathers, no field arithmetic), for several window widths. Prints the
-HIP-event duration of that kernel per launch. usage: python tools/gather_calibration.py [c ...]"""
+HIP-event duration of that kernel per launch. The twin exists only in a -DMG_CALIBRATION build of the library:
+    tools/build_variant.sh calib "-DMG_CALIBRATION" msm_bls381_g1        (here, before gpurun)
+which this script selects through MANTA_LIB; the shipped libmantagpu.so does not read MANTA_ACC_GATHER_ONLY.
+usage: python tools/gather_calibration.py [c ...]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -30,6 +33,10 @@ for c in [int(a) for a in sys.argv[1:]] or [16]:
     for g in (0, 1):
         env = dict(os.environ)
         if g:
+            lib = os.path.join(ROOT, "manta_rs_amd", "lib", "libmantagpu_calib.so")
+            if not os.path.exists(lib):
+                sys.exit("no calibration build: run tools/build_variant.sh calib \"-DMG_CALIBRATION\" msm_bls381_g1 first")
+            env["MANTA_LIB"] = lib
             env["MANTA_ACC_GATHER_ONLY"] = "1"
         r = subprocess.run([sys.executable, "-c", CHILD, str(c)], env=env, capture_output=True, text=True)
         print(r.stdout.strip() or r.stderr[-500:], flush=True)
