@@ -46,11 +46,80 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 # v_mad_u64_u32 per mixed addition in the 14 x 28-bit representation (ec_dev.h madd_lazy): 6 products x 406 + 2 squarings x
 # 315 + one fused a*b + c*d product with a single reduction (3 x 196 + 14 = 602); round 1 had 8 x 406 + 2 x 315 = 3878
 MADS_PER_MIXED_ADD = 6 * 406 + 2 * 315 + 602
-PEAK_TMAD_S = 1024 * 64 / 4.2 * 2.4e9 / 1e12  # 1024 SIMDs x 64 lanes / 4.2 cycles (profiles/r01_ubench2_mad_u64_u32.txt) x 2.4 GHz
+PEAK_TMAD_S_ASSUMED = 1024 * 64 / 4.2 * 2.4e9 / 1e12  # 1024 SIMDs x 64 lanes / 4.2 cycles (profiles/r01_ubench2_mad_u64_u32.txt) x an ASSUMED 2.4 GHz
 
 BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
           0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
 S0, S1 = 0x243F6A8885A308D313198A2E03707344, 0x9E3779B97F4A7C15F39CC0605CEDC835
+
+
+class SclkSampler(threading.Thread):
+    """samples the GPU's shader clock from sysfs while a timed loop runs (hwmon freq1_input in Hz, else the starred level of
+    pp_dpm_sclk); mean / min / max in MHz, or None where the box exposes neither"""
+
+    def __init__(self, period=0.004):
+        super().__init__(daemon=True)
+        import glob
+        self.src = None
+        for pat, kind in (("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input", "hwmon"), ("/sys/class/drm/card*/device/pp_dpm_sclk", "dpm")):
+            hits = sorted(glob.glob(pat))
+            if hits:
+                self.src = (hits[0], kind)
+                break
+        self.period, self.vals, self.stop_ev = period, [], threading.Event()
+
+    def read(self):
+        path, kind = self.src
+        txt = open(path).read()
+        if kind == "hwmon":
+            return float(txt.strip()) / 1e6
+        for ln in txt.splitlines():
+            if ln.rstrip().endswith("*"):
+                return float("".join(ch for ch in ln.split(":")[1] if ch.isdigit() or ch == "."))
+        return None
+
+    def run(self):
+        while self.src and not self.stop_ev.is_set():
+            try:
+                v = self.read()
+                if v:
+                    self.vals.append(v)
+            except Exception:
+                return
+            time.sleep(self.period)
+
+    def result(self):
+        self.stop_ev.set()
+        if self.is_alive():
+            self.join(timeout=1)
+        if not self.vals:
+            return None
+        return {"source": self.src[0], "samples": len(self.vals), "mean_MHz": round(sum(self.vals) / len(self.vals), 1),
+                "min_MHz": round(min(self.vals), 1), "max_MHz": round(max(self.vals), 1)}
+
+
+def hbm_reference():
+    """on-box figures next to the 8 TB/s vendor peak `roofline.peak` uses: device-to-device copy and a
+    triad-like a + b -> b over 1 GiB operands (torch, current device)"""
+    import torch
+    n = 1 << 28  # 1 GiB of float32
+    a = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+    b = torch.empty_like(a)
+
+    def timeit(f, reps=8):
+        f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / reps
+    tc = timeit(lambda: b.copy_(a))
+    tt = timeit(lambda: torch.add(a, b, out=b))
+    del a, b
+    torch.cuda.empty_cache()
+    return {"d2d_copy_TBps": round(2 * 4 * n / tc / 1e12, 2), "triad_TBps": round(3 * 4 * n / tt / 1e12, 2), "vendor_peak_TBps": HBM_PEAK_GBPS / 1e3,
+            "how": "torch copy_ / add(out=) over 1 GiB float32 operands, read + write bytes"}
 
 
 def host_info():
@@ -200,7 +269,11 @@ def msm_bench(args, env):
     result = inst.run(1, 1)
     assert (result == inst.expected()).all(), "MSM result does not match the closed-form expectation"
 
+    sampler = SclkSampler() if env.rank == 0 else None
+    if sampler:
+        sampler.start()
     dt, acc_pipe = inst.timed(args.steps, DEPTH, warmup=args.warmup, kernel_timing=True)
+    sclk = sampler.result() if sampler else None
     line = {
         "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(env.world * n * args.steps / dt / 1e6, 3),
         "unit": "Mscalar/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
@@ -273,13 +346,29 @@ def msm_bench(args, env):
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        mads = None
+        mads = clock = None
+        try:  # the issue peak of the multiplier and the clock under that load, measured now on this box (mg_clock_probe)
+            mhz, mad_per_us, probe_ms = inst.api.clock_probe(150000)
+            clock = {"s_memtime_MHz_under_int_mad_load": round(mhz, 1), "wave_mads_per_simd_per_us": round(mad_per_us, 2), "probe_ms": round(probe_ms, 2),
+                     "sclk_during_timed_msm_loop": sclk,
+                     "how": "two wavefronts per SIMD on every CU spinning on 8 independent v_mad_u64_u32 chains; s_memtime ticks per "
+                            "wall-clock second; sclk sampled from sysfs every 4 ms while the pipelined loop ran (None: not exposed on this box)"}
+            peak_meas = mad_per_us * 1e6 * 1024 * 64 / 1e12
+        except Exception as e:  # noqa: BLE001
+            clock, peak_meas = {"error": str(e)}, None
         if LOG_N == 20 and WINDOW_BITS == 16:  # ~15.06 mixed adds per scalar (16 signed 16-bit windows, top one nearly empty)
             m = n * 15.06 * MADS_PER_MIXED_ADD
-            mads = {"mads_per_launch": int(m), "achieved_Tmad_s": round(m / (k_alone * 1e-3) / 1e12, 2),
-                    "peak_Tmad_s": round(PEAK_TMAD_S, 2), "frac": round(m / (k_alone * 1e-3) / 1e12 / PEAK_TMAD_S, 3)}
+            ach = m / (k_alone * 1e-3) / 1e12
+            mads = {"mads_per_launch_modelled": int(m), "model": "15.06 mixed additions per scalar x %d multiply-adds each (PMC: 16.0 wave-additions per scalar-lane)" % MADS_PER_MIXED_ADD,
+                    "achieved_Tmad_s": round(ach, 2),
+                    "peak_Tmad_s": round(peak_meas, 2) if peak_meas else None, "frac": round(ach / peak_meas, 3) if peak_meas else None,
+                    "peak_how": "issue rate measured in this run by mg_clock_probe (no clock assumed) x 1024 SIMDs x 64 lanes",
+                    "peak_Tmad_s_assuming_2.4GHz": round(PEAK_TMAD_S_ASSUMED, 2), "frac_assuming_2.4GHz": round(ach / PEAK_TMAD_S_ASSUMED, 3)}
         roofline = {"bound": "hbm", "kernel": "accumulate_chunks<FpR<Bls381Fq>>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "traffic_source": "profiles/pmc_accumulate.json: FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes "
+                                      "of an earlier run of this build (not re-measured by this run)",
+                    "clock": clock,
                     "kernel_ms": round(k_alone, 4),
                     "kernel_ms_how": "HIP events on the kernel's own stream, averaged over the %d latency-mode steps of this run "
                                      "(one MSM in flight, so the span is the launch duration; rocprofv3 --kernel-trace of "
@@ -290,6 +379,11 @@ def msm_bench(args, env):
                     "algorithmic_bytes_per_launch": algo,
                     "note": "integer-multiply bound, not HBM bound (SURVEY.md F7); int_mad gives the bound that governs",
                     "int_mad": mads}
+    if env.rank == 0 and env.world == 1 and not args.quick:
+        try:
+            line["hbm_reference"] = hbm_reference()
+        except Exception as e:  # noqa: BLE001
+            line["hbm_reference"] = {"error": str(e)}
     line["roofline"], line["cpu_baseline"] = roofline, cpu
     # the CPU baseline runs LAST (main): OpenMP worker threads of the oracle must not share the host with the timed GPU legs
     line["_cpu_todo"] = (inst, result, n) if (env.rank == 0 and not args.no_cpu_baseline and env.world == 1) else None
@@ -333,6 +427,93 @@ def strong_scaling(args, env):
                      "Mscalar_s_pipelined": round(n_total * steps / dt3 / 1e6, 3)}
         inst.bases.close()
     return out
+
+
+def ntt_bench(env, log_n=20):
+    """SURVEY.md 8(d) "NTT micro": 2^20 uniform BLS12-381 Fr elements resident in HBM, forward / inverse / coset transforms in
+    place through mg_ntt_device (natural order in and out, arkworks format in and out). Algorithmic bytes = one read + one
+    write of the vector = 64 B per element. Parity gate: inverse(forward(x)) == x before timing."""
+    from manta_rs_amd import api, synth
+    curve, D = 1, 1 << log_n
+    p = synth.FR_MODULUS[curve]
+    rng = np.random.RandomState(0x4E5454)
+    x = rng.randint(0, 1 << 62, size=(D, 4), dtype=np.int64).astype(np.uint64)
+    x[:, 3] &= np.uint64((1 << 60) - 1)  # < p: valid Montgomery residues
+    d = api.DeviceBuffer.from_numpy(x)
+    dom = api.Radix2EvaluationDomain(curve, D)
+    dom.fft_device(d, False, False)
+    dom.fft_device(d, True, False)
+    assert (d.to_numpy(shape=(D, 4)) == x).all(), "ifft(fft(x)) != x"
+    dom.fft_device(d, False, True)
+    dom.fft_device(d, True, True)
+    assert (d.to_numpy(shape=(D, 4)) == x).all(), "coset_ifft(coset_fft(x)) != x"
+    out = {"curve": "BLS12-381", "log_n": log_n, "algorithmic_bytes": 64 * D, "data": "uniform Fr, resident in HBM, transformed in place"}
+    api.set_kernel_timing(True)
+    for name, inv, cos in (("fft", 0, 0), ("ifft", 1, 0), ("coset_fft", 0, 1), ("coset_ifft", 1, 1)):
+        reps, dev, parts = 12, [], []
+        for _ in range(2):
+            dom.fft_device(d, inv, cos)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dom.fft_device(d, inv, cos)
+            v = api.last_ntt_ms()
+            dev.append(v[0])
+            parts.append(v[1:])
+        wall = (time.perf_counter() - t0) / reps
+        ms = float(np.median(dev))
+        pm = np.median(np.array(parts), axis=0)
+        npass = -(-log_n // 10)
+        out[name] = {"device_ms": round(ms, 4), "Melem_per_s": round(D / ms / 1e3, 1), "algorithmic_GBps": round(64 * D / ms / 1e6, 1),
+                     "frac_of_hbm_peak": round(64 * D / ms / 1e6 / HBM_PEAK_GBPS, 4), "call_wall_ms": round(wall * 1e3, 4),
+                     "conversion_in_us": round(float(pm[0]) * 1e3, 1), "butterfly_passes": npass,
+                     "us_per_pass": round(float(pm[1]) * 1e3 / npass, 1), "conversion_out_us": round(float(pm[2]) * 1e3, 1)}
+    api.set_kernel_timing(False)
+    d.free()
+    return out
+
+
+def config2_bench(env, log_d=20):
+    """BASELINE configs[2]: "2^20 Fr radix-2 NTT + 2^20 G1/G2 MSM -> single Groth16 proof, 1 MI355X" (SURVEY.md 8(d) config 3):
+    BLS12-381, D = V = 2^20, P = 16, synthetic chain circuit, valid key generated on the GPU. Parity gate here: the proof
+    verifies on the GPU (mg_groth16_verify, BLS12-381 pairing) and is reproduced bit for bit by a second run; the byte
+    comparison with the CPU oracle at this size is tests/test_gpu_configs.py::test_config2_* (it takes minutes of CPU)."""
+    from manta_rs_amd import api, synth, keygen
+    curve, D, P = 1, 1 << log_d, 16
+    p = synth.FR_MODULUS[curve]
+    t0 = time.perf_counter()
+    c = synth.make_circuit(curve, D - P, D, P, seed=0x4D414E5441_0301)
+    rng = synth.XorShift(0x4D414E5441_0302)
+    pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
+    ctx = api.ProvingContext(curve, pk)
+    ctx.set_r1cs(api.R1CS.from_circuit(c))
+    setup_s = time.perf_counter() - t0
+    rs = synth.to_mont([rng.field(p), rng.field(p)], p, 4)
+    z = api.PinnedArray.like(c.z)
+    first = api.Groth16.prove_with_randomness(ctx, z.array, rs[0], rs[1])
+    vctx = api.VerifyingContext(curve, pk)
+    assert api.groth16_verify(vctx, c.z[1:c.P], api.proof_decode(curve, first)), "2^20 BLS12-381 proof does not verify"
+    vctx.close()
+    ts = []
+    for _ in range(6):
+        t = time.perf_counter()
+        pr = api.Groth16.prove_with_randomness(ctx, z.array, rs[0], rs[1])
+        ts.append(time.perf_counter() - t)
+        assert pr == first
+    api.set_kernel_timing(True)  # eager launches with events between the phases
+    phases = None
+    for _ in range(3):
+        assert api.Groth16.prove_with_randomness(ctx, z.array, rs[0], rs[1]) == first
+        phases = api.last_prove_phases_ms()
+    api.set_kernel_timing(False)
+    ctx.close()
+    z.free()
+    return {"workload": "one Groth16 proof, BLS12-381, D = V = 2^%d, P = 16: 3 SpMV + 7 NTT of 2^%d + 4 G1 MSM + 1 G2 MSM of ~2^%d terms" % (log_d, log_d, log_d),
+            "prove_ms": round(min(ts) * 1e3, 3), "prove_ms_median": round(float(np.median(ts)) * 1e3, 3), "proofs_per_s": round(1 / min(ts), 2),
+            "phases_ms": phases,
+            "phases_note": "HIP events between the phases of one proof enqueued with plain launches (the timed runs above replay captured "
+                           "graphs); the five MSMs run concurrently on their own streams, so the phases overlap and do not add up to prove_ms",
+            "parity": "verified on the GPU (BLS12-381 pairing), identical bytes on every run; oracle byte comparison in tests/test_gpu_configs.py",
+            "setup_s": round(setup_s, 1)}
 
 
 def sharded_proof_bench(args, env):
@@ -400,6 +581,32 @@ def sharded_proof_bench(args, env):
 
 
 # ---------------------------------------------------------------------------------------------------- proofs
+_DISTINCT = {}  # shape -> (circuit, [K, V, 4] uint64 assignments); filled by main() BEFORE the process initialises HIP
+
+
+def _assign_worker(seed):
+    return _REASSIGNER.assign(seed).z
+
+
+def precompute_assignments(shape, K):
+    """K independent satisfying assignments of the shape's circuit (z_0 = the circuit's own, z_j from
+    seed ...1000+j: fresh public inputs, fresh boolean witnesses, every gate output recomputed). ~0.1 s of Python each, so
+    they are made by a fork pool -- before this process touches the GPU (a forked HIP context is not usable)."""
+    global _REASSIGNER
+    import multiprocessing as mp
+    from manta_rs_amd import synth
+    c = synth.make_shape(synth.BN254, shape)
+    _REASSIGNER = synth.Reassigner(c)
+    try:
+        procs = max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        procs = 4
+    seeds = [0x4D414E5441_1000 + j for j in range(1, K)]
+    with mp.get_context("fork").Pool(procs) as pool:
+        zs = pool.map(_assign_worker, seeds, chunksize=max(1, len(seeds) // (4 * procs)))
+    _DISTINCT[shape] = (c, np.stack([c.z] + zs))
+
+
 class ProveSetup:
     def __init__(self, shape):
         from manta_rs_amd import api, synth, keygen
@@ -407,7 +614,7 @@ class ProveSetup:
         curve = self.curve = synth.BN254
         p = self.p = synth.FR_MODULUS[curve]
         t0 = time.perf_counter()
-        self.c = synth.make_shape(curve, shape)
+        self.c, self.zs = _DISTINCT[shape] if shape in _DISTINCT else (synth.make_shape(curve, shape), None)
         self.rng = synth.XorShift(0x4D414E5441_0002)
         toxic = [self.rng.field(p) for _ in range(5)]
         self.pk = keygen.generate(self.c, toxic)
@@ -431,9 +638,14 @@ class ProveSetup:
         self.api.synchronize()
 
     def zk(self, K):
+        """K assignments back to back: distinct ones when they were prepared (K <= their number), else K copies"""
         if K not in self.zK:
-            self.zK[K] = self.api.PinnedArray.like(np.stack([self.c.z] * K))
+            src = self.zs[:K] if self.zs is not None and len(self.zs) >= K else np.stack([self.c.z] * K)
+            self.zK[K] = self.api.PinnedArray.like(src)
         return self.zK[K].array
+
+    def distinct(self, K):
+        return self.zs is not None and len(self.zs) >= K
 
     def run(self, steps, threads, K):
         """`steps` proofs, `threads` host threads sharing ONE ProvingContext (the reference's signer does the same,
@@ -475,7 +687,7 @@ class ProveSetup:
         return env.max_over_ranks(time.perf_counter() - t0), proofs
 
 
-def verify_bench(ps, proofs):
+def verify_bench(ps, proofs, zs=None):
     """mg_groth16_verify / mg_groth16_verify_batch on the proofs just produced (same circuit and inputs for all of them:
     the verifier's work does not depend on that). Proof decoding (decompression + subgroup checks, host) is outside the
     timed region, as a `Proof` arrives deserialised in the reference."""
@@ -484,6 +696,10 @@ def verify_bench(ps, proofs):
     inputs = ps.c.z[1:ps.c.P]
     pts = [api.proof_decode(ps.curve, p) for p in proofs[:256]]
     assert api.groth16_verify(vctx, inputs, pts[0])
+    if zs is not None:  # distinct assignments: every proof against ITS public inputs; one against a neighbour's must fail
+        for i in (1, len(pts) // 2, len(pts) - 1):
+            assert api.groth16_verify(vctx, zs[i][1:ps.c.P], pts[i]), "proof %d of the distinct batch does not verify" % i
+        assert not api.groth16_verify(vctx, zs[2][1:ps.c.P], pts[1])
     bad = inputs.copy()
     bad[0] = ps.rs[0][0]
     assert not api.groth16_verify(vctx, bad, pts[0])
@@ -494,7 +710,7 @@ def verify_bench(ps, proofs):
     t1 = (time.perf_counter() - t0) / n1
     k = len(pts)
     rnd = np.random.RandomState(7).randint(1, 1 << 62, size=(k, 2)).astype(np.uint64)
-    allin = np.stack([inputs] * k)
+    allin = np.stack([inputs] * k) if zs is None else np.ascontiguousarray(zs[:k, 1:ps.c.P])
     assert api.groth16_verify_batch(vctx, allin, pts, rnd)
     t0 = time.perf_counter()
     nb = 3
@@ -561,17 +777,25 @@ def prove_bench(args, env, shape="private_transfer", full=True):
     dt, pb = ps.timed(env, nb, 2, K)
     assert pb[0] == first
     res["batched"] = {"proofs_per_s": round(env.world * nb / dt, 2), "host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,
-                      "ms_per_proof": round(dt / nb * 1e3, 4)}
+                      "ms_per_proof": round(dt / nb * 1e3, 4),
+                      "assignments": ("%d distinct satisfying assignments per call (fresh public inputs and witnesses, synth.Reassigner), "
+                                      "distinct (r, s) per proof" % K) if ps.distinct(K) else "one assignment repeated, distinct (r, s) per proof"}
     res["value"] = res["batched"]["proofs_per_s"]
     if full:  # SURVEY f-2: `Groth16::verify` on the GPU -- one proof at a time and 256 at once by random linear combination
-        res["verify"] = verify_bench(ps, pb)
+        res["verify"] = verify_bench(ps, pb, ps.zs if ps.distinct(K) else None)
     res["n_gpus"] = env.world
     res["scaling"] = "weak (replicas: every GPU proves its own stream, no collective)"
     algo_bytes = 7 * 64 * D + 32 * V + 32 * D + 64 * (3 * V - P + D) + 128 * V
-    res["roofline"] = {"bound": "hbm", "achieved": round(algo_bytes * res["value"] / 1e9, 3), "peak": HBM_PEAK_GBPS * env.world, "unit": "GB/s",
-                       "frac": round(algo_bytes * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6), "traffic": None,
-                       "algorithmic_bytes_per_proof": algo_bytes,
-                       "note": "whole-proof algorithmic bytes (SURVEY.md 8(d), SpMV term excluded); integer-multiply and latency bound"}
+    nnz, m = int(len(ps.c.A.col) + len(ps.c.B.col) + len(ps.c.C.col)), int(ps.c.m)
+    spmv_bytes = nnz * 36 + 3 * (m + 1) * 4 + 3 * m * 32  # SURVEY.md 8(d) SpMV term of THIS circuit (z is counted once above)
+    with_spmv = algo_bytes + spmv_bytes
+    res["roofline"] = {"bound": "hbm", "achieved": round(with_spmv * res["value"] / 1e9, 3), "peak": HBM_PEAK_GBPS * env.world, "unit": "GB/s",
+                       "frac": round(with_spmv * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6), "traffic": None,
+                       "algorithmic_bytes_per_proof": with_spmv,
+                       "algorithmic_bytes_per_proof_without_spmv": algo_bytes, "frac_without_spmv": round(algo_bytes * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6),
+                       "spmv_nnz": nnz,
+                       "note": "whole-proof algorithmic bytes (SURVEY.md 8(d)) incl. the SpMV term of the synthetic circuit (%d non-zeros; the survey's "
+                               "~68 MB assumed ~0.5 M of them); integer-multiply and latency bound" % nnz}
     res["_cpu_todo"] = (ps, proofs if proofs else pb) if (env.rank == 0 and env.world == 1 and not args.no_cpu_baseline) else None
     ps.release_gpu()  # the CPU baseline needs the host-side circuit / key / randomness only
     return res
@@ -611,6 +835,17 @@ def prove_leg_in_child(args, env):
     if out.returncode != 0 or not lines:
         raise RuntimeError("proofs leg failed on rank %d:\n%s" % (env.rank, out.stdout[-2000:] + out.stderr[-2000:]))
     res = json.loads(lines[-1])
+    if env.world == 1 and not args.quick:  # SURVEY a-11: the other two shapes of the reference's benches, batched stream only
+        res["shapes"] = {}
+        for shape in ("to_private", "to_public"):
+            o2 = subprocess.run(cmd[:2] + ["--workload", "prove", "--child", "--shape", shape, "--batched-only", "--no-cpu-baseline", "--gpus", "1",
+                                           "--steps", str(args.steps), "--warmup", str(args.warmup)], env=cenv, capture_output=True, text=True)
+            l2 = [ln for ln in o2.stdout.splitlines() if ln.startswith("{")]
+            if o2.returncode == 0 and l2:
+                r2 = json.loads(l2[-1])
+                res["shapes"][shape] = {"workload": r2["workload"], "batched": r2["batched"], "setup_s": r2["setup_s"]}
+            else:
+                res["shapes"][shape] = {"error": (o2.stdout[-500:] + o2.stderr[-500:])}
     if env.world > 1:
         parts = [None] * env.world
         env.dist.all_gather_object(parts, res["batched"])
@@ -639,6 +874,8 @@ def main():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)         # internal: print the proofs object only
     ap.add_argument("--batched-only", action="store_true", help=argparse.SUPPRESS)  # internal: skip the single-proof legs
     args = ap.parse_args()
+    if args.workload == "prove" and not args.batched_only and os.environ.get("MANTA_BENCH_DISTINCT", "1") != "0":
+        precompute_assignments(args.shape, 256)  # before anything initialises HIP in this process
     env = Env(args)
     if args.workload == "prove":
         res = prove_bench(args, env, args.shape, full=env.world == 1 and not args.batched_only)
@@ -663,6 +900,10 @@ def main():
     if args.workload == "both" and not args.quick:
         proofs = prove_leg_in_child(args, env)
     line, inst = msm_bench(args, env)
+    if args.workload == "both" and not args.quick and env.world == 1:
+        inst.bases.close()  # the 2 GiB window tables: the legs below allocate their own
+        line["ntt"] = ntt_bench(env)
+        line["config2"] = config2_bench(env)
     if args.workload == "both" and not args.quick:
         if env.world > 1:
             line["strong_scaling"] = strong_scaling(args, env)

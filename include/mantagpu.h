@@ -73,6 +73,18 @@ int mg_host_free(void *hptr);
  * duration of the calling thread's most recently finished MSM. Off by default. */
 int mg_set_kernel_timing(int on);
 float mg_last_accumulate_ms(void);
+/* With kernel timing on, the same for the calling thread's last mg_ntt / mg_ntt_device -- out4 = { whole call on the device,
+ * conversion in, butterfly passes, conversion out } in ms -- and for its last SINGLE proof, which is then enqueued with plain
+ * launches instead of the captured graphs -- out10 = { upload of z, witness map, MSM a, b_g1, b_g2, l, h (each on its own
+ * stream), part A (all but the G2 MSM) from upload to join, the G2 chain from upload to its end, host assembly after the
+ * GPU } in ms: the per-phase report SURVEY.md 8(d) asks of BASELINE configs[2]. */
+/* Clock probe: two wavefronts per SIMD on every CU spin on dependent v_mad_u64_u32 chains (the instruction the MSM is
+ * bound by) for `iters` x 32 multiply-adds each, reading the shader clock counter (s_memtime) and the constant-rate wall
+ * clock around the loop: *memtime_mhz = the rate the counter ran at under that load, *mad_issue_per_us_per_simd = wave-level
+ * multiply-adds a SIMD issued per microsecond (the measured issue peak, no clock assumed), *ms = duration of the probe. */
+int mg_clock_probe(unsigned iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms);
+int mg_last_ntt_ms(float out4[4]);
+int mg_last_prove_phases_ms(float out10[10]);
 
 /* ---- variable-base MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars)
  *      (ark-ec 0.3.0 msm/variable_base.rs; called 5x per proof from ark-groth16 create_proof, reached

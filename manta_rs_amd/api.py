@@ -67,6 +67,7 @@ EXPORTS = [
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
+    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe",
 ]
 
 
@@ -110,6 +111,30 @@ def set_kernel_timing(on):
 
 def last_accumulate_ms():
     return float(LIB.mg_last_accumulate_ms())
+
+
+def clock_probe(iters=200000):
+    """`mg_clock_probe`: (MHz the s_memtime counter ran at, wave-level v_mad_u64_u32 issued per SIMD and microsecond, probe ms)
+    under an all-SIMD integer multiply-add load of two wavefronts per SIMD"""
+    a, b, c = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+    _chk(LIB.mg_clock_probe(ctypes.c_uint(iters), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), "mg_clock_probe")
+    return a.value, b.value, c.value
+
+
+def last_ntt_ms():
+    """with kernel timing on: (whole call, conversion in, butterfly passes, conversion out) of this thread's last NTT, ms"""
+    v = (ctypes.c_float * 4)()
+    _chk(LIB.mg_last_ntt_ms(v), "mg_last_ntt_ms")
+    return [float(x) for x in v]
+
+
+def last_prove_phases_ms():
+    """with kernel timing on: the phase split of this thread's last single proof (see mantagpu.h), ms"""
+    v = (ctypes.c_float * 10)()
+    _chk(LIB.mg_last_prove_phases_ms(v), "mg_last_prove_phases_ms")
+    names = ("upload_z", "witness_map", "msm_a", "msm_b_g1", "msm_b_g2", "msm_l", "msm_h", "part_a_upload_to_join", "g2_chain_upload_to_end",
+             "host_assembly_after_gpu")
+    return {n: round(float(x), 4) for n, x in zip(names, v)}
 
 
 def synchronize():

@@ -98,6 +98,25 @@ MG_API int mg_set_kernel_timing(int on) {
     return MG_SUCCESS;
 }
 MG_API float mg_last_accumulate_ms(void) { return last_accumulate_ms(); }
+namespace mg {
+int clock_probe(u32 iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms);
+}
+MG_API int mg_clock_probe(unsigned iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms) {
+    MG_TRY
+    if (iters == 0 || iters > (1u << 24)) return MG_ERROR_INVALID_ARGUMENT;
+    return clock_probe(iters, memtime_mhz, mad_issue_per_us_per_simd, ms);
+    MG_CATCH
+}
+MG_API int mg_last_ntt_ms(float out4[4]) {
+    if (!out4) return MG_ERROR_INVALID_ARGUMENT;
+    get_last_ntt_ms(out4);
+    return MG_SUCCESS;
+}
+MG_API int mg_last_prove_phases_ms(float out10[10]) {
+    if (!out10) return MG_ERROR_INVALID_ARGUMENT;
+    get_last_prove_ms(out10);
+    return MG_SUCCESS;
+}
 
 // ---------------------------------------------------------------------------------------------- MSM
 static void bases_free(mg_bases *b) {

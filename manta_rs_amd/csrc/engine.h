@@ -41,6 +41,14 @@ void set_kernel_timing(bool on);
 bool kernel_timing();
 void set_last_accumulate_ms(float ms);
 float last_accumulate_ms();
+// with kernel timing on: the last mg_ntt / mg_ntt_device of this thread -- [0] whole call on the device, [1] conversion in,
+// [2] butterfly passes, [3] conversion out (ms); and the last single proof of this thread, run with eager launches --
+// [0] upload of z, [1] witness map, [2..6] MSM a, b_g1, b_g2, l, h (each on its own stream), [7] part A (everything but
+// the G2 MSM) from upload to join, [8] G2 MSM from upload to its end, [9] host assembly after the GPU (ms)
+void set_last_ntt_ms(const float v[4]);
+void get_last_ntt_ms(float v[4]);
+void set_last_prove_ms(const float v[10]);
+void get_last_prove_ms(float v[10]);
 // process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)
 constexpr int MAX_DEVICES = 16;
 int current_device(); // hipGetDevice, clamped to the engine tables

@@ -119,3 +119,73 @@ int field_op(int field, int op, int repr, int lazy_a, int lazy_b, const u32 *a, 
 }
 
 } // namespace mg
+
+// ---- clock probe (bench.py): what does the chip clock at under the accumulate kernel's kind of load? Every SIMD gets two
+// wavefronts spinning on eight independent v_mad_u64_u32 chains each (the multiplier the MSM is bound by); each wavefront reads the
+// shader-clock counter (s_memtime) and the constant-rate wall clock (s_memrealtime) before and after. ticks(s_memtime) per
+// wall-clock second = the frequency s_memtime counts at during the load.
+namespace mg {
+__global__ __launch_bounds__(256) void clock_probe_kernel(u32 iters, u32 seed, unsigned long long *__restrict__ out) {
+    unsigned long long acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = seed + threadIdx.x + 977u * k;
+    const u32 m = 0x9e3779b9u ^ blockIdx.x;
+    const long long c0 = clock64();
+    const unsigned long long w0 = wall_clock64();
+    for (u32 i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = (unsigned long long)(u32)acc[k] * m + acc[k]; // v_mad_u64_u32, eight independent chains
+    }
+    const long long c1 = clock64();
+    const unsigned long long w1 = wall_clock64();
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a ^= acc[k];
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        out[3 * w] = (unsigned long long)(c1 - c0);
+        out[3 * w + 1] = w1 - w0;
+        out[3 * w + 2] = a ^ b; // keeps the chain alive
+    }
+}
+// -> MHz of the s_memtime counter and of v_mad_u64_u32 issue (mads per SIMD-microsecond), duration of the probe in ms
+int clock_probe(u32 iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms) {
+    int dev = 0, cus = 0, wall_khz = 0;
+    MG_HIP(hipGetDevice(&dev));
+    MG_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    MG_HIP(hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, dev));
+    const u32 blocks = (u32)cus * 2; // 256 threads = 4 wavefronts per block, two blocks per CU: two wavefronts per SIMD
+    const size_t waves = (size_t)blocks * 4;
+    unsigned long long *d = nullptr;
+    MG_HIP(hipMalloc((void **)&d, waves * 3 * sizeof(unsigned long long)));
+    hipEvent_t e0, e1;
+    MG_HIP(hipEventCreate(&e0));
+    MG_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, 0, 64u, 1u, d); // warm-up
+    MG_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, 0, iters, 2u, d);
+    MG_HIP(hipEventRecord(e1, 0));
+    hipError_t e = hipEventSynchronize(e1);
+    std::vector<unsigned long long> h(waves * 3);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    float t = 0.f;
+    hipEventElapsedTime(&t, e0, e1);
+    hipFree(d);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess) {
+        set_last_hip_error(e, "clock probe", __FILE__, __LINE__);
+        return MG_ERR_HIP;
+    }
+    double ratio = 0;
+    for (size_t w = 0; w < waves; ++w) ratio += (double)h[3 * w] / (double)(h[3 * w + 1] ? h[3 * w + 1] : 1);
+    ratio /= (double)waves;
+    if (memtime_mhz) *memtime_mhz = ratio * (double)wall_khz / 1e3;
+    // 32 multiply-adds per iteration and lane-wavefront, two wavefronts per SIMD
+    if (mad_issue_per_us_per_simd) *mad_issue_per_us_per_simd = t > 0 ? 2.0 * 32.0 * (double)iters / ((double)t * 1e3) : 0;
+    if (ms) *ms = t;
+    return MG_OK;
+}
+} // namespace mg

@@ -401,14 +401,33 @@ template <class FrC> class FrEngineT : public FrEngine {
         std::lock_guard<std::mutex> g(scratch_mu_);
         if (!d->scratch_rr) MG_HIP(hipMalloc((void **)&d->scratch_rr, (size_t)n * RK * 4));
         u32 *tmp = d->scratch_rr;
+        const bool timed = kernel_timing(); // bench.py's NTT leg: HIP events between the kernels of this call
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (timed)
+            for (auto &e : ev) MG_HIP(hipEventCreate(&e));
+        if (timed) MG_HIP(hipEventRecord(ev[0], s));
         hipLaunchKernelGGL((ntt_load_rr_kernel<FrC>), dim3(gn), dim3(256), 0, s, d_data, log_n,
                            (!inverse && coset) ? d->coset_fwd_rr : (const u32 *)nullptr, tmp);
+        if (timed) MG_HIP(hipEventRecord(ev[1], s));
         const u32 *post = inverse && coset && log_n > 0 ? d->coset_inv_rr : nullptr; // n^-1 g^-i, natural order
         run_passes<false>(tmp, tmp, tmp, 1, inverse ? d->tw_inv_rr : d->tw_fwd_rr, log_n, post, s);
+        if (timed) MG_HIP(hipEventRecord(ev[2], s));
         // plain ifft: times n^-1 in the conversion kernel (for n = 1 the coset tables are 1 as well)
         hipLaunchKernelGGL((rr_to_std_kernel<FrC>), dim3(gn), dim3(256), 0, s, tmp, (size_t)n,
                            (inverse && !coset && log_n > 0) ? d->consts_rr : (const u32 *)nullptr, d_data);
+        if (timed) MG_HIP(hipEventRecord(ev[3], s));
         hipError_t e = hipStreamSynchronize(s); // the scratch vector is handed to the next caller after this
+        if (timed) {
+            float v[4] = {0, 0, 0, 0};
+            if (e == hipSuccess) {
+                hipEventElapsedTime(&v[0], ev[0], ev[3]);
+                hipEventElapsedTime(&v[1], ev[0], ev[1]);
+                hipEventElapsedTime(&v[2], ev[1], ev[2]);
+                hipEventElapsedTime(&v[3], ev[2], ev[3]);
+            }
+            set_last_ntt_ms(v);
+            for (auto &x : ev) hipEventDestroy(x);
+        }
         if (e != hipSuccess) {
             set_last_hip_error(e, "ntt transform", __FILE__, __LINE__);
             return MG_ERR_HIP;

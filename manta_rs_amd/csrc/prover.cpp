@@ -18,6 +18,7 @@
 #include <map>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -69,6 +70,11 @@ struct ProveWs {
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
     int eager_runs = 0;
     bool no_graph = false;
+    // kernel timing (bench.py's per-phase split of a single proof): timing events, created on first use; a timed pass is
+    // enqueued eagerly -- [0] before the upload of z, [1] after it, [2] witness map done, [3 + 2i], [4 + 2i] around MSM i on
+    // its stream, [13] part A joined, [14] G2 MSM done
+    hipEvent_t tev[15] = {};
+    bool timed = false;
     void drop_graphs() {
         if (g_all) hipGraphExecDestroy(g_all);
         if (g_g2) hipGraphExecDestroy(g_g2);
@@ -97,6 +103,8 @@ struct ProveWs {
         if (z_ready) hipEventDestroy(z_ready);
         if (h_ready) hipEventDestroy(h_ready);
         if (fork) hipEventDestroy(fork);
+        for (auto &e : tev)
+            if (e) hipEventDestroy(e);
         stream_pool_put(stream); // never destroyed: see stream_pool_get()
         stream_pool_put(side[0]);
         stream_pool_put(side[1]);
@@ -296,12 +304,12 @@ class ProverImpl : public Prover {
         return MG_OK;
     }
 
-    // Replaces the circuit. All-or-nothing, on every shard at once (two phases): first every shard validates the three
-    // matrices, uploads them into temporaries and builds the h-query tables of a new domain size -- nothing that a proof can
-    // see changes, and a failure on any shard (say, out of memory on one device) frees the temporaries everywhere and leaves
-    // the previous circuit, if any, fully usable; then the exclusive locks of ALL shards are taken in the order in which a
-    // pass takes its shared ones (shard 0, then the peers) -- so no pass is in flight on any of them -- and every shard is
-    // switched over under them: a proof never runs with some shards on the new matrices and others on the old.
+    // Replaces the circuit. All-or-nothing, on every shard at once: the exclusive locks of ALL shards are taken in the order in
+    // which a pass takes its shared ones (shard 0, then the peers) -- so no pass is in flight on any of them; then, in two
+    // phases, every shard first validates the three matrices, uploads them into temporaries and builds the h-query tables of
+    // a new domain size -- a failure on any shard (say, out of memory on one device) frees the temporaries everywhere and
+    // leaves the previous circuit, if any, fully usable -- and only when all of them have succeeded is every shard switched
+    // over: a proof never runs with some shards on the new matrices and others on the old.
     struct StagedR1cs {
         DevCsr A, B, C;
         BaseSet *h = nullptr, *h_wide = nullptr;
@@ -316,6 +324,12 @@ class ProverImpl : public Prover {
         std::lock_guard<std::mutex> one_at_a_time(set_mu_);
         std::vector<ProverImpl *> all{this};
         all.insert(all.end(), peers_.begin(), peers_.end());
+        // The exclusive locks are taken BEFORE staging as well: staging uploads with synchronous copies, builds window tables
+        // on the default stream and ends in hipDeviceSynchronize, and the HIP runtime fails the graph capture of a proof
+        // slot on another thread when that happens meanwhile (seen on MI355X: mg_groth16_prove returning a HIP error while a
+        // circuit was being staged). With every shard locked no pass is in flight, none starts, nothing is capturing.
+        std::vector<std::unique_lock<std::shared_mutex>> locks;
+        for (ProverImpl *q : all) locks.emplace_back(q->shape_mu_);
         std::vector<StagedR1cs> st(all.size());
         for (size_t g = 0; g < all.size() && !rc; ++g) rc = all[g]->stage_r1cs(a, b, c, m, st[g]);
         if (rc) {
@@ -323,11 +337,7 @@ class ProverImpl : public Prover {
             hipSetDevice(prev);
             return rc;
         }
-        {
-            std::vector<std::unique_lock<std::shared_mutex>> locks;
-            for (ProverImpl *q : all) locks.emplace_back(q->shape_mu_);
-            for (size_t g = 0; g < all.size(); ++g) all[g]->commit_staged(st[g]);
-        }
+        for (size_t g = 0; g < all.size(); ++g) all[g]->commit_staged(st[g]);
         hipSetDevice(prev);
         return MG_OK;
     }
@@ -577,7 +587,14 @@ class ProverImpl : public Prover {
         const u32 *dz = w->z.as<u32>();
         // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
         // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-        const bool wide = w->k >= 4;
+        // batched passes switch to the wide-window tables (fewer mixed additions, longer bucket reduce) from this many proofs
+        // on: a pass of a few coalesced single calls is still a latency chain and keeps the narrow ones (MANTA_WIDE_MIN)
+        static const u32 wide_min = [] {
+            const char *e = std::getenv("MANTA_WIDE_MIN");
+            const int v = e ? std::atoi(e) : 4;
+            return (u32)(v >= 1 && v <= 64 ? v : 4);
+        }();
+        const bool wide = w->k >= wide_min;
         // a range shard multiplies its contiguous slice of every query by the matching slice of the scalars
         const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
         const size_t hlo = shard_lo(D), hn = shard_hi(D) - hlo;
@@ -608,13 +625,18 @@ class ProverImpl : public Prover {
             return MG_OK;
         }
         // the z MSMs see witness scalars (mostly 0 / 1 / small): compact their zero digits; h is dense
-        return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
+        if (w->timed) MG_HIP(hipEventRecord(w->tev[3 + 2 * i], msm_stream(w, i)));
+        const int rc = w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
+        if (w->timed && !rc) MG_HIP(hipEventRecord(w->tev[4 + 2 * i], msm_stream(w, i)));
+        return rc;
     }
     int enqueue_part_a(ProveWs *w, bool use_graphs) {
         int rc;
         const MsmArgs a = msm_args(w);
         MG_HIP(hipEventRecord(w->fork, w->stream)); // z is on the device (upload_z ran on this stream)
+        if (w->timed) MG_HIP(hipEventRecord(w->tev[1], w->stream));
         if ((rc = launch_witness_map(w, use_graphs))) return rc;
+        if (w->timed) MG_HIP(hipEventRecord(w->tev[2], w->stream));
         for (int i = 0; i < 5; ++i) {
             if (!in_part_a(i)) continue;
             hipStream_t ms = msm_stream(w, i);
@@ -625,14 +647,23 @@ class ProverImpl : public Prover {
             hipStream_t ms = msm_stream(w, i);
             if (in_part_a(i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
+        if (w->timed) MG_HIP(hipEventRecord(w->tev[13], w->stream));
         return MG_OK;
     }
     int enqueue_part_b(ProveWs *w, bool use_graphs) { return enqueue_msm(w, msm_args(w), 2, use_graphs); }
 
     int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
+        if (w->timed) MG_HIP(hipEventRecord(w->tev[0], w->stream));
         int rc = upload_z(w, z_src);
         if (rc) return rc;
         hipStream_t g2s = msm_stream(w, 2);
+        if (w->timed) { // eager launches with events between the phases
+            if ((rc = enqueue_part_a(w, false))) return rc;
+            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
+            if ((rc = enqueue_part_b(w, false))) return rc;
+            MG_HIP(hipEventRecord(w->tev[14], g2s));
+            return MG_OK;
+        }
         if (w->g_all && w->g_g2) { // "single" mode replay
             // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
             // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
@@ -939,8 +970,17 @@ class ProverImpl : public Prover {
             std::memcpy(w->h_z, z, zbytes);
             z_src = (const uint64_t *)w->h_z;
         }
-        if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2) build_graphs(w);
-        if (w->graphs_ready) {
+        w->timed = false;
+        if (kernel_timing() && k == 1 && peers_.empty()) {
+            bool ok = true;
+            for (auto &e : w->tev)
+                if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
+            w->timed = ok;
+        }
+        if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2 && !w->timed) build_graphs(w);
+        if (w->timed) {
+            rc = enqueue_proof(w, z_src, false);
+        } else if (w->graphs_ready) {
             rc = enqueue_proof(w, z_src, graph_mode() == GRAPH_SPLIT);
             if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
                 hipStreamSynchronize(w->stream);
@@ -1220,6 +1260,16 @@ class ProverImpl : public Prover {
         if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
         // ---- part B: the G2 element
         collect(msm_stream(w, 2), false);
+        float phases[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const bool timed = w->timed && !rc;
+        if (timed) { // every event has completed: both parts were synchronised above
+            hipEventElapsedTime(&phases[0], w->tev[0], w->tev[1]);
+            hipEventElapsedTime(&phases[1], w->tev[1], w->tev[2]);
+            for (int i = 0; i < 5; ++i) hipEventElapsedTime(&phases[2 + i], w->tev[3 + 2 * i], w->tev[4 + 2 * i]);
+            hipEventElapsedTime(&phases[7], w->tev[0], w->tev[13]);
+            hipEventElapsedTime(&phases[8], w->tev[0], w->tev[14]);
+        }
+        const auto t_host = std::chrono::steady_clock::now();
         ws_release(w);
         p.w = nullptr;
         if (peer_passes)
@@ -1230,6 +1280,10 @@ class ProverImpl : public Prover {
             }
         if (rc) return rc;
         assemble_g2(k, res.data(), bl.data(), p.out);
+        if (timed) {
+            phases[9] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host).count();
+            set_last_prove_ms(phases);
+        }
         return MG_OK;
     }
 };

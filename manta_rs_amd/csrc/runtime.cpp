@@ -29,6 +29,11 @@ void set_kernel_timing(bool on) { g_kernel_timing = on; }
 bool kernel_timing() { return g_kernel_timing; }
 void set_last_accumulate_ms(float ms) { g_last_acc_ms = ms; }
 float last_accumulate_ms() { return g_last_acc_ms; }
+static thread_local float g_last_ntt_ms[4] = {0, 0, 0, 0}, g_last_prove_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+void set_last_ntt_ms(const float v[4]) { std::memcpy(g_last_ntt_ms, v, sizeof(g_last_ntt_ms)); }
+void get_last_ntt_ms(float v[4]) { std::memcpy(v, g_last_ntt_ms, sizeof(g_last_ntt_ms)); }
+void set_last_prove_ms(const float v[10]) { std::memcpy(g_last_prove_ms, v, sizeof(g_last_prove_ms)); }
+void get_last_prove_ms(float v[10]) { std::memcpy(v, g_last_prove_ms, sizeof(g_last_prove_ms)); }
 
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap) return MG_OK;
