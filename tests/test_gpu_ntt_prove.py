@@ -133,15 +133,8 @@ def test_ntt_full_size_roundtrip_and_linearity(gpu, curve):
 
 
 def _pk_bytes(curve, pk):
-    """arkworks 0.3 ProvingKey::serialize_unchecked layout (SURVEY.md App. A.3 / App. C), written with the
-    oracle's uncompressed point encoder."""
-    import struct
-    ser1 = lambda p: O.serialize(curve, 1, p, compressed=False)
-    ser2 = lambda p: O.serialize(curve, 2, p, compressed=False)
-    vec = lambda pts, f: struct.pack("<Q", len(pts)) + b"".join(f(p) for p in pts)
-    return (ser1(pk.alpha_g1[0]) + ser2(pk.beta_g2[0]) + ser2(pk.gamma_g2[0]) + ser2(pk.delta_g2[0]) +
-            vec(pk.gamma_abc_g1, ser1) + ser1(pk.beta_g1[0]) + ser1(pk.delta_g1[0]) + vec(pk.a_query, ser1) +
-            vec(pk.b_g1_query, ser1) + vec(pk.b_g2_query, ser2) + vec(pk.h_query, ser1) + vec(pk.l_query, ser1))
+    import fixture_io
+    return fixture_io.pk_bytes(O, curve, pk)
 
 
 @pytest.mark.parametrize("curve", [0, 1])

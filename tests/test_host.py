@@ -205,6 +205,25 @@ def test_rust_patch_has_no_panic_on_upload_failure():
     assert ".gpu()?" in added and "GpuProvingContext::new(&self.proving_key, None).map_err(|_| Error)?" in added
 
 
+def test_capture_fixture_container_round_trips_and_matches_the_rust_writer():
+    """tests/fixture_io.py mirrors rust/capture/src/lib.rs (the writer that runs next to the reference): same section list,
+    and encode -> decode gives back every field; truncation and trailing bytes are refused."""
+    import fixture_io as FX
+    rust = open(os.path.join(ROOT, "rust", "capture", "src", "lib.rs")).read()
+    assert 'pub const SECTIONS: &str = "%s";' % FX.SECTIONS in rust and 'b"MGFX0001"' in rust
+    c = synth.make_circuit(0, 40, 30, 4, seed=5)
+    r, s = np.arange(4, dtype=np.uint64) + 7, np.arange(4, dtype=np.uint64) + 11
+    blob = FX.encode(0, c.A, c.B, c.C, c.m, c.P, c.z, r, s, b"\x01" * 100, b"\x02" * 128)
+    fx = FX.decode(blob)
+    assert (fx.curve, fx.m, fx.P, fx.V) == (0, c.m, c.P, c.V)
+    for got, want in ((fx.A, c.A), (fx.B, c.B), (fx.C, c.C)):
+        assert (got.row_ptr == want.row_ptr).all() and (got.col == want.col).all() and (got.val == want.val).all()
+    assert (fx.z == c.z).all() and (fx.r == r).all() and (fx.s == s).all() and fx.pk_bytes == b"\x01" * 100 and fx.proof == b"\x02" * 128
+    for bad in (blob[:-1], blob + b"\x00", b"XXXXXXXX" + blob[8:]):
+        with pytest.raises(ValueError):
+            FX.decode(bad)
+
+
 def test_release_library_has_no_calibration_switch():
     """The gather-only calibration twin of the accumulate kernel (wrong results by design) and the environment variable
     that selected it exist only in -DMG_CALIBRATION builds: nothing in the shipped library reads MANTA_ACC_GATHER_ONLY."""

@@ -6,7 +6,8 @@ import numpy as np
 import bench
 ps = bench.ProveSetup("private_transfer")
 api = ps.api
-for k in (1, 2, 3, 4, 6, 8, 16, 32):
+KS = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 6, 8, 16, 32]
+for k in KS:
     zs = ps.zk(k) if k > 1 else ps.z1_pin.array
     sel = list(range(k))
     def one():
