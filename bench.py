@@ -53,49 +53,41 @@ BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55
 S0, S1 = 0x243F6A8885A308D313198A2E03707344, 0x9E3779B97F4A7C15F39CC0605CEDC835
 
 
-class SclkSampler(threading.Thread):
-    """samples the GPU's shader clock from sysfs while a timed loop runs (hwmon freq1_input in Hz, else the starred level of
-    pp_dpm_sclk); mean / min / max in MHz, or None where the box exposes neither"""
-
-    def __init__(self, period=0.004):
-        super().__init__(daemon=True)
-        import glob
-        self.src = None
-        for pat, kind in (("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input", "hwmon"), ("/sys/class/drm/card*/device/pp_dpm_sclk", "dpm")):
-            hits = sorted(glob.glob(pat))
-            if hits:
-                self.src = (hits[0], kind)
-                break
-        self.period, self.vals, self.stop_ev = period, [], threading.Event()
-
-    def read(self):
-        path, kind = self.src
-        txt = open(path).read()
-        if kind == "hwmon":
-            return float(txt.strip()) / 1e6
-        for ln in txt.splitlines():
-            if ln.rstrip().endswith("*"):
-                return float("".join(ch for ch in ln.split(":")[1] if ch.isdigit() or ch == "."))
+def pmc_traffic():
+    """HBM traffic of the accumulate kernel measured by THIS run: two child runs of the MSM headline under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit one,
+    MI355X_MICROARCH.md "rocprofv3 PMC slots"), per-launch average over the launches of accumulate_chunks. Raw counter values
+    (KiB): the 2x correction of the guide applies to wide coalesced streaming reads; this kernel's pattern -- one 128 B gather per
+    mixed addition -- was calibrated with a gather-only twin (profiles/r02_pmc_and_gather_calibration.txt) and is not
+    under-reported. Returns None when rocprofv3 is not available."""
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
         return None
-
-    def run(self):
-        while self.src and not self.stop_ev.is_set():
-            try:
-                v = self.read()
-                if v:
-                    self.vals.append(v)
-            except Exception:
-                return
-            time.sleep(self.period)
-
-    def result(self):
-        self.stop_ev.set()
-        if self.is_alive():
-            self.join(timeout=1)
-        if not self.vals:
-            return None
-        return {"source": self.src[0], "samples": len(self.vals), "mean_MHz": round(sum(self.vals) / len(self.vals), 1),
-                "min_MHz": round(min(self.vals), 1), "max_MHz": round(max(self.vals), 1)}
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="mg_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", MANTA_BENCH_NO_PMC="1")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "m", "--", sys.executable, os.path.abspath(__file__), "--workload", "msm",
+               "--quick", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"]
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+        dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            shutil.rmtree(d, ignore_errors=True)
+            return {"error": "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])}
+        db = sqlite3.connect(dbs[0])
+        rows = list(db.execute("select count(*), sum(value) from counters_collection where kernel_name like '%accumulate_chunks%' and counter_name = ?",
+                               (counter,)))
+        db.close()
+        shutil.rmtree(d, ignore_errors=True)
+        if not rows or not rows[0][0]:
+            return {"error": "no %s rows for accumulate_chunks" % counter}
+        out[counter] = (int(rows[0][0]), float(rows[0][1]) / rows[0][0])
+    kib = out["FETCH_SIZE"][1] + out["WRITE_SIZE"][1]
+    return {"hbm_bytes_per_launch": int(kib * 1024), "FETCH_SIZE_KiB_per_launch": round(out["FETCH_SIZE"][1], 1),
+            "WRITE_SIZE_KiB_per_launch": round(out["WRITE_SIZE"][1], 1), "launches_averaged": out["FETCH_SIZE"][0]}
 
 
 def hbm_reference():
@@ -209,6 +201,7 @@ class MsmInstance:
         self.p = p
         self.G = synth.to_mont(list(BLS_G1 if curve == 1 else (1, 2)), q, synth.FQ_LIMBS[curve]).reshape(-1)
         self.launch_kw = {}
+        self.acc_mhz = []
         lo, hi = distributed.shard_range(n_total, env.rank, env.world)
         self.n = hi - lo
         self.ks = [(S0 + i * S1) % p for i in range(lo, hi)]
@@ -236,6 +229,7 @@ class MsmInstance:
             out = pending.pop(0).finish()  # local fold + all_gather of the partial points + N-term sum
             if acc_ms is not None:
                 acc_ms.append(self.api.last_accumulate_ms())  # HIP events around the accumulate kernel, on its stream
+                self.acc_mhz.append(self.api.last_accumulate_mhz())  # shader clock of the same launch (s_memtime / wall clock)
             return out
         for _ in range(steps):
             pending.append(self.msm.launch(self.d_sc, self.n, **self.launch_kw))
@@ -269,11 +263,8 @@ def msm_bench(args, env):
     result = inst.run(1, 1)
     assert (result == inst.expected()).all(), "MSM result does not match the closed-form expectation"
 
-    sampler = SclkSampler() if env.rank == 0 else None
-    if sampler:
-        sampler.start()
     dt, acc_pipe = inst.timed(args.steps, DEPTH, warmup=args.warmup, kernel_timing=True)
-    sclk = sampler.result() if sampler else None
+    mhz_pipe = [v for v in inst.acc_mhz if v > 0]
     line = {
         "metric": "G1 MSM Mscalar/s at 2^%d" % LOG_N, "value": round(env.world * n * args.steps / dt / 1e6, 3),
         "unit": "Mscalar/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
@@ -283,7 +274,9 @@ def msm_bench(args, env):
     # ---- latency mode (one MSM at a time: nothing hides the merge / reduce / host-fold tail) doubles as the
     # stand-alone measurement of the dominant kernel: with one MSM in flight the HIP-event span IS the kernel's duration
     lat_steps = max(5, min(args.steps, 10))
+    inst.acc_mhz = []
     dt_lat, acc_alone = inst.timed(lat_steps, 1, warmup=2, kernel_timing=True)
+    mhz_alone = [v for v in inst.acc_mhz if v > 0]
     # ---- plain bases: what `VariableBaseMSM::multi_scalar_mul(bases, scalars)` literally takes (no precomputed tables)
     plain = None
     if env.world == 1 and not args.quick:
@@ -349,10 +342,12 @@ def msm_bench(args, env):
         mads = clock = None
         try:  # the issue peak of the multiplier and the clock under that load, measured now on this box (mg_clock_probe)
             mhz, mad_per_us, probe_ms = inst.api.clock_probe(150000)
-            clock = {"s_memtime_MHz_under_int_mad_load": round(mhz, 1), "wave_mads_per_simd_per_us": round(mad_per_us, 2), "probe_ms": round(probe_ms, 2),
-                     "sclk_during_timed_msm_loop": sclk,
-                     "how": "two wavefronts per SIMD on every CU spinning on 8 independent v_mad_u64_u32 chains; s_memtime ticks per "
-                            "wall-clock second; sclk sampled from sysfs every 4 ms while the pipelined loop ran (None: not exposed on this box)"}
+            clock = {"probe_MHz": round(mhz, 1), "probe_wave_mads_per_simd_per_us": round(mad_per_us, 2), "probe_ms": round(probe_ms, 2),
+                     "accumulate_kernel_MHz_latency_mode": round(float(np.mean(mhz_alone)), 1) if mhz_alone else None,
+                     "accumulate_kernel_MHz_pipelined": round(float(np.mean(mhz_pipe)), 1) if mhz_pipe else None,
+                     "how": "shader clock = s_memtime ticks per wall-clock second (s_memrealtime, constant rate). probe: mg_clock_probe, two "
+                            "wavefronts per SIMD on every CU spinning on 8 independent v_mad_u64_u32 chains each; accumulate kernel: its first "
+                            "wavefront brackets its own run (the launches of the timed loops above)"}
             peak_meas = mad_per_us * 1e6 * 1024 * 64 / 1e12
         except Exception as e:  # noqa: BLE001
             clock, peak_meas = {"error": str(e)}, None
@@ -364,10 +359,26 @@ def msm_bench(args, env):
                     "peak_Tmad_s": round(peak_meas, 2) if peak_meas else None, "frac": round(ach / peak_meas, 3) if peak_meas else None,
                     "peak_how": "issue rate measured in this run by mg_clock_probe (no clock assumed) x 1024 SIMDs x 64 lanes",
                     "peak_Tmad_s_assuming_2.4GHz": round(PEAK_TMAD_S_ASSUMED, 2), "frac_assuming_2.4GHz": round(ach / PEAK_TMAD_S_ASSUMED, 3)}
+            if peak_meas and mhz_alone:
+                # the probe's issue rate scaled to the clock the accumulate kernel itself ran at (same launches as kernel_ms)
+                pk = peak_meas * float(np.mean(mhz_alone)) / mhz
+                mads["peak_Tmad_s_at_the_kernels_own_clock"] = round(pk, 2)
+                mads["frac_at_the_kernels_own_clock"] = round(ach / pk, 3)
+        traffic_source = ("profiles/pmc_accumulate.json: FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes of an earlier "
+                          "run of this build (not re-measured by this run)")
+        live = None
+        if env.world == 1 and not args.quick and not os.environ.get("MANTA_BENCH_NO_PMC") and LOG_N == 20:
+            try:
+                live = pmc_traffic()
+            except Exception as e:  # noqa: BLE001
+                live = {"error": str(e)}
+            if live and "hbm_bytes_per_launch" in live:
+                traffic = live["hbm_bytes_per_launch"]
+                traffic_source = ("measured by this run: two child runs under rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate "
+                                  "passes), raw counters, average over %d launches of this kernel" % live["launches_averaged"])
         roofline = {"bound": "hbm", "kernel": "accumulate_chunks<FpR<Bls381Fq>>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "traffic_source": "profiles/pmc_accumulate.json: FETCH_SIZE + WRITE_SIZE of this kernel from separate rocprofv3 --pmc passes "
-                                      "of an earlier run of this build (not re-measured by this run)",
+                    "traffic_source": traffic_source, "traffic_pmc": live,
                     "clock": clock,
                     "kernel_ms": round(k_alone, 4),
                     "kernel_ms_how": "HIP events on the kernel's own stream, averaged over the %d latency-mode steps of this run "

@@ -73,6 +73,7 @@ int mg_host_free(void *hptr);
  * duration of the calling thread's most recently finished MSM. Off by default. */
 int mg_set_kernel_timing(int on);
 float mg_last_accumulate_ms(void);
+float mg_last_accumulate_mhz(void); /* the shader clock that launch ran at: s_memtime ticks of its first wavefront per wall-clock second */
 /* With kernel timing on, the same for the calling thread's last mg_ntt / mg_ntt_device -- out4 = { whole call on the device,
  * conversion in, butterfly passes, conversion out } in ms -- and for its last SINGLE proof, which is then enqueued with plain
  * launches instead of the captured graphs -- out10 = { upload of z, witness map, MSM a, b_g1, b_g2, l, h (each on its own

@@ -45,6 +45,7 @@ def _load():
     lib.mg_ctx_num_variables.restype = ctypes.c_uint64
     lib.mg_ctx_num_inputs.restype = ctypes.c_uint64
     lib.mg_last_accumulate_ms.restype = ctypes.c_float
+    lib.mg_last_accumulate_mhz.restype = ctypes.c_float
     lib.mg_vk_encoded_size.restype = ctypes.c_size_t
     lib.mg_vk_num_inputs.restype = ctypes.c_uint64
     lib.mg_xyzz_limbs.restype = ctypes.c_size_t
@@ -67,7 +68,7 @@ EXPORTS = [
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
-    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe",
+    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz",
 ]
 
 
@@ -111,6 +112,10 @@ def set_kernel_timing(on):
 
 def last_accumulate_ms():
     return float(LIB.mg_last_accumulate_ms())
+
+
+def last_accumulate_mhz():
+    return float(LIB.mg_last_accumulate_mhz())
 
 
 def clock_probe(iters=200000):

@@ -98,6 +98,7 @@ MG_API int mg_set_kernel_timing(int on) {
     return MG_SUCCESS;
 }
 MG_API float mg_last_accumulate_ms(void) { return last_accumulate_ms(); }
+MG_API float mg_last_accumulate_mhz(void) { return last_accumulate_mhz(); }
 namespace mg {
 int clock_probe(u32 iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms);
 }

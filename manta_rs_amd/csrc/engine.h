@@ -41,6 +41,8 @@ void set_kernel_timing(bool on);
 bool kernel_timing();
 void set_last_accumulate_ms(float ms);
 float last_accumulate_ms();
+void set_last_accumulate_mhz(float mhz); // shader clock of the same launch: s_memtime ticks of its first wavefront per wall-clock second
+float last_accumulate_mhz();
 // with kernel timing on: the last mg_ntt / mg_ntt_device of this thread -- [0] whole call on the device, [1] conversion in,
 // [2] butterfly passes, [3] conversion out (ms); and the last single proof of this thread, run with eager launches --
 // [0] upload of z, [1] witness map, [2..6] MSM a, b_g1, b_g2, l, h (each on its own stream), [7] part A (everything but
@@ -125,6 +127,7 @@ struct MsmWorkspace {
     size_t extra_off_pts = 0;                                       // where the extras start in h_stage (points)
     const u32 *d_tail = nullptr; // device copy of what msm_launch staged for the host fold (arkworks-format XYZZ points)
     DevBuf folded;               // msm_fold_device: one arkworks-format XYZZ point per batch member
+    DevBuf clk;                  // kernel timing: (s_memtime ticks, wall-clock ticks) of the accumulate kernel's first wavefront
     DevBuf scratch;              // caller-side scalars uploaded for one launch (the verifier's small MSMs)
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;

@@ -167,14 +167,22 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
 // (179 VGPRs for BLS12-381 G1 -> two wavefronts per SIMD, which already saturates the integer pipe; forcing
 // three through the launch bounds spills and is slower, software-prefetching the gather changes nothing; BN254 G1 needs 130
 // -> three per SIMD, and asking for four -- amdgpu_waves_per_eu(4, 4): 128 VGPRs, two spilled -- changes nothing either)
-template <class F>
+// PROBE = true is the measurement twin bench.py's roofline leg runs (kernel timing on): identical but for its first wavefront
+// bracketing its whole run with the shader clock counter (s_memtime) and the constant-rate wall clock -- ticks per wall-clock
+// second = the clock the kernel actually ran at. A template parameter, not a run-time test: the extra live values cost the
+// product kernel six VGPRs when they were an `if`.
+template <class F, bool PROBE = false>
 __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
                                                          u32 astride, u32 *__restrict__ buckets,
                                                          u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T,
-                                                         const u32 *__restrict__ count) {
+                                                         const u32 *__restrict__ count, unsigned long long *__restrict__ clk) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
+    long long c0 = 0;
+    unsigned long long w0 = 0;
+    if constexpr (PROBE)
+        if (t == 0) c0 = clock64(), w0 = wall_clock64();
     if (count) M = *count; // compacted pairs: lanes past the last pair have nothing to do
     const size_t begin = (size_t)t * L;
     size_t end = begin + L;
@@ -214,6 +222,8 @@ __global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__
         pkeys[2 * t + 1] = cur; // may be `invalid` (then the point is never read as a summand)
         acc.store(ppts + (size_t)(2 * t + 1) * XYZZ<F>::WORDS);
     }
+    if constexpr (PROBE)
+        if (t == 0) clk[0] = (unsigned long long)(clock64() - c0), clk[1] = wall_clock64() - w0;
 }
 
 #ifdef MG_CALIBRATION
@@ -1354,7 +1364,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             return rc;
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
         ws->timed = kernel_timing() && !ws->capturing;
-        if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
+        if (ws->timed) {
+            if ((rc = ws->clk.reserve(64))) return rc;
+            MG_HIP(hipMemsetAsync(ws->clk.p, 0, 16, s));
+            MG_HIP(hipEventRecord(ws->t0, s));
+        }
 #ifdef MG_CALIBRATION
         static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration build only (wrong results)
         if (gather_only)
@@ -1363,9 +1377,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                                (const u32 *)d_count);
         else
 #endif
-        hipLaunchKernelGGL((accumulate_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
-                           ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
-                           ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count);
+        if (ws->timed)
+            hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+                               ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count, ws->clk.as<unsigned long long>());
+        else
+            hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+                               ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count, (unsigned long long *)nullptr);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * T;
         int src = 0;
@@ -1576,6 +1595,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (ws->timed && !already_synced) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ws->t0, ws->t1) == hipSuccess) set_last_accumulate_ms(ms);
+            unsigned long long ck[2] = {0, 0};
+            int khz = 0, dev = 0;
+            if (hipMemcpy(ck, ws->clk.p, 16, hipMemcpyDeviceToHost) == hipSuccess && ck[1] && hipGetDevice(&dev) == hipSuccess &&
+                hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess)
+                set_last_accumulate_mhz((float)((double)ck[0] / (double)ck[1] * (double)khz / 1e3));
         }
         const MsmPlan &pl = ws->plan;
         const u32 Wb = (u32)pl.Wb, segs = ws->batch * Wb, T1 = ws->T1, nP = ws->nP;

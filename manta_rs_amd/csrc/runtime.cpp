@@ -29,6 +29,9 @@ void set_kernel_timing(bool on) { g_kernel_timing = on; }
 bool kernel_timing() { return g_kernel_timing; }
 void set_last_accumulate_ms(float ms) { g_last_acc_ms = ms; }
 float last_accumulate_ms() { return g_last_acc_ms; }
+static thread_local float g_last_acc_mhz = 0.f;
+void set_last_accumulate_mhz(float mhz) { g_last_acc_mhz = mhz; }
+float last_accumulate_mhz() { return g_last_acc_mhz; }
 static thread_local float g_last_ntt_ms[4] = {0, 0, 0, 0}, g_last_prove_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 void set_last_ntt_ms(const float v[4]) { std::memcpy(g_last_ntt_ms, v, sizeof(g_last_ntt_ms)); }
 void get_last_ntt_ms(float v[4]) { std::memcpy(v, g_last_ntt_ms, sizeof(g_last_ntt_ms)); }
@@ -103,7 +106,7 @@ void stream_pool_put(hipStream_t s) {
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
-                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch};
+                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch, &clk};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (done) hipEventDestroy(done);

@@ -117,6 +117,7 @@ extern "C" {
     pub fn mg_host_free(hptr: *mut c_void) -> c_int;
     pub fn mg_set_kernel_timing(on: c_int) -> c_int;
     pub fn mg_last_accumulate_ms() -> c_float;
+    pub fn mg_last_accumulate_mhz() -> c_float;
     pub fn mg_clock_probe(iters: c_uint, memtime_mhz: *mut f64, mad_issue_per_us_per_simd: *mut f64, ms: *mut f64) -> c_int;
     pub fn mg_last_ntt_ms(out4: *mut c_float) -> c_int;
     pub fn mg_last_prove_phases_ms(out10: *mut c_float) -> c_int;
