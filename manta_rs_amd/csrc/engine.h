@@ -139,6 +139,7 @@ struct MsmWorkspace {
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
     bool timed = false;
+    bool in_graph_slot = false; // owned by a proof slot whose launches are captured into hipGraphs (prover.cpp)
     bool capturing = false; // msm_launch is being stream-captured: enqueue kernels and copies only, no event records
     float accumulate_ms = 0.f;
     // host-side description of what was staged (filled by msm_launch, consumed by msm_finish)

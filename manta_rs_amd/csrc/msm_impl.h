@@ -1417,7 +1417,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipStream_t side = nullptr; // plain sums of the front levels run beside the weighted chain (stand-alone MSMs)
         {
             const RedKnobs &rk = red_knobs();
-            if (rk.lgS > 0 && rn >= rk.min_items) {
+            // (never for the MSMs of a proof slot -- ws->in_graph_slot: their launches are captured into hipGraphs, and a pass captured
+            // with the front levels in it made hipGraphLaunch segfault on ROCm 7.0, the multi-branch-graph defect described in
+            // runtime.cpp; eagerly launched, the batched prover gains 2-3 % from them: profiles/r03_batched_front_levels.txt)
+            if (rk.lgS > 0 && rn >= rk.min_items && !ws->in_graph_slot) {
                 if (!ws->capturing && !ws->run_on && rk.side) {
                     if (!ws->side_stream) {
                         MG_HIP(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking));

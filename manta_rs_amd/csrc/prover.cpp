@@ -95,6 +95,7 @@ struct ProveWs {
         for (int i = 0; i < 5; ++i)
             if (mw[i]) {
                 mw[i]->run_on = nullptr;
+                mw[i]->in_graph_slot = false;
                 me[i]->ws_release(mw[i]);
             }
         z.release();
@@ -448,6 +449,7 @@ class ProverImpl : public Prover {
                 delete w;
                 return nullptr;
             }
+            w->mw[i]->in_graph_slot = graphs_enabled();
         }
         // Three streams per proof, not six: the G2 MSM is the critical path (~3x a G1 MSM), so the three
         // z-MSMs over G1 run back to back beside it and the h MSM follows the witness map on the main stream.
