@@ -278,7 +278,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                       u32 invalid, int final_level, u32 *__restrict__ buckets,
                                                       u32 *__restrict__ okeys, u32 *__restrict__ opts, u32 n_waves) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -371,7 +371,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                            u32 invalid, int final_level, u32 *__restrict__ buckets,
                                                            u32 *__restrict__ okeys, u32 *__restrict__ opts) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x; // logical wave
@@ -473,7 +473,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_ATTR void tile_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                    u32 item_off, u32 n_items, u32 tiles_per_seg, u32 n_waves,
                                                    u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= n_waves) return;
@@ -526,7 +526,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_SERIAL_ATTR void serial_reduce(const u32 *__restrict__ in, u32 seg_stride /*points*/, u32 item_off,
                                                      u32 n_items, u32 S, u32 lanes_per_seg, u32 n_lanes,
                                                      u32 *__restrict__ outA, u32 *__restrict__ outS) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_lanes) return;
@@ -552,7 +552,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void serial_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/, u32 item_off,
                                                           u32 n_items, u32 S, u32 lanes_per_seg, u32 n_lanes,
                                                           u32 *__restrict__ outA, u32 *__restrict__ outS) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr size_t XW = XYZZ<F>::WORDS;
     const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
@@ -582,7 +582,7 @@ template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void tile_reduce_coop(const u32 *__restrict__ in, u32 seg_stride /*points*/,
                                                         u32 item_off, u32 n_items, u32 tiles_per_seg,
                                                         u32 *__restrict__ outA, u32 *__restrict__ outS, int std_out) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     const u32 tile_id = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void tile_reduce_coop(const 
 template <class F>
 __global__ __launch_bounds__(128) MG_TAIL_ATTR void reduce_level1(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
                                                      u32 *__restrict__ out_std) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     constexpr int XW = XYZZ<F>::WORDS;
     constexpr int SW = XYZZ<typename F::Std>::WORDS;
     const u32 seg = blockIdx.x;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(128) MG_TAIL_ATTR void reduce_level1(const u32 *__r
 template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void reduce_level1_coop(const u32 *__restrict__ A0, const u32 *__restrict__ S0, u32 T0,
                                                           u32 *__restrict__ out_std) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr int XW = XYZZ<F>::WORDS;
     constexpr int SW = XYZZ<typename F::Std>::WORDS;
@@ -704,7 +704,7 @@ struct FoldDesc {
 };
 template <class F>
 __global__ __launch_bounds__(64) void fold_windows(FoldDesc d, u32 *__restrict__ out, size_t out_stride) {
-    MG_PRIO_HIGH();
+    MG_PRIO_FOR(F);
     typedef typename F::Std S;
     constexpr int SW = XYZZ<S>::WORDS;
     const u32 q = blockIdx.x;

@@ -1,0 +1,5 @@
+V=$PWD/manta_rs_amd/lib/libmantagpu_frnoprio.so
+for rep in 1 2 3; do
+echo "== prio"; timeout 200 python tools/batch_threads_sweep.py 1024 2>/dev/null | grep -E "K=" | tail -2; timeout 100 python tools/prove_profile.py 2>/dev/null | tail -1
+echo "== noprio"; MANTA_LIB=$V timeout 200 python tools/batch_threads_sweep.py 1024 2>/dev/null | grep -E "K=" | tail -2; MANTA_LIB=$V timeout 100 python tools/prove_profile.py 2>/dev/null | tail -1
+done
