@@ -28,6 +28,40 @@ typedef uint64_t u64;
 #endif
 #define MG_PRIO_FOR(F) MG_PRIO_HIGH()
 
+enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_HIP = 2, MG_ERR_OOM = 3, MG_ERR_DOMAIN = 4, MG_ERR_STATE = 5 };
+
+#define MG_HIP(expr)                                                                                              \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) {                                                                                   \
+            mg::set_last_hip_error(e_, #expr, __FILE__, __LINE__);                                                \
+            return (e_ == hipErrorOutOfMemory) ? mg::MG_ERR_OOM : mg::MG_ERR_HIP;                                 \
+        }                                                                                                         \
+    } while (0)
+void set_last_hip_error(hipError_t e, const char *expr, const char *file, int line);
+// When on, every MSM brackets its accumulate kernel with HIP events on the launch stream (bench.py's
+// roofline leg); off by default.
+void set_kernel_timing(bool on);
+bool kernel_timing();
+void set_last_accumulate_ms(float ms);
+float last_accumulate_ms();
+void set_last_accumulate_mhz(float mhz); // shader clock of the same launch: s_memtime ticks of its first wavefront per wall-clock second
+float last_accumulate_mhz();
+// with kernel timing on: the last mg_ntt / mg_ntt_device of this thread -- [0] whole call on the device, [1] conversion in,
+// [2] butterfly passes, [3] conversion out (ms); and the last single proof of this thread, run with eager launches --
+// [0] upload of z, [1] witness map, [2..6] MSM a, b_g1, b_g2, l, h (each on its own stream), [7] part A (everything but
+// the G2 MSM) from upload to join, [8] G2 MSM from upload to its end, [9] host assembly after the GPU (ms)
+void set_last_ntt_ms(const float v[4]);
+void get_last_ntt_ms(float v[4]);
+void set_last_prove_ms(const float v[10]);
+void get_last_prove_ms(float v[10]);
+// process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)
+constexpr int MAX_DEVICES = 16;
+int current_device(); // hipGetDevice, clamped to the engine tables
+hipStream_t stream_pool_get();
+void stream_pool_put(hipStream_t s);
+const char *last_error_string();
+
 // makes `dev` the current device for a scope and restores the caller's on the way out: a host thread that drives several
 // GPUs must not find its device changed by a call into the library
 struct DeviceScope {
