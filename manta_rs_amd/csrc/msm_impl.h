@@ -171,8 +171,13 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
 // bracketing its whole run with the shader clock counter (s_memtime) and the constant-rate wall clock -- ticks per wall-clock
 // second = the clock the kernel actually ran at. A template parameter, not a run-time test: the extra live values cost the
 // product kernel six VGPRs when they were an `if`.
+#ifdef MG_ACC_WAVES // per translation unit: cap the accumulate kernel's registers for this many wavefronts per SIMD
+#define MG_ACC_ATTR __attribute__((amdgpu_waves_per_eu(MG_ACC_WAVES, MG_ACC_WAVES)))
+#else
+#define MG_ACC_ATTR
+#endif
 template <class F, bool PROBE = false>
-__global__ __launch_bounds__(256) void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
+__global__ __launch_bounds__(256) MG_ACC_ATTR void accumulate_chunks(const u32 *__restrict__ keys, const u32 *__restrict__ vals,
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
                                                          u32 astride, u32 *__restrict__ buckets,
                                                          u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T,

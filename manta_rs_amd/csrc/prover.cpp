@@ -748,6 +748,16 @@ class ProverImpl : public Prover {
     std::condition_variable cq_cv_;
     std::deque<Req *> cq_;
     int cq_inflight_ = 0;
+    bool cq_gathering_ = false; // a leader is waiting for the callers of the pass that has just finished
+    size_t cq_last_k_ = 1;      // size of the most recently finished pass
+    static int coalesce_gather_us() {
+        static const int n = [] {
+            const char *e = std::getenv("MANTA_COALESCE_GATHER_US");
+            const int v = e ? std::atoi(e) : 100; // (0 / 40 / 80 / 150 / 300 us -> six threads 1 609 / 1 621 / 1 784 / 1 850 / 1 620 proofs/s)
+            return v >= 0 && v <= 2000 ? v : 100;
+        }();
+        return n;
+    }
     static int coalesce_inflight() {
         static const int n = [] {
             const char *e = std::getenv("MANTA_COALESCE");
@@ -762,9 +772,26 @@ class ProverImpl : public Prover {
         Req me{z, r, s, proof_out};
         std::unique_lock<std::mutex> lk(cq_mu_);
         cq_.push_back(&me);
+        if (cq_gathering_) cq_cv_.notify_all(); // a leader is collecting arrivals
         for (;;) {
             if (me.done) return me.rc;
-            if (cq_inflight_ < coalesce_inflight() && !cq_.empty()) { // lead a pass: everything queued, oldest first
+            if (!cq_gathering_ && cq_inflight_ < coalesce_inflight() && !cq_.empty()) { // lead a pass: everything queued, oldest first
+                // The callers of a pass that has just finished come back one after the other within a few tens of microseconds.
+                // While ANOTHER pass keeps the GPU busy nothing is lost by letting them all arrive: without this the first one
+                // back led a pass of one and the rest followed as a pass of two -- six signer threads then ran as passes of
+                // 1 + 2 + 3 instead of 3 + 3. Only when a pass is in flight, only up to the size of the last finished pass, at
+                // most coalesce_gather_us(): a lone caller, or callers that never overlapped, are not delayed.
+                if (cq_inflight_ >= 1 && cq_.size() < cq_last_k_ && coalesce_gather_us() > 0) {
+                    cq_gathering_ = true;
+                    const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(coalesce_gather_us());
+                    while (cq_.size() < cq_last_k_ && cq_cv_.wait_until(lk, deadline) != std::cv_status::timeout) {
+                    }
+                    cq_gathering_ = false;
+                    if (me.done) { // (cannot happen while this thread gathers -- nobody else leads -- but stay safe)
+                        cq_cv_.notify_all();
+                        return me.rc;
+                    }
+                }
                 std::vector<Req *> batch;
                 while (!cq_.empty() && batch.size() < BATCH_CHUNK) {
                     batch.push_back(cq_.front());
@@ -783,6 +810,7 @@ class ProverImpl : public Prover {
                 lk.lock();
                 for (Req *q : batch) q->rc = rc, q->done = true;
                 --cq_inflight_;
+                cq_last_k_ = batch.size();
                 cq_cv_.notify_all();
                 continue;
             }
