@@ -784,7 +784,8 @@ class ProverImpl : public Prover {
                 if (cq_inflight_ >= 1 && cq_.size() < cq_last_k_ && coalesce_gather_us() > 0) {
                     cq_gathering_ = true;
                     const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(coalesce_gather_us());
-                    while (cq_.size() < cq_last_k_ && cq_cv_.wait_until(lk, deadline) != std::cv_status::timeout) {
+                    while (cq_.size() < cq_last_k_ && cq_inflight_ >= 1 && // (the other pass may finish meanwhile: then go at once)
+                           cq_cv_.wait_until(lk, deadline) != std::cv_status::timeout) {
                     }
                     cq_gathering_ = false;
                     if (me.done) { // (cannot happen while this thread gathers -- nobody else leads -- but stay safe)
