@@ -588,6 +588,21 @@ def sharded_proof_bench(args, env):
                        "ms_per_proof": round(dtb / (nb * K) * 1e3, 4)},
            "scaling": "strong (one proof's MSMs split N ways; the witness map is recomputed on every rank)"}
     sp.close()
+    # the alternative placement of SURVEY.md 8(e): every MSM computed in full by one rank (at most five busy), same exchange
+    tp = distributed.ShardedProver(curve, pk, max_batch=K, placement="task")
+    tp.set_r1cs(api.R1CS.from_circuit(c))
+    assert tp.prove(z1.array, rs[0][0], rs[0][1]) == first, "task-parallel proof differs from the range-sharded one"
+    for i in range(8):
+        tp.prove(z1.array, rs[i % nrs][0], rs[i % nrs][1])
+    env.barrier()
+    t0 = time.perf_counter()
+    for i in range(n1):
+        tp.prove(z1.array, rs[i % nrs][0], rs[i % nrs][1])
+    env.barrier()
+    dtt = env.max_over_ranks(time.perf_counter() - t0)
+    out["task_parallel"] = {"placement": "MSM i computed in full by one rank: masks %s (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h)" % distributed.task_masks(env.world),
+                            "sequential": {"ms_per_proof": round(dtt / n1 * 1e3, 4), "proofs_per_s": round(n1 / dtt, 2)}}
+    tp.close()
     return out
 
 

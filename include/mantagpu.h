@@ -253,6 +253,16 @@ int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, siz
  *     per rank and proof); adds them and finishes the proofs exactly like mg_groth16_prove -- bytes identical to the
  *     single-GPU context's. Host-only work: any rank (or all) may call it. */
 int mg_ctx_create_shard(mg_curve_t curve, const mg_pk_view *pk, int shard, int n_shards, mg_ctx **out);
+/* The alternative placement of SURVEY.md 8(e): TASK-parallel -- this process holds the whole key and computes the MSMs of
+ * task_mask in full (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h; the witness map only when it owns h); for the others
+ * mg_groth16_partials_launch writes the point at infinity, so the same gather + mg_groth16_assemble finish the proof. Five point
+ * transfers instead of a sum over ranks, at most five busy GPUs. mg_groth16_prove on such a context returns MG_ERROR_STATE. */
+#define MG_TASK_A 1u
+#define MG_TASK_B_G1 2u
+#define MG_TASK_B_G2 4u
+#define MG_TASK_L 8u
+#define MG_TASK_H 16u
+int mg_ctx_create_task(mg_curve_t curve, const mg_pk_view *pk, unsigned task_mask, mg_ctx **out);
 typedef struct mg_partials_job mg_partials_job;
 size_t mg_partials_slot_limbs(const mg_ctx *ctx);
 int mg_groth16_partials_launch(const mg_ctx *ctx, uint64_t k, const uint64_t *z_mont, uint64_t *d_out, void *stream,

@@ -68,7 +68,7 @@ EXPORTS = [
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
-    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz",
+    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
 ]
 
 
@@ -511,7 +511,7 @@ class ProvingContext:
     """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
     device-resident proving key; created once, shared by every proof of the shape."""
 
-    def __init__(self, curve, pk, devices=None, shard=None):
+    def __init__(self, curve, pk, devices=None, shard=None, task_mask=None):
         """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
         b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P.
         devices: list of HIP device indices -> every MSM of a proof is range-sharded over them
@@ -523,7 +523,9 @@ class ProvingContext:
                                                      "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
         v = _PkView(pk.V, pk.P, self._keep[8].shape[0], *[_p(a) for a in self._keep])
         h = _vp()
-        if shard is not None:
+        if task_mask is not None:  # task placement: this process computes the MSMs of the mask in full (`mg_ctx_create_task`)
+            _chk(LIB.mg_ctx_create_task(curve, ctypes.byref(v), ctypes.c_uint(int(task_mask)), ctypes.byref(h)), "mg_ctx_create_task")
+        elif shard is not None:
             _chk(LIB.mg_ctx_create_shard(curve, ctypes.byref(v), int(shard[0]), int(shard[1]), ctypes.byref(h)), "mg_ctx_create_shard")
         elif devices is None:
             _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")

@@ -468,6 +468,16 @@ MG_API int mg_ctx_create_shard(mg_curve_t curve, const mg_pk_view *pk, int shard
     return MG_SUCCESS;
     MG_CATCH
 }
+MG_API int mg_ctx_create_task(mg_curve_t curve, const mg_pk_view *pk, unsigned task_mask, mg_ctx **out) {
+    MG_TRY
+    if (!out) return MG_ERROR_INVALID_ARGUMENT;
+    Prover *p = nullptr;
+    int rc = prover_create_task((int)curve, pk, (u32)task_mask, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
 struct mg_partials_job {
     Prover *p;
     void *job;

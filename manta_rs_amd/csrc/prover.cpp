@@ -143,6 +143,10 @@ class ProverImpl : public Prover {
     int curve_ = 0;
     int dev_ = 0;                      // the HIP device this (shard of the) context lives on
     u32 shard_ = 0, n_shards_ = 1;     // range shard g of G: every MSM of a proof covers the g-th contiguous slice of its query
+    // task placement (SURVEY.md 8(e) last row; prover_create_task): bit i set = this context computes MSM i (a, b_g1, b_g2, l, h)
+    // in full; the others are some other rank's. Only the partials interface works on such a context; it launches eagerly.
+    u32 task_mask_ = 0x1f;
+    bool does(int i) const { return (task_mask_ >> i) & 1u; }
     std::vector<ProverImpl *> peers_;  // shard 0 only: shards 1 .. G-1 (owned); a pass runs on all of them, shard 0 assembles
     FrEngine *fr_ = nullptr;
     GroupEngine *g1_ = nullptr, *g2_ = nullptr;
@@ -637,22 +641,22 @@ class ProverImpl : public Prover {
         const MsmArgs a = msm_args(w);
         MG_HIP(hipEventRecord(w->fork, w->stream)); // z is on the device (upload_z ran on this stream)
         if (w->timed) MG_HIP(hipEventRecord(w->tev[1], w->stream));
-        if ((rc = launch_witness_map(w, use_graphs))) return rc;
+        if (does(4) && (rc = launch_witness_map(w, use_graphs))) return rc; // h is only needed by the h MSM
         if (w->timed) MG_HIP(hipEventRecord(w->tev[2], w->stream));
         for (int i = 0; i < 5; ++i) {
-            if (!in_part_a(i)) continue;
+            if (!in_part_a(i) || !does(i)) continue;
             hipStream_t ms = msm_stream(w, i);
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
             if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }
         for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
             hipStream_t ms = msm_stream(w, i);
-            if (in_part_a(i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
+            if (in_part_a(i) && does(i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         if (w->timed) MG_HIP(hipEventRecord(w->tev[13], w->stream));
         return MG_OK;
     }
-    int enqueue_part_b(ProveWs *w, bool use_graphs) { return enqueue_msm(w, msm_args(w), 2, use_graphs); }
+    int enqueue_part_b(ProveWs *w, bool use_graphs) { return does(2) ? enqueue_msm(w, msm_args(w), 2, use_graphs) : MG_OK; }
 
     int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
         if (w->timed) MG_HIP(hipEventRecord(w->tev[0], w->stream));
@@ -768,6 +772,7 @@ class ProverImpl : public Prover {
     }
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
         if (!z || !r || !s || !proof_out) return MG_ERR_ARG;
+        if (task_mask_ != 0x1f) return MG_ERR_STATE; // holds some of the MSMs only: partials_launch / assemble
         if (coalesce_inflight() == 0 || !peers_.empty()) return prove_pass(1, z, r, s, proof_out);
         Req me{z, r, s, proof_out};
         std::unique_lock<std::mutex> lk(cq_mu_);
@@ -864,6 +869,7 @@ class ProverImpl : public Prover {
     }
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
+        if (task_mask_ != 0x1f) return MG_ERR_STATE;
         if (k64 <= BATCH_CHUNK) return prove_pass(k64, z, r, s, proofs_out);
         // (passes of exactly BATCH_CHUNK proofs plus one remainder: equalising the pass sizes -- 256 proofs as 9 x 29 instead
         // of 8 x 32 -- was measured and is slower: every distinct pass size needs its own workspaces and captured graphs)
@@ -1007,7 +1013,8 @@ class ProverImpl : public Prover {
             z_src = (const uint64_t *)w->h_z;
         }
         w->timed = false;
-        if (kernel_timing() && k == 1 && peers_.empty()) {
+        if (task_mask_ != 0x1f) w->no_graph = true; // a subset of the MSMs: plain launches
+        if (kernel_timing() && k == 1 && peers_.empty() && task_mask_ == 0x1f) {
             bool ok = true;
             for (auto &e : w->tev)
                 if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
@@ -1194,8 +1201,14 @@ class ProverImpl : public Prover {
         // "single" mode -- on the stream its graph was launched on (the G1 MSMs are joined inside that graph)
         const bool replayed = w->graphs_ready && w->g_all && w->g_g2;
         auto fold_stream = [&](int i) { return replayed ? (i == 2 ? msm_stream(w, 2) : w->stream) : msm_stream(w, i); };
-        for (int i = 0; i < 5 && !rc; ++i)
-            rc = w->me[i]->msm_fold_device(w->mw[i], (u32 *)d_out + (size_t)i * sw, 5 * sw, fold_stream(i));
+        for (int i = 0; i < 5 && !rc; ++i) {
+            if (does(i)) {
+                rc = w->me[i]->msm_fold_device(w->mw[i], (u32 *)d_out + (size_t)i * sw, 5 * sw, fold_stream(i));
+            } else { // another rank's MSM: this rank contributes the point at infinity (all-zero XYZZ)
+                for (u64 q = 0; q < k64 && !rc; ++q)
+                    if (hipMemsetAsync((u32 *)d_out + (q * 5 + (u64)i) * sw, 0, sw * 4, fold_stream(i)) != hipSuccess) rc = MG_ERR_HIP;
+            }
+        }
         hipStream_t cs = (hipStream_t)consumer;
         if (!rc) {
             hipError_t e = hipSuccess;
@@ -1340,6 +1353,24 @@ int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards
     MG_HIP(hipGetDevice(&dev));
     ProverImpl *p = new ProverImpl();
     const int rc = p->init(curve, pk, dev, shard, n_shards);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return MG_OK;
+}
+
+// Task placement (last row): the context holds the whole key and computes the MSMs of `task_mask` in full (bit
+// i: a, b_g1, b_g2, l, h); the partial results of the ranks -- infinity where a rank does not own an MSM -- meet through the same
+// partials_launch / all_gather / assemble path as the range shards.
+int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **out) {
+    if (!pk || !out || task_mask > 0x1f) return MG_ERR_ARG;
+    int dev = 0;
+    MG_HIP(hipGetDevice(&dev));
+    ProverImpl *p = new ProverImpl();
+    p->task_mask_ = task_mask;
+    const int rc = p->init(curve, pk, dev, 0, 1);
     if (rc) {
         delete p;
         return rc;

@@ -74,6 +74,7 @@ int prover_create(int curve, const mg_pk_view *pk, Prover **out);
 // every MSM of a proof range-sharded over the listed devices; devices may repeat
 int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out);
 int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out);
+int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **out);
 // arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
 int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices = nullptr,
                              int n_devices = 0);

@@ -166,6 +166,19 @@ class ShardedMSM:
         return self.launch(d, local_scalars.shape[0]).finish()
 
 
+def task_masks(world: int):
+    """Task-parallel placement (last row): which of the five MSMs (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h) each rank
+    computes in full. Longest-processing-time greedy over rough weights -- the G2 MSM costs about three G1 MSMs of the same length,
+    h is dense and twice as long as the witness MSMs; ranks beyond the fifth get nothing."""
+    weights = {2: 3.0, 4: 2.0, 0: 1.0, 1: 1.0, 3: 1.0}
+    bins = [[0.0, 0] for _ in range(min(world, 5))]
+    for i, w in sorted(weights.items(), key=lambda kv: -kv[1]):
+        b = min(bins, key=lambda x: x[0])
+        b[0] += w
+        b[1] |= 1 << i
+    return [b[1] for b in bins] + [0] * (world - len(bins))
+
+
 class ShardedProofJob:
     def __init__(self, prover, k, rs, ss, slot=None, job=None, parts=None):
         self.prover, self.k, self.rs, self.ss, self.slot, self.job, self.parts = prover, k, rs, ss, slot, job, parts
@@ -186,12 +199,23 @@ class ShardedProver:
     points per proof; every rank then assembles the same proof bytes -- identical to the single-GPU context's.
     max_batch: proofs per pass (<= 32); the exchange buffers are sized for it."""
 
-    def __init__(self, curve, pk, process_group=None, force_collective=False, max_batch=1, ctx=None):
+    def __init__(self, curve, pk, process_group=None, force_collective=False, max_batch=1, ctx=None, placement="range"):
+        """placement: "range" (every MSM split into `world` contiguous ranges, the default and what north_star names) or "task"
+        (every MSM computed in full by ONE rank, `task_masks`): the exchange and the assembly are the same, a rank that does not
+        own an MSM contributes the point at infinity."""
         import torch.distributed as dist
         self.curve = curve
         world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        self.ctx = ctx if ctx is not None else api.ProvingContext(curve, pk, shard=(rank, world))
+        if placement not in ("range", "task"):
+            raise ValueError("placement is 'range' or 'task'")
+        self.placement = placement
+        if ctx is not None:
+            self.ctx = ctx
+        elif placement == "task":
+            self.ctx = api.ProvingContext(curve, pk, task_mask=task_masks(world)[rank])
+        else:
+            self.ctx = api.ProvingContext(curve, pk, shard=(rank, world))
         self.slot = self.ctx.partials_slot_limbs
         self.max_batch = int(max_batch)
         self.exchange = PartialPointExchange(curve, 2, process_group, force_collective=force_collective,

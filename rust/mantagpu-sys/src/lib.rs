@@ -18,6 +18,11 @@ pub const MG_ERROR_OUT_OF_MEMORY: c_int = 3;
 pub const MG_ERROR_DOMAIN_TOO_LARGE: c_int = 4;
 pub const MG_ERROR_STATE: c_int = 5;
 pub const MG_ERROR_CHECKSUM: c_int = 6;
+pub const MG_TASK_A: c_uint = 1;
+pub const MG_TASK_B_G1: c_uint = 2;
+pub const MG_TASK_B_G2: c_uint = 4;
+pub const MG_TASK_L: c_uint = 8;
+pub const MG_TASK_H: c_uint = 16;
 
 pub const MG_SCALARS_MONT: c_int = 1;
 pub const MG_SCALARS_SPARSE: c_int = 2;
@@ -232,6 +237,7 @@ extern "C" {
         out: *mut *mut mg_ctx,
     ) -> c_int;
     pub fn mg_ctx_create_shard(curve: mg_curve_t, pk: *const mg_pk_view, shard: c_int, n_shards: c_int, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_ctx_create_task(curve: mg_curve_t, pk: *const mg_pk_view, task_mask: c_uint, out: *mut *mut mg_ctx) -> c_int;
     pub fn mg_partials_slot_limbs(ctx: *const mg_ctx) -> usize;
     pub fn mg_groth16_partials_launch(
         ctx: *const mg_ctx,

@@ -136,6 +136,16 @@ for i in range(3):
     assert sp.prove(c.z, rs[2 * i], rs[2 * i + 1]) == want, i
 zs = np.stack([c.z] * 2)
 assert sp.prove_batch(zs, rs[0:2], rs[2:4]) == api.Groth16.prove_batch(ctx, zs, rs[0:2], rs[2:4])
+# task placement (SURVEY.md 8(e), last row): rank 0 computes b_g2 and b_g1, rank 1 a, l and the witness map + h; same exchange, same bytes
+assert distributed.task_masks(2) == [0b00110, 0b11001] and sorted(distributed.task_masks(8))[-5:] == [1, 2, 4, 8, 16]
+tp = distributed.ShardedProver(curve, pk, max_batch=2, placement="task")
+tp.set_r1cs(r1cs)
+for i in range(3):
+    assert tp.prove(c.z, rs[2 * i], rs[2 * i + 1]) == api.Groth16.prove_with_randomness(ctx, c.z, rs[2 * i], rs[2 * i + 1]), i
+assert tp.prove_batch(zs, rs[0:2], rs[2:4]) == api.Groth16.prove_batch(ctx, zs, rs[0:2], rs[2:4])
+import pytest
+with pytest.raises(api.MantaGpuError):      # a task context cannot prove on its own
+    api.Groth16.prove_with_randomness(tp.ctx, c.z, rs[0], rs[1])
 dist.barrier()
 print("rank", rank, "sharded proof ok")
 '''
