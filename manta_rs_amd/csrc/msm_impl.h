@@ -1220,7 +1220,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         } else {
             int lg = 0;
             while (((size_t)1 << lg) < n) ++lg;
-            int c = c_override > 0 ? c_override : (lg <= 8 ? 5 : lg <= 12 ? 8 : lg <= 15 ? 10 : lg <= 18 ? 12 : 14);
+            // (2^20 plain bases, one MSM at a time: c = 14 / 15 / 16 / 17 -> 4.98 / 4.77 / 4.48 / 5.02 ms with the front levels of the
+            // bucket reduce, which 16 windows of 32 768 buckets need: profiles/r03_plain_bases_sweep.txt)
+            int c = c_override > 0 ? c_override : (lg <= 8 ? 5 : lg <= 12 ? 8 : lg <= 15 ? 10 : lg <= 18 ? 12 : lg <= 19 ? 14 : 16);
             p.c = c;
             p.W = (FrC::BITS + 1 + c - 1) / c;
             p.Wb = p.W;
@@ -1280,10 +1282,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // front levels of the bucket reduce (serial_reduce): 2^lgS0 items per lane while a level has >= 2^18 items, 2^lgS below
-    // (MANTA_RED_S0 / MANTA_RED_S; MANTA_RED_S=0, the default: scan kernels only), applied while a window segment has at
+    // (MANTA_RED_S0 / MANTA_RED_S; MANTA_RED_S=0: scan kernels only; unset = automatic: plain bases with >= 2^19 buckets in all), applied while a window segment has at
     // least min_items items (MANTA_RED_MIN); 2^lgSP items per lane in the plain sums of the Sx arrays (MANTA_RED_SP), which
     // run on a side stream next to the weighted chain unless MANTA_RED_SIDE=0.
-    // OFF by default -- measured on MI355X, 2^20 BLS12-381 G1 (profiles/r03_window_and_tail_study.txt): with MANTA_RED_S=3 one
+    // OFF for precomputed tables -- measured on MI355X, 2^20 BLS12-381 G1 (profiles/r03_window_and_tail_study.txt): with MANTA_RED_S=3 one
     // MSM at a time gets 5 % faster at c = 16 (3.66 -> 3.48 ms) and c = 20 becomes usable (3.83 ms against 5.2 ms with the scan
     // kernels alone), but with three MSMs in flight -- the headline -- nothing is gained at c = 16 (343 against 348 Mscalar/s
     // inline, 315 with the side stream: two more streams on the runtime's four hardware queues) and c = 20 stays behind
@@ -1297,7 +1299,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     };
     static const RedKnobs &red_knobs() {
         static const RedKnobs k = [] {
-            RedKnobs r{2, 0, 3, 16384u, true};
+            RedKnobs r{2, -1, 3, 16384u, true}; // lgS = -1: automatic (below)
             auto env = [](const char *n, int lo, int hi, int dflt) {
                 const char *e = getenv(n);
                 if (!e) return dflt;
@@ -1305,7 +1307,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 return v < lo ? lo : (v > hi ? hi : v);
             };
             r.lgS0 = env("MANTA_RED_S0", 1, 8, r.lgS0);
-            r.lgS = env("MANTA_RED_S", 0, 8, r.lgS);
+            r.lgS = env("MANTA_RED_S", -1, 8, r.lgS);
             r.lgSP = env("MANTA_RED_SP", 1, 8, r.lgSP);
             r.min_items = (u32)env("MANTA_RED_MIN", 128, 1 << 30, (int)r.min_items);
             r.side = env("MANTA_RED_SIDE", 0, 1, 1) != 0;
@@ -1425,7 +1427,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // (never for the MSMs of a proof slot -- ws->in_graph_slot: their launches are captured into hipGraphs, and a pass captured
             // with the front levels in it made hipGraphLaunch segfault on ROCm 7.0, the multi-branch-graph defect described in
             // runtime.cpp; eagerly launched, the batched prover gains 2-3 % from them: profiles/r03_batched_front_levels.txt)
-            if (rk.lgS > 0 && rn >= rk.min_items && !ws->in_graph_slot) {
+            // automatic (MANTA_RED_S unset): on for plain bases with many windows of many buckets (2^20 terms: 16 windows x 32 768:
+            // 4.98 -> 4.48 ms one at a time, the same three in flight), off for precomputed tables, where c = 16 is one window of
+            // 32 768 buckets and the scan kernels are as fast (section 4.0 of DESIGN.md)
+            const int lgS_eff = rk.lgS >= 0 ? rk.lgS : ((pl.Wb > 1 && (size_t)segs * pl.B >= ((size_t)1 << 19)) ? 3 : 0);
+            if (lgS_eff > 0 && rn >= rk.min_items && !ws->in_graph_slot) {
                 if (!ws->capturing && !ws->run_on && rk.side) {
                     if (!ws->side_stream) {
                         MG_HIP(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking));
@@ -1457,7 +1463,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                     while (n >= rk.min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
                         // the big first levels are throughput-bound: short stretches = enough lanes for two wavefronts per SIMD;
                         // below that a level is a latency chain either way and longer stretches save a level
-                        const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : rk.lgS;
+                        const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : lgS_eff;
                         const u32 lanes = cdiv(n, 1u << lg);
                         u32 *A = take((size_t)segs * lanes), *Sx = take((size_t)segs * lanes);
                         if (pass) level(s, in, stride, off, n, lg, lanes, A, Sx);
