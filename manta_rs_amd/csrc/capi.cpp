@@ -280,8 +280,7 @@ MG_API int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine) {
         int rc2 = j.eng->msm_finish(j.ws, &hp);
         if (rc2) {
             hipStreamSynchronize(j.ws->stream);
-                if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
-        if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
+            if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
             j.ws->pending = 0;
         } else {
             e0->hp_add(&total, &hp);

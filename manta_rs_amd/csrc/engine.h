@@ -3,6 +3,7 @@
 // C ABI (include/mantagpu.h) can dispatch on (curve, group) at run time.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
@@ -138,7 +139,7 @@ struct MsmWorkspace {
     hipStream_t stream = nullptr;
     hipStream_t run_on = nullptr; // when set, msm_launch enqueues on this stream instead of the workspace's own
     // stand-alone MSMs: the plain sums of the bucket reduce's front levels run here, beside the weighted chain
-    hipStream_t side_stream = nullptr;
+    hipStream_t side_stream = nullptr; // the ENGINE's side stream once this workspace has used it (not owned)
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel

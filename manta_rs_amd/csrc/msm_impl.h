@@ -1282,16 +1282,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     // front levels of the bucket reduce (serial_reduce): 2^lgS0 items per lane while a level has >= 2^18 items, 2^lgS below
-    // (MANTA_RED_S0 / MANTA_RED_S; MANTA_RED_S=0: scan kernels only; unset = automatic: plain bases with >= 2^19 buckets in all), applied while a window segment has at
+    // (MANTA_RED_S0 / MANTA_RED_S; MANTA_RED_S=0: scan kernels only; unset = 3), applied while a window segment has at
     // least min_items items (MANTA_RED_MIN); 2^lgSP items per lane in the plain sums of the Sx arrays (MANTA_RED_SP), which
     // run on a side stream next to the weighted chain unless MANTA_RED_SIDE=0.
-    // OFF for precomputed tables -- measured on MI355X, 2^20 BLS12-381 G1 (profiles/r03_window_and_tail_study.txt): with MANTA_RED_S=3 one
-    // MSM at a time gets 5 % faster at c = 16 (3.66 -> 3.48 ms) and c = 20 becomes usable (3.83 ms against 5.2 ms with the scan
-    // kernels alone), but with three MSMs in flight -- the headline -- nothing is gained at c = 16 (343 against 348 Mscalar/s
-    // inline, 315 with the side stream: two more streams on the runtime's four hardware queues) and c = 20 stays behind
-    // (300-340): the accumulate kernel of c = 20 is 19 % shorter, and its reduce is eight more dependent launches of 70-220 us
-    // that cannot share a SIMD with the two resident accumulate wavefronts of the neighbouring MSMs (216-298 VGPRs each
-    // against the 192 those leave free), so they queue behind whole accumulate kernels.
+    // History (profiles/r03_window_and_tail_study.txt): the first versions -- serial chains for the plain sums, a side stream per
+    // workspace -- lost 6-9 % of the pipelined rate and were off by default; c = 20 tables (accumulate kernel 19 % shorter) still do
+    // not pay: the 2^19-bucket reduce is eight more dependent launches and a third sort pass.
     struct RedKnobs {
         int lgS0, lgS, lgSP;
         u32 min_items;
@@ -1315,6 +1311,19 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }();
         return k;
     }
+
+    hipStream_t engine_side_stream() {
+        std::lock_guard<std::mutex> g(side_mu_);
+        if (!side_stream_) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&side_stream_, hipStreamNonBlocking, hi) != hipSuccess)
+                side_stream_ = nullptr;
+        }
+        return side_stream_;
+    }
+    std::mutex side_mu_;
+    hipStream_t side_stream_ = nullptr; // process lifetime
 
     // ---------------------------------------------------------------- launch
     int msm_launch(const BaseSet *bs, const u32 *d_scalars, size_t n, int scalar_mode, int c_override,
@@ -1427,18 +1436,23 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // (never for the MSMs of a proof slot -- ws->in_graph_slot: their launches are captured into hipGraphs, and a pass captured
             // with the front levels in it made hipGraphLaunch segfault on ROCm 7.0, the multi-branch-graph defect described in
             // runtime.cpp; eagerly launched, the batched prover gains 2-3 % from them: profiles/r03_batched_front_levels.txt)
-            // automatic (MANTA_RED_S unset): on for plain bases with many windows of many buckets (2^20 terms: 16 windows x 32 768:
-            // 4.98 -> 4.48 ms one at a time, the same three in flight), off for precomputed tables, where c = 16 is one window of
-            // 32 768 buckets and the scan kernels are as fast (section 4.0 of DESIGN.md)
-            const int lgS_eff = rk.lgS >= 0 ? rk.lgS : ((pl.Wb > 1 && (size_t)segs * pl.B >= ((size_t)1 << 19)) ? 3 : 0);
+            // On by default (MANTA_RED_S unset = 3) wherever a window segment has >= min_items buckets: same box, three runs each,
+            // 2^20 BLS12-381 G1, c = 16 tables -- scan kernels only 364-367 Mscalar/s three in flight / 3.62-3.66 ms one at a time,
+            // with one front level 364-376 / 3.42-3.51; plain bases (16 windows x 32 768 buckets) 4.98 -> 4.36 ms
+            // (profiles/r03_front_levels_ab.txt). The plain sums ride on ONE high-priority side stream per engine: a side stream per
+            // workspace aliased the runtime's four normal-priority hardware queues and cost the pipelined rate 10-15 % by itself.
+            const int lgS_eff = rk.lgS >= 0 ? rk.lgS : 3;
             if (lgS_eff > 0 && rn >= rk.min_items && !ws->in_graph_slot) {
                 if (!ws->capturing && !ws->run_on && rk.side) {
-                    if (!ws->side_stream) {
-                        MG_HIP(hipStreamCreateWithFlags(&ws->side_stream, hipStreamNonBlocking));
+                    // ONE side stream per engine, high priority (= the runtime's other pool of hardware queues): a stream per
+                    // workspace put six streams on the four normal-priority queues and cost the pipelined rate 15 % through
+                    // aliasing alone, whether or not the side stream was used (measured: 308 against 365 Mscalar/s)
+                    if (!(side = engine_side_stream())) return MG_ERR_HIP;
+                    if (!ws->side_fork) {
                         MG_HIP(hipEventCreateWithFlags(&ws->side_fork, hipEventDisableTiming));
                         MG_HIP(hipEventCreateWithFlags(&ws->side_join, hipEventDisableTiming));
                     }
-                    side = ws->side_stream;
+                    ws->side_stream = side; // (for the abandon paths: they drain it; not owned by the workspace)
                 }
                 // one level: lanes of 2^lg items; cooperative additions when the level has few lanes
                 auto level = [&](hipStream_t st, const u32 *in, u32 stride, u32 off, u32 n, int lg, u32 lanes, u32 *A, u32 *Sx) {

@@ -114,7 +114,6 @@ MsmWorkspace::~MsmWorkspace() {
     if (t1) hipEventDestroy(t1);
     if (side_fork) hipEventDestroy(side_fork);
     if (side_join) hipEventDestroy(side_join);
-    if (side_stream) hipStreamDestroy(side_stream);
     if (stream) hipStreamDestroy(stream);
 }
 
