@@ -39,7 +39,7 @@ import numpy as np  # noqa: E402
 
 LOG_N = int(os.environ.get("MANTA_BENCH_LOGN", "20"))  # 20 = the BASELINE config; smaller n only for studies
 CURVE = 1  # BLS12-381
-WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "16"))
+WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "17"))  # 255 = 15 x 17: fifteen signed windows (scalars above r / 2 are negated)
 DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
 ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
@@ -317,8 +317,9 @@ def msm_bench(args, env):
         "workload": "2^%d BLS12-381 G1 variable-base MSM per GPU, uniform scalars resident in HBM" % LOG_N,
         "curve": "BLS12-381", "log_n": LOG_N, "window_bits": WINDOW_BITS, "msms_in_flight": DEPTH,
         "precomputed_base_multiples": True, "bases_hbm_bytes": inst.bases.device_bytes(),
-        "note": "headline = pipelined (%d MSMs in flight) against bases with precomputed 2^(16w) multiples (a full 2^20 "
-                "BLS12-381 key needs 5 such tables, ~10 GB of the 288 GB)" % DEPTH,
+        "windows": -(-255 // WINDOW_BITS),
+        "note": "headline = pipelined (%d MSMs in flight) against bases with precomputed 2^(%dw) multiples (a full 2^20 "
+                "BLS12-381 key needs 5 such tables, ~10 GB of the 288 GB)" % (DEPTH, WINDOW_BITS),
         "latency_mode": {"Mscalar_s": round(env.world * n * lat_steps / dt_lat / 1e6, 2), "ms_per_msm": round(dt_lat / lat_steps * 1e3, 4)},
         "plain_bases": plain,
         "other_inputs_same_size": other,
@@ -351,10 +352,13 @@ def msm_bench(args, env):
             peak_meas = mad_per_us * 1e6 * 1024 * 64 / 1e12
         except Exception as e:  # noqa: BLE001
             clock, peak_meas = {"error": str(e)}, None
-        if LOG_N == 20 and WINDOW_BITS == 16:  # ~15.06 mixed adds per scalar (16 signed 16-bit windows, top one nearly empty)
-            m = n * 15.06 * MADS_PER_MIXED_ADD
+        if LOG_N == 20 and WINDOW_BITS >= 15:
+            # modelled low: 0.941 mixed additions per (scalar, window) -- the PMC count of wave-additions per scalar-lane is 1.0 per window
+            windows = -(-255 // WINDOW_BITS)
+            adds = 15.06 / 16 * windows
+            m = n * adds * MADS_PER_MIXED_ADD
             ach = m / (k_alone * 1e-3) / 1e12
-            mads = {"mads_per_launch_modelled": int(m), "model": "15.06 mixed additions per scalar x %d multiply-adds each (PMC: 16.0 wave-additions per scalar-lane)" % MADS_PER_MIXED_ADD,
+            mads = {"mads_per_launch_modelled": int(m), "model": "%.2f mixed additions per scalar (%d windows) x %d multiply-adds each (PMC: %d.0 wave-additions per scalar-lane)" % (adds, windows, MADS_PER_MIXED_ADD, windows),
                     "achieved_Tmad_s": round(ach, 2),
                     "peak_Tmad_s": round(peak_meas, 2) if peak_meas else None, "frac": round(ach / peak_meas, 3) if peak_meas else None,
                     "peak_how": "issue rate measured in this run by mg_clock_probe (no clock assumed) x 1024 SIMDs x 64 lanes",
@@ -426,7 +430,7 @@ def strong_scaling(args, env):
     """1/2/4/8-GPU times for a FIXED n = 2^20 and a fixed n = 35 174 (the PrivateTransfer witness MSM),
     split into N contiguous ranges -- expected near-linear at 2^20, flat or worse at 35 k (launch-latency-bound)."""
     out = {}
-    for name, n_total, c in (("n_2^20", 1 << 20, 16), ("n_35174", 35174, 8)):
+    for name, n_total, c in (("n_2^20", 1 << 20, WINDOW_BITS), ("n_35174", 35174, 8)):
         inst = MsmInstance(env, n_total, c, seed=0x5354524F)
         got = inst.run(1, 1)
         assert (got == inst.expected()).all(), "strong-scaling MSM does not match the closed form"

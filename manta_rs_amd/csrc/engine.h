@@ -101,7 +101,7 @@ enum { SCALARS_CANONICAL = 0, SCALARS_MONT = 1, SCALARS_WORK = 2 };
 // Pippenger plan. Signed digits of c bits, B = 2^(c-1) buckets per bucket-window.
 struct MsmPlan {
     int c = 0;       // window bits
-    int W = 0;       // windows = ceil((scalar_bits+1)/c)
+    int W = 0;       // windows = ceil(scalar_bits / c): digits_kernel folds k > r / 2 to r - k
     u32 B = 0;       // buckets per window
     int Wb = 0;      // bucket windows: W (plain) or 1 (bases precomputed for every window)
     bool precomp = false;

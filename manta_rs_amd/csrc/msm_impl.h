@@ -96,6 +96,28 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
             for (int j = 0; j < 8; ++j) s[j] = f.v[j];
         }
     }
+    // k P = (r - k)(-P): the smaller of k and r - k is below 2^(BITS - 1), so ceil(BITS / c) signed windows hold it -- one fewer
+    // than the ceil((BITS + 1) / c) a scalar up to r - 1 needs whenever c divides BITS (BLS12-381, 255 bits: 15 windows of 17
+    // bits instead of 16). The sign of every digit flips with the scalar. (Scalars are canonical, mantagpu.h; one that is not
+    // below r is left as it is.)
+    u32 flip = 0;
+    {
+        u32 t[8], bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u64 d = (u64)FrC::P[j] - s[j] - bw;
+            t[j] = (u32)d;
+            bw = (u32)(d >> 63);
+        }
+        bool lt = false; // r - k < k
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lt = t[j] != s[j] ? t[j] < s[j] : lt;
+        if (!bw && lt) {
+            flip = 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = t[j];
+        }
+    }
     const u32 mask = (1u << c) - 1;
     // signed digit of the NEXT window (0 = nothing to add): the low c bits, then the scalar moves right by c -- eight
     // funnel shifts instead of a dynamically indexed limb pair (~90 instructions per window in selects, which made this
@@ -118,7 +140,7 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
             const u32 d = next_digit(s, carry, neg); // s = 0 without a scalar
             const size_t o = (size_t)w * n + i;
             keys[o] = d ? key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1)) : invalid;
-            vals[o] = d ? ((precomp ? ((u32)w * tstride + i) : i) | (neg << 31)) : 0;
+            vals[o] = d ? ((precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31)) : 0;
         }
         return;
     }
@@ -155,7 +177,7 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
         if (d) {
             const u32 o = base + (u32)__popcll(m & lt);
             keys[o] = key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1));
-            vals[o] = (precomp ? ((u32)w * tstride + i) : i) | (neg << 31);
+            vals[o] = (precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31);
         }
         base += (u32)__popcll(m);
     }
@@ -1144,7 +1166,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         int W = 1;
         if (pre_c > 0) {
-            W = (FrC::BITS + 1 + pre_c - 1) / pre_c;
+            W = (FrC::BITS + pre_c - 1) / pre_c; // digits_kernel: |k| < 2^(BITS - 1)
             bs->pre_c = pre_c;
             bs->pre_W = W;
         }
@@ -1224,7 +1246,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // bucket reduce, which 16 windows of 32 768 buckets need: profiles/r03_plain_bases_sweep.txt)
             int c = c_override > 0 ? c_override : (lg <= 8 ? 5 : lg <= 12 ? 8 : lg <= 15 ? 10 : lg <= 18 ? 12 : lg <= 19 ? 14 : 16);
             p.c = c;
-            p.W = (FrC::BITS + 1 + c - 1) / c;
+            p.W = (FrC::BITS + c - 1) / c;
             p.Wb = p.W;
         }
         p.B = 1u << (p.c - 1);
@@ -1358,6 +1380,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
         int end_bit = 1;
         while ((1u << end_bit) <= invalid) ++end_bit;
+        // the fixed layout marks a zero digit with the key `invalid` = one past the last bucket; where that key alone would cost
+        // the sort another 8-bit pass (2^16 buckets: c = 17 tables) the compacting digit kernel is used instead -- its second walk
+        // over the digits is a fifth of a radix pass
+        int end_bit_real = 1;
+        while (nb > 1 && (1u << end_bit_real) <= nb - 1) ++end_bit_real;
+        if ((end_bit + 7) / 8 > (end_bit_real + 7) / 8) sparse = true;
+        if (sparse) end_bit = end_bit_real; // no pair carries the invalid key there
         // zero digits are compacted away by the digit kernel; how many pairs remain is known on the device only
         u32 *d_count = nullptr;
         if (sparse && sort_pairs_takes_device_count(end_bit)) {
@@ -1436,7 +1465,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // (never for the MSMs of a proof slot -- ws->in_graph_slot: their launches are captured into hipGraphs, and a pass captured
             // with the front levels in it made hipGraphLaunch segfault on ROCm 7.0, the multi-branch-graph defect described in
             // runtime.cpp; eagerly launched, the batched prover gains 2-3 % from them: profiles/r03_batched_front_levels.txt)
-            // On by default (MANTA_RED_S unset = 3) wherever a window segment has >= min_items buckets: same box, three runs each,
+            // On by default (MANTA_RED_S unset = 8 buckets per lane, 16 from 2^16 buckets on) wherever a window segment has >= min_items buckets: same box, three runs each,
             // 2^20 BLS12-381 G1, c = 16 tables -- scan kernels only 364-367 Mscalar/s three in flight / 3.62-3.66 ms one at a time,
             // with one front level 364-376 / 3.42-3.51; plain bases (16 windows x 32 768 buckets) 4.98 -> 4.36 ms
             // (profiles/r03_front_levels_ab.txt). The plain sums ride on ONE high-priority side stream per engine: a side stream per
@@ -1477,7 +1506,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                     while (n >= rk.min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
                         // the big first levels are throughput-bound: short stretches = enough lanes for two wavefronts per SIMD;
                         // below that a level is a latency chain either way and longer stretches save a level
-                        const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : lgS_eff;
+                        // (2^16 buckets -- c = 17 tables --: 16 per lane leaves the scan kernels the 4 096 items they take at c = 16;
+                        // 8 per lane left 8 192 and a non-cooperative tile kernel of 0.36 ms: 3.65-3.79 ms one MSM at a time against
+                        // 3.44-3.50, 362-365 Mscalar/s three in flight against 371; 32: 357-368)
+                        const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : (rk.lgS < 0 && n >= (1u << 16) ? 4 : lgS_eff);
                         const u32 lanes = cdiv(n, 1u << lg);
                         u32 *A = take((size_t)segs * lanes), *Sx = take((size_t)segs * lanes);
                         if (pass) level(s, in, stride, off, n, lg, lanes, A, Sx);

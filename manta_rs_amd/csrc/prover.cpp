@@ -213,7 +213,7 @@ class ProverImpl : public Prover {
         // (B = 128: two tiles); the extra windows only add perfectly parallel mixed additions.
         if (n <= (1u << 17)) return 8;
         if (n <= (1u << 19)) return 12;
-        return 16;
+        return 17; // 255 = 15 x 17, 254 < 15 x 17: fifteen windows on both curves (digits_kernel negates scalars above r / 2)
     }
 
     // contiguous slice of an n-entry query owned by this shard

@@ -60,6 +60,27 @@ def test_msm_precomputed_tables(gpu, curve, group, c):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("curve,group,pre", [(1, 1, 17), (1, 1, 15), (1, 1, 5), (1, 2, 17), (1, 1, 0), (0, 1, 11), (0, 1, 0), (0, 2, 7)])
+def test_msm_scalars_around_half_the_group_order(gpu, curve, group, pre):
+    """The digit kernel recodes k > r / 2 as -(r - k), which is what lets a window width that divides the scalar's bit length
+    (BLS12-381: 255 = 15 x 17) do with one window fewer: the scalars where that folding switches, the largest ones, and the ones
+    whose top window is full, mixed into uniform ones -- against the oracle, table widths that divide 255 and ones that do not."""
+    n = 400
+    r = synth.FR_MODULUS[curve]
+    pts = H.random_points(curve, group, n, seed=55)
+    ks = synth.limbs_to_ints(synth.msm_scalars(curve, n, "U", seed=56))
+    bits = r.bit_length()
+    edge = [0, 1, 2, (r - 1) // 2 - 1, (r - 1) // 2, (r + 1) // 2, (r + 1) // 2 + 1, r - 2, r - 1, (1 << (bits - 1)) - 1, 1 << (bits - 1),
+            (1 << (bits - 1)) + 1, (1 << (bits - 2)) - 1, 1 << (bits - 2), r - (1 << (bits - 2)), r >> 1, (r >> 1) ^ ((1 << 200) - 1)]
+    edge = [e % r for e in edge]
+    for j, e in enumerate(edge):
+        ks[7 * j + 3] = e
+    sc = synth.ints_to_limbs(ks, 4)
+    want = O.msm(curve, group, pts, sc, algo=1)
+    got = gpu.VariableBaseMSM.multi_scalar_mul(gpu.Bases(curve, group, pts, precompute_window_bits=pre), sc)
+    assert (got == want).all()
+
+
 def test_msm_all_zero_and_all_one(gpu):
     n = 300
     pts = H.random_points(0, 1, n, seed=2)
@@ -102,7 +123,7 @@ def test_msm_medium_closed_form(gpu, curve):
         assert (got == want).all(), pre
 
 
-@pytest.mark.parametrize("curve,pre", [(1, 16), (0, 16), (1, 0)])
+@pytest.mark.parametrize("curve,pre", [(1, 16), (1, 17), (0, 16), (1, 0)])
 def test_msm_full_size_2_20_closed_form(gpu, curve, pre):
     """BASELINE size (n = 2^20), property check that needs no O(n) oracle run: bases P_i = [s0 + i s1]G built
     by the library's fixed-base batch multiply, so sum k_i P_i = [sum k_i (s0 + i s1) mod r] G. Run for uniform
