@@ -26,6 +26,7 @@
 #include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -203,14 +204,23 @@ __global__ __launch_bounds__(256) MG_ACC_ATTR void accumulate_chunks(const u32 *
                                                          u32 M, u32 L, u32 invalid, const u32 *__restrict__ bases,
                                                          u32 astride, u32 *__restrict__ buckets,
                                                          u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T,
-                                                         const u32 *__restrict__ count, unsigned long long *__restrict__ clk) {
+                                                         const u32 *__restrict__ count, unsigned long long *__restrict__ clk,
+                                                         u32 adapt) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     long long c0 = 0;
     unsigned long long w0 = 0;
     if constexpr (PROBE)
         if (t == 0) c0 = clock64(), w0 = wall_clock64();
-    if (count) M = *count; // compacted pairs: lanes past the last pair have nothing to do
+    if (count) {
+        M = *count; // compacted pairs: lanes past the last pair have nothing to do
+        // adapt: the host launched ONE round of lanes (T = what the chip holds at this kernel's occupancy) without knowing how many
+        // pairs survived the compaction; the chunk length that spreads them over exactly those lanes is only known here
+        if (adapt) {
+            const u32 l = (M + T - 1) / T;
+            L = l > L ? l : L;
+        }
+    }
     const size_t begin = (size_t)t * L;
     size_t end = begin + L;
     if (end > M) end = M;
@@ -1151,6 +1161,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 n = kept;
             }
         }
+        prime_occupancy();
         BaseSet *bs = new BaseSet();
         bs->curve = CURVE_ID;
         bs->group = GROUP;
@@ -1274,6 +1285,41 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         return p;
     }
 
+    // lanes of one full round of the accumulate kernel: what the device holds at the kernel's own occupancy (single MSMs: the
+    // shortest chain) or at two wavefronts per SIMD (batched passes: that saturates the integer pipe, and fewer lanes mean fewer
+    // partials to merge). MANTA_ACC_ROUND_WAVES = wavefronts per SIMD, 0 = off (host-side chunk length only).
+    u32 acc_round_lanes(u32 batch) {
+        static const int knob = [] {
+            const char *e = getenv("MANTA_ACC_ROUND_WAVES");
+            return e ? atoi(e) : -1;
+        }();
+        if (knob == 0) return 0;
+        const int dev = current_device();
+        if (dev < 0 || dev >= 64 || !occ_[dev].cus.load(std::memory_order_acquire)) return 0; // (primed by bases_create)
+        u32 w = occ_[dev].blocks; // 256-thread blocks per CU = wavefronts per SIMD
+        if (knob > 0) w = (u32)knob < w ? (u32)knob : w;
+        else if (batch > 1 && w > 2) w = 2;
+        return w * 256u * occ_[dev].cus.load(std::memory_order_relaxed);
+    }
+    struct Occ {
+        u32 blocks = 0;
+        std::atomic<u32> cus{0};
+    } occ_[64];
+    // (asked once per device outside any stream capture: bases_create runs before the first MSM on its device)
+    void prime_occupancy() {
+        const int dev = current_device();
+        if (dev < 0 || dev >= 64 || occ_[dev].cus.load(std::memory_order_acquire)) return;
+        int nb = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, accumulate_chunks<F, false>, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || nb < 1 || cus < 1) {
+            (void)hipGetLastError();
+            return;
+        }
+        std::lock_guard<std::mutex> g(side_mu_);
+        occ_[dev].blocks = (u32)nb;
+        occ_[dev].cus.store((u32)cus, std::memory_order_release);
+    }
+
     // few tiles = a pure latency chain: spread each addition over the workgroup's four wavefronts
     static bool coop_tiles(u32 tiles) {
         static const int lim = [] {
@@ -1394,6 +1440,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             d_count = ws->count.as<u32>();
             MG_HIP(hipMemsetAsync(d_count, 0, 4, s));
         }
+        // Compacted pairs (witness MSMs: two thirds of the digits are zero): the host sized T for all n W digits, so the pairs
+        // that remain fill an arbitrary part of it -- 1.35 rounds of wavefronts for the G2 MSM of a PrivateTransfer proof, i.e. two
+        // rounds of 6 dependent additions where one round of 9 does, and 1.4 wavefronts per SIMD for a batched pass where two
+        // balanced ones do. Launch one round of lanes and let the kernel derive the chunk length from the pair count.
+        u32 Tl = T, adapt = 0;
+        if (d_count) {
+            const u32 tgt = acc_round_lanes(batch);
+            if (tgt && Tl > tgt) Tl = tgt, adapt = 1;
+        }
         static const u32 dthreads_sparse = [] {
             const char *e = getenv("MANTA_DIGITS_THREADS");
             const int v = e ? atoi(e) : 0;
@@ -1423,15 +1478,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         else
 #endif
         if (ws->timed)
-            hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+            hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                                ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
-                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count, ws->clk.as<unsigned long long>());
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, ws->clk.as<unsigned long long>(), adapt);
         else
-            hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
+            hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                                ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
-                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), T, (const u32 *)d_count, (unsigned long long *)nullptr);
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, (unsigned long long *)nullptr, adapt);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
-        u32 cnt = 2 * T;
+        u32 cnt = 2 * Tl;
         int src = 0;
         for (int level = 0;; ++level) {
             // entries folded serially per lane: the first level is throughput-bound (as many entries as
