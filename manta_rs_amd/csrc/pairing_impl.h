@@ -118,32 +118,79 @@ template <class K> class PairingEngineT : public PairingEngine {
 
     int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                         const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) override {
-        if (!p_affine_host || !d_coeffs || !n || !out_f12_host) return MG_ERR_ARG;
+        void *h = nullptr;
+        const int rc = pairing_product_begin(p_affine_host, d_coeffs, q_affine_host, skip, n, n, &h);
+        return rc ? rc : pairing_product_end(h, nullptr, do_final_exp, out_f12_host);
+    }
+
+    // The same product in two steps: begin() starts the Miller loops of the first n_early pairs; end() takes the G1 points of
+    // the remaining ones (their G2 sides -- prepared coefficients -- were given to begin()), runs their Miller loops on a second
+    // stream next to the ones still in flight, then the product tree and the final exponentiation. A verification computes
+    // its prepared-inputs point (an MSM) between the two calls instead of in front of all three Miller loops.
+    int pairing_product_begin(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
+                              const unsigned char *skip, size_t n, size_t n_early, void **handle) override {
+        if (!p_affine_host || !d_coeffs || !n || !handle || n_early > n || !n_early) return MG_ERR_ARG;
         for (size_t i = 0; i < n; ++i)
-            if (!d_coeffs[i] && !q_affine_host) return MG_ERR_ARG;
+            if (!d_coeffs[i] && (!q_affine_host || i >= n_early)) return MG_ERR_ARG;
         // one device block and one upload: [P | Q | coefficient pointers | skip flags] then the Fq12 work arrays
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t pb = n * 2 * P::N * 4, qb = q_affine_host ? n * 2 * P::F2W * 4 : 0, cb = n * sizeof(u32 *);
         const size_t o_q = up(pb), o_c = o_q + up(qb), o_s = o_c + up(cb), in_bytes = o_s + up(n);
         const size_t o_f = in_bytes, o_g = o_f + up(n * P::F12W * 4), total = o_g + up((n / 8 + 2) * P::F12W * 4);
-        // pooled workspace (device block + pinned staging + a non-blocking stream of its own): no hipMalloc / hipFree per call --
+        // pooled workspace (device block + pinned staging + non-blocking streams of its own): no hipMalloc / hipFree per call --
         // hipFree synchronises the whole device and would stall every proof in flight on this GPU -- and nothing on stream 0
-        Ws *w = ws_get(total, in_bytes > (size_t)P::F12W * 4 ? in_bytes : (size_t)P::F12W * 4);
+        const size_t late_bytes = up((n - n_early) * 2 * P::N * 4);
+        const size_t hmain = up(in_bytes > (size_t)P::F12W * 4 ? in_bytes : (size_t)P::F12W * 4);
+        Ws *w = ws_get(total, hmain + late_bytes);
         if (!w) return MG_ERR_OOM;
         unsigned char *stage = (unsigned char *)w->h;
         std::memset(stage, 0, in_bytes);
-        std::memcpy(stage, p_affine_host, pb);
+        std::memcpy(stage, p_affine_host, n_early * 2 * P::N * 4);
         if (qb) std::memcpy(stage + o_q, q_affine_host, qb);
         std::memcpy(stage + o_c, d_coeffs, cb);
         if (skip) std::memcpy(stage + o_s, skip, n);
+        w->n = n, w->n_early = n_early, w->o_q = qb ? o_q : 0, w->o_c = o_c, w->o_s = o_s, w->o_f = o_f, w->o_g = o_g, w->h_late = hmain;
+        unsigned char *d = w->d;
+        hipError_t e = hipMemcpyAsync(d, stage, in_bytes, hipMemcpyHostToDevice, w->s);
+        if (e == hipSuccess && n_early < n) e = hipEventRecord(w->ev, w->s); // the late pairs' coefficient pointers and flags sit in the block this upload fills
+        if (e == hipSuccess)
+            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n_early), dim3(128), PW::miller_lds_bytes(), w->s, (const u32 *)d,
+                               (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
+                               n_early, (u32 *)(d + o_f));
+        if (e != hipSuccess) {
+            hipStreamSynchronize(w->s);
+            ws_put(w);
+            set_last_hip_error(e, "pairing product", __FILE__, __LINE__);
+            return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
+        }
+        *handle = w;
+        return MG_OK;
+    }
+
+    int pairing_product_end(void *handle, const u32 *p_late_affine_host, bool do_final_exp, u32 *out_f12_host) override {
+        Ws *w = (Ws *)handle;
+        if (!w) return MG_ERR_ARG;
+        const size_t n = w->n, n_late = n - w->n_early;
         unsigned char *d = w->d;
         hipStream_t st = w->s;
-        hipError_t e = hipMemcpyAsync(d, stage, in_bytes, hipMemcpyHostToDevice, st);
+        hipError_t e = hipSuccess;
+        if (n_late && (!p_late_affine_host || !out_f12_host)) e = hipErrorInvalidValue;
+        if (e == hipSuccess && n_late) {
+            const size_t off = w->n_early * 2 * P::N * 4, lb = n_late * 2 * P::N * 4;
+            std::memcpy((unsigned char *)w->h + w->h_late, p_late_affine_host, lb);
+            e = hipStreamWaitEvent(w->s2, w->ev, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(d + off, (unsigned char *)w->h + w->h_late, lb, hipMemcpyHostToDevice, w->s2);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n_late), dim3(128), PW::miller_lds_bytes(), w->s2,
+                                   (const u32 *)(d + off), (const u32 *const *)(d + w->o_c) + w->n_early, (const u32 *)nullptr,
+                                   (const unsigned char *)(d + w->o_s) + w->n_early, n_late,
+                                   (u32 *)(d + w->o_f) + w->n_early * P::F12W);
+                e = hipEventRecord(w->ev2, w->s2);
+            }
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, w->ev2, 0);
+        }
         if (e == hipSuccess) {
-            u32 *df = (u32 *)(d + o_f), *dg = (u32 *)(d + o_g);
-            hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n), dim3(128), PW::miller_lds_bytes(), st, (const u32 *)d,
-                               (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
-                               n, df);
+            u32 *df = (u32 *)(d + w->o_f), *dg = (u32 *)(d + w->o_g);
             // product tree: chunks of 8 per wavefront until one element is left
             u32 *src = df, *dst = dg;
             size_t m = n;
@@ -160,9 +207,11 @@ template <class K> class PairingEngineT : public PairingEngine {
                 src = dst;
             }
             e = hipMemcpyAsync(w->h, src, P::F12W * 4, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e == hipSuccess) std::memcpy(out_f12_host, w->h, P::F12W * 4);
         }
+        const hipError_t e2 = hipStreamSynchronize(st); // (also on the error paths: nothing of this call stays in flight)
+        if (n_late) hipStreamSynchronize(w->s2);
+        if (e == hipSuccess) e = e2;
+        if (e == hipSuccess) std::memcpy(out_f12_host, w->h, P::F12W * 4);
         ws_put(w);
         if (e != hipSuccess) {
             set_last_hip_error(e, "pairing product", __FILE__, __LINE__);
@@ -170,13 +219,21 @@ template <class K> class PairingEngineT : public PairingEngine {
         }
         return MG_OK;
     }
+    void pairing_product_abandon(void *handle) override {
+        Ws *w = (Ws *)handle;
+        if (!w) return;
+        hipStreamSynchronize(w->s);
+        ws_put(w);
+    }
 
     // ---- workspace pool (per engine = per device and curve)
     struct Ws {
         unsigned char *d = nullptr;
         void *h = nullptr;
         size_t dcap = 0, hcap = 0;
-        hipStream_t s = nullptr;
+        hipStream_t s = nullptr, s2 = nullptr; // s2: the Miller loops of pairs handed in late
+        hipEvent_t ev = nullptr, ev2 = nullptr;
+        size_t n = 0, n_early = 0, o_q = 0, o_c = 0, o_s = 0, o_f = 0, o_g = 0, h_late = 0; // the product in flight
     };
     std::mutex ws_mu_;
     std::vector<Ws *> ws_free_;
@@ -191,8 +248,11 @@ template <class K> class PairingEngineT : public PairingEngine {
         }
         if (!w) {
             w = new Ws();
-            if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess) {
-                delete w;
+            if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess ||
+                hipStreamCreateWithFlags(&w->s2, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&w->ev2, hipEventDisableTiming) != hipSuccess) {
+                delete w; // (creation failures at start-up only; the handles made so far are left to process exit)
                 return nullptr;
             }
         }

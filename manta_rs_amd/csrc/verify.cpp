@@ -325,25 +325,33 @@ template <class Curve, class K> class VerifierT : public Verifier {
         DeviceScope on_device(dev_);
         *ok = 0;
         const u64 *A = proof, *B = proof + G1L, *Cc = proof + G1L + G2L;
-        // prepared_inputs = abc[0] + sum_j input_j abc[j+1]: a P-term MSM with the scalar 1 in front
+        // e(A, B) and e(C, -delta) do not depend on the public inputs: their Miller loops start first. B is the one G2 point that
+        // is new with every proof: its line coefficients are computed next to its Miller loop
+        const u32 *cp[3] = {nullptr, d_delta_neg(), d_gamma_neg()};
+        std::vector<u64> ps(2 * G1L);
+        std::memcpy(ps.data(), A, G1L * 8);
+        std::memcpy(ps.data() + G1L, Cc, G1L * 8);
+        std::vector<u64> qs(3 * G2L, 0);
+        std::memcpy(qs.data(), B, G2L * 8);
+        unsigned char skip[3] = {(unsigned char)is_zero_limbs(B, G2L), 0, 0};
+        void *pp = nullptr;
+        int rc = pe_->pairing_product_begin((const u32 *)ps.data(), cp, (const u32 *)qs.data(), skip, 3, 2, &pp);
+        if (rc) return rc;
+        // prepared_inputs = abc[0] + sum_j input_j abc[j+1]: a P-term MSM with the scalar 1 in front, next to those loops
         std::vector<u64> sc(P_ * 4);
         HR one = HR::one();
         std::memcpy(sc.data(), one.v, 32);
         if (P_ > 1) std::memcpy(sc.data() + 4, inputs, (P_ - 1) * 32);
         HostPoint pi;
-        int rc = abc_msm(sc.data(), P_, &pi);
-        if (rc) return rc;
-        std::vector<u64> ps(3 * G1L);
-        std::memcpy(ps.data(), A, G1L * 8);
-        g1_->hp_to_affine(&pi, (u32 *)(ps.data() + G1L));
-        std::memcpy(ps.data() + 2 * G1L, Cc, G1L * 8);
-        // B is the one G2 point that is new with every proof: its line coefficients are computed next to its Miller loop
-        const u32 *cp[3] = {nullptr, d_gamma_neg(), d_delta_neg()};
-        std::vector<u64> qs(3 * G2L, 0);
-        std::memcpy(qs.data(), B, G2L * 8);
-        unsigned char skip[3] = {(unsigned char)is_zero_limbs(B, G2L), 0, 0};
+        rc = abc_msm(sc.data(), P_, &pi);
+        if (rc) {
+            pe_->pairing_product_abandon(pp);
+            return rc;
+        }
+        std::vector<u64> late(G1L);
+        g1_->hp_to_affine(&pi, (u32 *)late.data());
         std::vector<u32> out(pe_->f12_words());
-        rc = pe_->pairing_product((const u32 *)ps.data(), cp, (const u32 *)qs.data(), skip, 3, true, out.data());
+        rc = pe_->pairing_product_end(pp, (const u32 *)late.data(), true, out.data()); // + e(prepared_inputs, -gamma)
         if (rc) return rc;
         *ok = std::memcmp(out.data(), alpha_beta_.data(), out.size() * 4) == 0;
         return MG_OK;

@@ -20,6 +20,13 @@ class PairingEngine {
     // skip[i] != 0 leaves pair i out (its G2 point was infinity)
     virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                                 const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) = 0;
+    // the same in two steps: the Miller loops of the first n_early pairs start at once (P points of those only; coefficients /
+    // Q / skip of all n); end() takes the G1 points of the other pairs -- which must have prepared coefficients -- and finishes.
+    // A handle is consumed by exactly one end() or abandon().
+    virtual int pairing_product_begin(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
+                                      const unsigned char *skip, size_t n, size_t n_early, void **handle) = 0;
+    virtual int pairing_product_end(void *handle, const u32 *p_late_affine_host, bool do_final_exp, u32 *out_f12_host) = 0;
+    virtual void pairing_product_abandon(void *handle) = 0;
     // *ok = (prod_i e(P_i, Q_i) == 1): all points host affine Montgomery words, every Q_i prepared on the fly; a pair with an
     // infinity member (all-zero words) contributes 1
     virtual int product_is_one(const u32 *p_affine_host, const u32 *q_affine_host, size_t n, int *ok) = 0;

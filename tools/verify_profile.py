@@ -1,18 +1,23 @@
-"""dev tool: a few single Groth16 verifications + one batch of 64 (for rocprofv3 --kernel-trace --stats)."""
+"""dev tool: single verifications of a PrivateTransfer-shape proof (for rocprofv3 --kernel-trace; prints ms per verification)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench
-ps = bench.ProveSetup("to_private")
-api = ps.api
-proofs = ps.run(64, 1, 32)
-vctx = api.VerifyingContext(ps.curve, ps.pk)
-inputs = ps.c.z[1:ps.c.P]
-pts = [api.proof_decode(ps.curve, p) for p in proofs]
-assert api.groth16_verify(vctx, inputs, pts[0])
+from manta_rs_amd import api, synth, keygen
+api.init(0)
+curve = 0
+p = synth.FR_MODULUS[curve]
+c = synth.make_shape(curve, "private_transfer")
+rng = synth.XorShift(5)
+pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
+ctx = api.ProvingContext(curve, pk)
+ctx.set_r1cs(api.R1CS.from_circuit(c))
+rs = synth.to_mont([rng.field(p) for _ in range(2)], p, 4)
+proof = api.proof_decode(curve, api.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]))
+vctx = api.VerifyingContext(curve, pk)
+inputs = c.z[1:c.P]
+for _ in range(3):
+    assert api.groth16_verify(vctx, inputs, proof)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 t = time.perf_counter()
-for i in range(5): assert api.groth16_verify(vctx, inputs, pts[i])
-print(f"single verify: {(time.perf_counter()-t)/5*1e3:.2f} ms")
-import numpy as np
-t = time.perf_counter()
-assert api.groth16_verify_batch(vctx, np.stack([inputs] * 64), pts, np.arange(1, 129, dtype=np.uint64).reshape(64, 2))
-print(f"batch of 64: {(time.perf_counter()-t)*1e3:.2f} ms")
+for _ in range(N):
+    api.groth16_verify(vctx, inputs, proof)
+print(f"verify: {(time.perf_counter()-t)/N*1e3:.3f} ms")
