@@ -92,7 +92,10 @@ int mg_last_prove_phases_ms(float out10[10]);
  *      from manta-crypto/src/arkworks/groth16.rs:597) ------------------------------------------------ */
 /* Register `n` affine points (host pointer, or device pointer if on_device). group = 1 (G1) or 2 (G2).
  * precompute_window_bits > 0 additionally stores 2^(c*w)*P for every window (HBM for speed: all
- * windows then share one bucket set and no doubling chain remains); 0 = plain bases. */
+ * windows then share one bucket set and no doubling chain remains); 0 = plain bases;
+ * -12 .. -2 = FULL tables of window width c = -precompute_window_bits: every multiple m*2^(c*w)*P, m = 1 .. 2^(c-1), so
+ * that a signed digit addresses its summand and the MSM is one plain sum (no buckets, no sort, no bucket reduce) --
+ * ceil(bits/c) * 2^(c-1) points per base, fewer than 2^31 in all, for fixed proving-key queries of proof size. */
 int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine_mont, size_t n, int on_device,
                     int precompute_window_bits, mg_bases **out);
 /* The same vector range-sharded over a list of devices ("MSM shards by scalar/base

@@ -130,7 +130,7 @@ static void bases_free(mg_bases *b) {
 }
 static int bases_create_on(mg_curve_t curve, int group, const uint64_t *affine, size_t n, int on_device, int pre_c,
                            const int *devices, int n_devices, mg_bases **out) {
-    if (!out || !affine || n == 0 || pre_c < 0 || pre_c > 24 || n_devices < 1 || n_devices > 64 || (size_t)n_devices > n)
+    if (!out || !affine || n == 0 || pre_c < -12 || pre_c == -1 || pre_c > 24 || n_devices < 1 || n_devices > 64 || (size_t)n_devices > n)
         return MG_ERROR_INVALID_ARGUMENT;
     if (on_device && n_devices != 1) return MG_ERROR_INVALID_ARGUMENT; // a device pointer belongs to one device
     int count = 0;

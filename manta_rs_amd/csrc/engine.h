@@ -105,6 +105,7 @@ struct MsmPlan {
     u32 B = 0;       // buckets per window
     int Wb = 0;      // bucket windows: W (plain) or 1 (bases precomputed for every window)
     bool precomp = false;
+    bool full = false; // every multiple 1..B of every window tabulated: digits address table entries, no buckets
     u32 L = 0;       // sorted entries per thread in the chunk-accumulate kernel
 };
 
@@ -117,6 +118,7 @@ struct BaseSet {
     u32 *d_map = nullptr; // compacted sets: stored point i belongs to scalar d_map[i]; nullptr = identity
     u32 *d_pts = nullptr; // affine AoS; with precompute: W tables of n points, table w = 2^(c w) * P
     int pre_c = 0, pre_W = 0; // 0 = no precompute
+    bool full = false;        // with precompute: the B = 2^(c-1) multiples m 2^(c w) P of every window too, entry ((w n + i) B + m - 1)
     size_t bytes = 0;
 };
 
@@ -168,6 +170,7 @@ class GroupEngine {
     virtual int affine_words() const = 0; // u32 per affine point
     virtual int xyzz_words() const = 0;
     virtual int scalar_bits() const = 0;
+    virtual int base_record_bytes() const = 0; // HBM bytes of one stored base point (internal affine record, padded)
 
     // bases: affine Montgomery AoS (host or device pointer). precompute_c > 0 builds 2^(c w) tables.
     // drop_infinity (host sources only): points at infinity are removed from the stored set (proving-key

@@ -140,8 +140,8 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
         for (int w = 0; w < W; ++w) {
             const u32 d = next_digit(s, carry, neg); // s = 0 without a scalar
             const size_t o = (size_t)w * n + i;
-            keys[o] = d ? key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1)) : invalid;
-            vals[o] = d ? ((precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31)) : 0;
+            keys[o] = d ? key0 + (precomp == 2 ? 0u : precomp ? (d - 1) : ((u32)w * B + d - 1)) : invalid;
+            vals[o] = d ? ((precomp == 2 ? ((u32)w * tstride + i) * B + (d - 1) : precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31)) : 0;
         }
         return;
     }
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
         const unsigned long long m = __ballot(d != 0);
         if (d) {
             const u32 o = base + (u32)__popcll(m & lt);
-            keys[o] = key0 + (precomp ? (d - 1) : ((u32)w * B + d - 1));
-            vals[o] = (precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31);
+            keys[o] = key0 + (precomp == 2 ? 0u : precomp ? (d - 1) : ((u32)w * B + d - 1));
+            vals[o] = (precomp == 2 ? ((u32)w * tstride + i) * B + (d - 1) : precomp ? ((u32)w * tstride + i) : i) | ((neg ^ flip) << 31);
         }
         base += (u32)__popcll(m);
     }
@@ -816,6 +816,20 @@ __global__ __launch_bounds__(256) void precompute_chain(const u32 *__restrict__ 
         p.store(xyzz_out + ((size_t)(w - 1) * n + i) * XYZZ<F>::WORDS);
     }
 }
+// full tables: the multiples m Q, m = 1 .. B, of `cnt` window bases Q = 2^(c w) P (affine, from entry j0 on) as XYZZ points,
+// entry (t B + m - 1) -- B - 1 mixed additions per lane (the first is the doubling Q + Q: madd's exact exceptional cases)
+template <class F>
+__global__ __launch_bounds__(256) void full_table_chain(const u32 *__restrict__ win, u32 astride, size_t j0, u32 cnt, u32 B,
+                                                        u32 *__restrict__ xyzz_out) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= cnt) return;
+    const Affine<F> q = Affine<F>::load(win + (j0 + t) * astride);
+    XYZZ<F> acc = XYZZ<F>::from_affine(q);
+    for (u32 m = 0; m < B; ++m) {
+        if (m) acc.madd(q, false);
+        acc.store(xyzz_out + ((size_t)t * B + m) * XYZZ<F>::WORDS);
+    }
+}
 template <class F> struct FieldInv; // Fermat inversion on the device (slow, one-off use only)
 template <class C> struct FieldInv<Fp<C>> {
     static __device__ Fp<C> inv(const Fp<C> &a) { return Fp<C>::inv(a); }
@@ -1101,6 +1115,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     int affine_words() const override { return AW_IO; }
     int xyzz_words() const override { return XW_IO; }
     int scalar_bits() const override { return FrC::BITS; }
+    int base_record_bytes() const override { return AWS * 4; }
     int point_bytes(bool compressed) const override { return compressed ? HF::BYTES : 2 * HF::BYTES; }
 
     static HP &hp(HostPoint *p) { return *reinterpret_cast<HP *>(p); }
@@ -1175,21 +1190,40 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 return MG_ERR_OOM;
             }
         }
+        // pre_c < 0: FULL tables of window width -pre_c -- besides 2^(c w) P every multiple m 2^(c w) P, m = 1 .. 2^(c-1), so that
+        // a signed digit addresses its summand directly and the MSM is one plain sum: no buckets, no sort, no bucket reduce
+        const bool full = pre_c < 0;
+        if (full) pre_c = -pre_c;
         int W = 1;
         if (pre_c > 0) {
             W = (FrC::BITS + pre_c - 1) / pre_c; // digits_kernel: |k| < 2^(BITS - 1)
             bs->pre_c = pre_c;
             bs->pre_W = W;
+            bs->full = full;
         }
-        bs->bytes = (size_t)W * n * AWS * 4;
+        const u32 FB = full ? 1u << (pre_c - 1) : 1u; // table entries per (window, base)
+        if (full && (pre_c < 2 || pre_c > 12 || (size_t)W * n * FB >= ((size_t)1 << 31))) {
+            bases_destroy(bs);
+            return MG_ERR_ARG;
+        }
+        bs->bytes = (size_t)W * n * FB * AWS * 4;
         hipError_t e = hipMalloc((void **)&bs->d_pts, bs->bytes);
+        u32 *win_pts = nullptr; // full: the window tables are an intermediate, freed below
+        if (e == hipSuccess && full) e = hipMalloc((void **)&win_pts, (size_t)W * n * AWS * 4);
         if (e != hipSuccess) {
-            delete bs;
+            bases_destroy(bs);
             set_last_hip_error(e, "hipMalloc(bases)", __FILE__, __LINE__);
             return MG_ERR_OOM;
         }
+        struct FreeWin {
+            u32 *&p;
+            ~FreeWin() {
+                if (p) hipFree(p);
+            }
+        } free_win{win_pts};
+        u32 *const dst = full ? win_pts : bs->d_pts;
         if (SAME) {
-            e = hipMemcpy(bs->d_pts, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+            e = hipMemcpy(dst, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
         } else { // convert arkworks limbs -> internal representation on the device
             u32 *stage = nullptr;
             const u32 *src = pts;
@@ -1200,7 +1234,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 src = stage;
             }
             if (e == hipSuccess) {
-                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, bs->d_pts, (u32)AWS);
+                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, dst, (u32)AWS);
                 e = hipDeviceSynchronize();
             }
             if (stage) hipFree(stage);
@@ -1219,17 +1253,43 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 set_last_hip_error(e, "hipMalloc(precompute tmp)", __FILE__, __LINE__);
                 return MG_ERR_OOM;
             }
-            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, bs->d_pts, (u32)AWS, (u32)n,
+            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, dst, (u32)AWS, (u32)n,
                                pre_c, W, tmp);
             constexpr int KB = 16;
             hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(cnt, KB), 256)), dim3(256), 0, 0, tmp,
-                               cnt, bs->d_pts + n * AWS, (u32)AWS);
+                               cnt, dst + n * AWS, (u32)AWS);
             e = hipDeviceSynchronize();
             hipFree(tmp);
             if (e != hipSuccess) {
                 bases_destroy(bs);
                 set_last_hip_error(e, "precompute kernels", __FILE__, __LINE__);
                 return MG_ERR_HIP;
+            }
+        }
+        if (full) { // expand the window tables, a slice of (window, base) pairs at a time (<= 512 MB of XYZZ points in flight)
+            u32 *const final_pts = bs->d_pts;
+            const size_t pairs = (size_t)W * n;
+            size_t slice = ((size_t)512 << 20) / ((size_t)FB * XW * 4);
+            if (slice < 256) slice = 256;
+            if (slice > pairs) slice = pairs;
+            u32 *tmp = nullptr;
+            e = hipMalloc((void **)&tmp, slice * FB * XW * 4);
+            constexpr int KBF = 64; // one Fermat inversion per 64 points
+            for (size_t j0 = 0; e == hipSuccess && j0 < pairs; j0 += slice) {
+                const size_t cntp = pairs - j0 < slice ? pairs - j0 : slice;
+                hipLaunchKernelGGL((full_table_chain<F>), dim3(cdiv(cntp, 256)), dim3(256), 0, 0, win_pts, (u32)AWS, j0, (u32)cntp, FB,
+                                   tmp);
+                hipLaunchKernelGGL((xyzz_to_affine_batch<F, KBF>), dim3(cdiv(cdiv(cntp * FB, KBF), 256)), dim3(256), 0, 0, tmp,
+                                   cntp * FB, final_pts + j0 * FB * AWS, (u32)AWS);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            else (void)hipDeviceSynchronize();
+            if (tmp) hipFree(tmp);
+            if (e != hipSuccess) {
+                bases_destroy(bs);
+                set_last_hip_error(e, "full-table kernels", __FILE__, __LINE__);
+                return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;
             }
         }
         *out = bs;
@@ -1249,6 +1309,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             p.c = bs->pre_c;
             p.W = bs->pre_W;
             p.precomp = true;
+            p.full = bs->full;
             p.Wb = 1;
         } else {
             int lg = 0;
@@ -1403,8 +1464,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         const MsmPlan pl = plan_for(bs, n, c_override, batch);
         hipStream_t s = ws->run_on ? ws->run_on : ws->stream;
         const size_t M = n * (size_t)pl.W * batch;
-        if (M >= (1ull << 31) || (size_t)batch * pl.Wb * pl.B >= (1ull << 24)) return MG_ERR_ARG;
-        const u32 seg_keys = (u32)pl.Wb * pl.B; // bucket keys per scalar vector
+        // full tables: a digit addresses its summand, every pair of a scalar vector carries the same key and the "bucket" is the result
+        const u32 KB = pl.full ? 1u : pl.B; // bucket keys per bucket window
+        if (M >= (1ull << 31) || (size_t)batch * pl.Wb * KB >= (1ull << 24)) return MG_ERR_ARG;
+        if (pl.full) sparse = true; // compacting digit kernel: no invalid keys, so a single MSM needs no sort at all
+        const u32 seg_keys = (u32)pl.Wb * KB; // bucket keys per scalar vector
         const u32 nb = batch * seg_keys;        // real buckets; key nb = INVALID
         const u32 invalid = nb;
         int rc;
@@ -1423,7 +1487,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             return rc;
 
         // with precomputed tables the base index is w*stride + i: table w starts bs->n points after w-1
-        if ((size_t)pl.W * bs->n >= (1ull << 31)) return MG_ERR_ARG;
+        if ((size_t)pl.W * bs->n * (pl.full ? pl.B : 1u) >= (1ull << 31)) return MG_ERR_ARG;
         int end_bit = 1;
         while ((1u << end_bit) <= invalid) ++end_bit;
         // the fixed layout marks a zero digit with the key `invalid` = one past the last bucket; where that key alone would cost
@@ -1456,11 +1520,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }();
         const u32 dthreads = d_count ? dthreads_sparse : 256u; // compacting path: fewer, larger workgroups = fewer atomics on the counter
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, dthreads), batch), dim3(dthreads), 0, s, d_scalars, (u32)n, pl.c, pl.W,
-                           pl.B, pl.precomp ? 1 : 0, (u32)bs->n, scalar_mode, invalid,
+                           pl.B, pl.full ? 2 : (pl.precomp ? 1 : 0), (u32)bs->n, scalar_mode, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
                            scalar_stride_words, seg_keys, d_count);
-        if ((rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
-                             ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
+        // one key in all (a single MSM on full tables, pairs compacted): any order is sorted
+        const bool no_sort = nb == 1 && d_count;
+        const u32 *skeys = no_sort ? ws->keys_in.as<u32>() : ws->keys_out.as<u32>();
+        const u32 *svals = no_sort ? ws->vals_in.as<u32>() : ws->vals_out.as<u32>();
+        if (!no_sort && (rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
+                                         ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
             return rc;
         MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
         ws->timed = kernel_timing() && !ws->capturing;
@@ -1478,12 +1546,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         else
 #endif
         if (ws->timed)
-            hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
-                               ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+            hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
+                               svals, (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                                ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, ws->clk.as<unsigned long long>(), adapt);
         else
-            hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
-                               ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+            hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
+                               svals, (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                                ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, (unsigned long long *)nullptr, adapt);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * Tl;
@@ -1512,7 +1580,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // what the scan kernels below reduce: (array, points per segment, first item, items); the front levels replace
         // the bucket array by their A arrays
         const u32 *rin = ws->buckets.as<u32>();
-        u32 rstride = pl.B, roff = 0, rn = pl.B, tail_shift = 0, n_extra = 0;
+        u32 rstride = KB, roff = 0, rn = KB, tail_shift = 0, n_extra = 0;
         u32 extra_shift[MsmWorkspace::MAX_EXTRA] = {};
         hipStream_t side = nullptr; // plain sums of the front levels run beside the weighted chain (stand-alone MSMs)
         {
@@ -1614,7 +1682,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         constexpr int XWM = XW > XW_IO ? XW : XW_IO;
         if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
-            if (coop_tiles(segs))
+            if (coop_tiles(segs) && rn > 1) // (rn = 1, full tables: the scan kernel has no addition to make, it converts the point)
                 hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, s, rin, rstride, roff, rn, 1u,
                                    ws->redA.as<u32>(), ws->redS.as<u32>(), 1);
             else

@@ -158,6 +158,9 @@ class ProverImpl : public Prover {
     // the z queries again with 10-bit windows for batched passes (fewer mixed additions; single proofs want the
     // short bucket reduce of narrow windows, above all on the G2 chain); nullptr: same as the narrow set
     BaseSet *a_bs_wide_ = nullptr, *b1_bs_wide_ = nullptr, *b2_bs_wide_ = nullptr, *l_bs_wide_ = nullptr;
+    // the five queries once more as FULL tables (every multiple of every window: the MSM is one plain sum), for passes of ONE
+    // proof -- their latency chain loses the sort, the merge into buckets and the bucket reduce; nullptr: bucket tables
+    BaseSet *a_bs_full_ = nullptr, *b1_bs_full_ = nullptr, *b2_bs_full_ = nullptr, *l_bs_full_ = nullptr, *h_bs_full_ = nullptr;
     HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
     HostPoint a0_alpha_, b10_beta_, b20_beta_; // constant terms of g_a, g1_b, g2_b folded once
     void *delta1_tab_ = nullptr, *delta2_tab_ = nullptr; // fixed-base tables for r*delta, s*delta, rs*delta
@@ -183,6 +186,11 @@ class ProverImpl : public Prover {
         if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
         if (l_bs_) g1_->bases_destroy(l_bs_);
         if (b2_bs_) g2_->bases_destroy(b2_bs_);
+        if (a_bs_full_) g1_->bases_destroy(a_bs_full_);
+        if (b1_bs_full_) g1_->bases_destroy(b1_bs_full_);
+        if (l_bs_full_) g1_->bases_destroy(l_bs_full_);
+        if (h_bs_full_) g1_->bases_destroy(h_bs_full_);
+        if (b2_bs_full_) g2_->bases_destroy(b2_bs_full_);
         if (a_bs_wide_) g1_->bases_destroy(a_bs_wide_);
         if (b1_bs_wide_) g1_->bases_destroy(b1_bs_wide_);
         if (l_bs_wide_) g1_->bases_destroy(l_bs_wide_);
@@ -214,6 +222,29 @@ class ProverImpl : public Prover {
         if (n <= (1u << 17)) return 8;
         if (n <= (1u << 19)) return 12;
         return 17; // 255 = 15 x 17, 254 < 15 x 17: fifteen windows on both curves (digits_kernel negates scalars above r / 2)
+    }
+
+    // FULL tables for the queries single proofs run on (mg_bases_create with a negative width: every multiple of every window
+    // tabulated, the MSM is one plain sum -- no sort, no merge into buckets, no bucket reduce on the latency chain of a proof):
+    // the widest window whose table fits the budget per query. MANTA_FULL_TABLE_GB (default 12; 0 = bucket tables only),
+    // MANTA_FULL_C = fixed width. Returns the (negative) width argument, or 0.
+    static int full_c_for(GroupEngine *g, u64 n) {
+        static const double budget = [] {
+            const char *e = std::getenv("MANTA_FULL_TABLE_GB");
+            return e ? std::atof(e) : 12.0;
+        }();
+        static const int fixed = [] {
+            const char *e = std::getenv("MANTA_FULL_C");
+            const int v = e ? std::atoi(e) : 0;
+            return v >= 2 && v <= 12 ? v : 0;
+        }();
+        if (budget <= 0 || n == 0) return 0;
+        for (int c = fixed ? fixed : 8; c >= (fixed ? fixed : 4); --c) {
+            const u64 per = (u64)((g->scalar_bits() + c - 1) / c) << (c - 1);
+            if (per * n >= ((u64)1 << 31)) continue;
+            if ((double)(per * n) * g->base_record_bytes() <= budget * 1e9) return -c;
+        }
+        return 0;
     }
 
     // contiguous slice of an n-entry query owned by this shard
@@ -261,6 +292,9 @@ class ProverImpl : public Prover {
         const u32 *aq = (const u32 *)pk->a_query + (1 + zlo) * w1, *b1q = (const u32 *)pk->b_g1_query + (1 + zlo) * w1;
         const u32 *b2q = (const u32 *)pk->b_g2_query + (1 + zlo) * w2, *lq = (const u32 *)pk->l_query + llo * w1;
         const int c_z = pre_c_for(V_ - 1);
+        const bool proof_sized = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
+        const int f_z1 = proof_sized ? full_c_for(g1_, zn) : 0, f_z2 = proof_sized ? full_c_for(g2_, zn) : 0;
+        const int f_l = proof_sized ? full_c_for(g1_, ln) : 0;
         if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
         if ((rc = g1_->bases_create(b1q, zn, false, c_z, &b1_bs_, true))) return rc;
         // The G2 MSM is the latency-critical chain of a single proof: 6-bit windows (32 buckets: one tile, no second
@@ -270,6 +304,10 @@ class ProverImpl : public Prover {
         const int c_g2 = small ? 6 : c_z;
         if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
         if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
+        if (f_z1 && (rc = g1_->bases_create(aq, zn, false, f_z1, &a_bs_full_, true))) return rc;
+        if (f_z1 && (rc = g1_->bases_create(b1q, zn, false, f_z1, &b1_bs_full_, true))) return rc;
+        if (f_z2 && (rc = g2_->bases_create(b2q, zn, false, f_z2, &b2_bs_full_, true))) return rc;
+        if (f_l && (rc = g1_->bases_create(lq, ln, false, f_l, &l_bs_full_, true))) return rc;
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
             int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
             if (const char *e = std::getenv("MANTA_PROVE_CW")) cw = std::atoi(e) >= 6 && std::atoi(e) <= 16 ? std::atoi(e) : cw; // tuning override
@@ -317,7 +355,7 @@ class ProverImpl : public Prover {
     // over: a proof never runs with some shards on the new matrices and others on the old.
     struct StagedR1cs {
         DevCsr A, B, C;
-        BaseSet *h = nullptr, *h_wide = nullptr;
+        BaseSet *h = nullptr, *h_wide = nullptr, *h_full = nullptr;
         bool new_domain = false;
         unsigned lg = 0;
         u64 m = 0;
@@ -354,7 +392,8 @@ class ProverImpl : public Prover {
         free_csr(st.A), free_csr(st.B), free_csr(st.C);
         if (st.h) g1_->bases_destroy(st.h);
         if (st.h_wide) g1_->bases_destroy(st.h_wide);
-        st.h = st.h_wide = nullptr;
+        if (st.h_full) g1_->bases_destroy(st.h_full);
+        st.h = st.h_wide = st.h_full = nullptr;
     }
     // phase 1 on this shard: nothing visible to a proof is touched
     int stage_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, StagedR1cs &st) {
@@ -389,8 +428,10 @@ class ProverImpl : public Prover {
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
             if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
+            const int f_h = lg <= 17 && !std::getenv("MANTA_PROVE_CH") ? full_c_for(g1_, hi - lo) : 0;
             rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &st.h);
             if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &st.h_wide);
+            if (!rc && f_h) rc = g1_->bases_create(perm.data(), hi - lo, false, f_h, &st.h_full);
             if (rc) return rc;
         }
         return MG_OK;
@@ -405,8 +446,9 @@ class ProverImpl : public Prover {
         if (st.new_domain) {
             if (h_bs_) g1_->bases_destroy(h_bs_);
             if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
-            h_bs_ = st.h, h_bs_wide_ = st.h_wide;
-            st.h = st.h_wide = nullptr;
+            if (h_bs_full_) g1_->bases_destroy(h_bs_full_);
+            h_bs_ = st.h, h_bs_wide_ = st.h_wide, h_bs_full_ = st.h_full;
+            st.h = st.h_wide = st.h_full = nullptr;
         }
         // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them (slots of
         // another generation that are still in flight cannot exist -- the exclusive locks waited for them)
@@ -605,9 +647,10 @@ class ProverImpl : public Prover {
         const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
         const size_t hlo = shard_lo(D), hn = shard_hi(D) - hlo;
         const u32 *sz = dz + (1 + zlo) * 8;
-        return MsmArgs{{wide && a_bs_wide_ ? a_bs_wide_ : a_bs_, wide && b1_bs_wide_ ? b1_bs_wide_ : b1_bs_,
-                        wide && b2_bs_wide_ ? b2_bs_wide_ : b2_bs_, wide && l_bs_wide_ ? l_bs_wide_ : l_bs_,
-                        wide && h_bs_wide_ ? h_bs_wide_ : h_bs_},
+        const bool one = w->k == 1; // a single proof: full tables where the key has them
+        auto pick = [&](BaseSet *full, BaseSet *wd, BaseSet *narrow) { return one && full ? full : (wide && wd ? wd : narrow); };
+        return MsmArgs{{pick(a_bs_full_, a_bs_wide_, a_bs_), pick(b1_bs_full_, b1_bs_wide_, b1_bs_), pick(b2_bs_full_, b2_bs_wide_, b2_bs_),
+                        pick(l_bs_full_, l_bs_wide_, l_bs_), pick(h_bs_full_, h_bs_wide_, h_bs_)},
                        {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * (size_t)fr_->work_words()},
                        {zn, zn, zn, ln, hn},
                        {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * (size_t)fr_->work_words()}};

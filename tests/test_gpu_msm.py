@@ -81,6 +81,34 @@ def test_msm_scalars_around_half_the_group_order(gpu, curve, group, pre):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("curve,group,c", [(0, 1, 8), (0, 1, 3), (0, 2, 6), (1, 1, 5), (1, 1, 7), (1, 2, 4), (0, 1, 2)])
+def test_msm_full_tables(gpu, curve, group, c):
+    """precompute_window_bits = -c: every multiple m 2^(cw) P of every window is tabulated, a signed digit addresses its
+    summand, the MSM is one plain sum (no buckets, no sort, no bucket reduce). Against the oracle: uniform and witness-like
+    scalars, infinity bases, repeated bases, P + (-P), the scalars around r / 2 and the largest ones, a digit equal to 2^(c-1)."""
+    n = 700
+    r = synth.FR_MODULUS[curve]
+    pts = H.random_points(curve, group, n, seed=61)
+    pts[3] = 0
+    pts[44] = 0
+    pts[40] = pts[41]
+    b = gpu.Bases(curve, group, pts, precompute_window_bits=-c)
+    for dist in ("U", "W"):
+        ks = synth.limbs_to_ints(synth.msm_scalars(curve, n, dist, seed=62))
+        edge = [0, 1, (r - 1) // 2, (r + 1) // 2, r - 1, r - 2, 1 << (c - 1), (1 << (c - 1)) + 1, (1 << c) - 1, 1 << c,
+                ((1 << (c - 1)) << c) | (1 << (c - 1)), r - (1 << (c - 1))]
+        for j, e in enumerate(edge):
+            ks[11 * j + 5] = e % r
+        ks[40], ks[41] = 5, r - 5
+        sc = synth.ints_to_limbs(ks, 4)
+        want = O.msm(curve, group, pts, sc, algo=1)
+        assert (gpu.VariableBaseMSM.multi_scalar_mul(b, sc) == want).all(), dist
+        dsc = gpu.DeviceBuffer.from_numpy(sc)
+        assert (gpu.VariableBaseMSM.launch(b, dsc, n, sparse=True).finish() == want).all(), dist
+    z = np.zeros((n, 4), dtype=np.uint64)
+    assert not gpu.VariableBaseMSM.multi_scalar_mul(b, z).any()
+
+
 def test_msm_all_zero_and_all_one(gpu):
     n = 300
     pts = H.random_points(0, 1, n, seed=2)
