@@ -226,12 +226,12 @@ class ProverImpl : public Prover {
 
     // FULL tables for the queries single proofs run on (mg_bases_create with a negative width: every multiple of every window
     // tabulated, the MSM is one plain sum -- no sort, no merge into buckets, no bucket reduce on the latency chain of a proof):
-    // the widest window whose table fits the budget per query. MANTA_FULL_TABLE_GB (default 12; 0 = bucket tables only),
+    // the widest window whose table fits the budget per query. MANTA_FULL_TABLE_GB (default 24: ~80 GB of the 288 for a PrivateTransfer key; 0 = bucket tables only),
     // MANTA_FULL_C = fixed width. Returns the (negative) width argument, or 0.
     static int full_c_for(GroupEngine *g, u64 n) {
         static const double budget = [] {
             const char *e = std::getenv("MANTA_FULL_TABLE_GB");
-            return e ? std::atof(e) : 12.0;
+            return e ? std::atof(e) : 24.0;
         }();
         static const int fixed = [] {
             const char *e = std::getenv("MANTA_FULL_C");
@@ -239,10 +239,15 @@ class ProverImpl : public Prover {
             return v >= 2 && v <= 12 ? v : 0;
         }();
         if (budget <= 0 || n == 0) return 0;
+        // never more than a twelfth of what is free now per query (five queries: well under half of it), so that a second and a
+        // third context on the same device get narrower tables instead of an allocation failure
+        size_t free_b = 0, total_b = 0;
+        double cap = budget * 1e9;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 12.0 < cap) cap = (double)free_b / 12.0;
         for (int c = fixed ? fixed : 8; c >= (fixed ? fixed : 4); --c) {
             const u64 per = (u64)((g->scalar_bits() + c - 1) / c) << (c - 1);
             if (per * n >= ((u64)1 << 31)) continue;
-            if ((double)(per * n) * g->base_record_bytes() <= budget * 1e9) return -c;
+            if ((double)(per * n) * g->base_record_bytes() <= cap) return -c;
         }
         return 0;
     }
@@ -304,10 +309,21 @@ class ProverImpl : public Prover {
         const int c_g2 = small ? 6 : c_z;
         if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
         if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
-        if (f_z1 && (rc = g1_->bases_create(aq, zn, false, f_z1, &a_bs_full_, true))) return rc;
-        if (f_z1 && (rc = g1_->bases_create(b1q, zn, false, f_z1, &b1_bs_full_, true))) return rc;
-        if (f_z2 && (rc = g2_->bases_create(b2q, zn, false, f_z2, &b2_bs_full_, true))) return rc;
-        if (f_l && (rc = g1_->bases_create(lq, ln, false, f_l, &l_bs_full_, true))) return rc;
+        // (an optimisation: a table that does not fit any more is left out, the bucket tables above serve its MSM)
+        auto try_full = [&](GroupEngine *g, const u32 *q, size_t cnt, int f, BaseSet **dst) -> int {
+            if (!f) return MG_OK;
+            const int r = g->bases_create(q, cnt, false, f, dst, true);
+            if (r == MG_ERR_OOM) {
+                *dst = nullptr;
+                (void)hipGetLastError();
+                return MG_OK;
+            }
+            return r;
+        };
+        if ((rc = try_full(g2_, b2q, zn, f_z2, &b2_bs_full_))) return rc; // the G2 chain first: the longest of a proof
+        if ((rc = try_full(g1_, aq, zn, f_z1, &a_bs_full_))) return rc;
+        if ((rc = try_full(g1_, b1q, zn, f_z1, &b1_bs_full_))) return rc;
+        if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
             int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
             if (const char *e = std::getenv("MANTA_PROVE_CW")) cw = std::atoi(e) >= 6 && std::atoi(e) <= 16 ? std::atoi(e) : cw; // tuning override
@@ -431,7 +447,10 @@ class ProverImpl : public Prover {
             const int f_h = lg <= 17 && !std::getenv("MANTA_PROVE_CH") ? full_c_for(g1_, hi - lo) : 0;
             rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &st.h);
             if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &st.h_wide);
-            if (!rc && f_h) rc = g1_->bases_create(perm.data(), hi - lo, false, f_h, &st.h_full);
+            if (!rc && f_h && g1_->bases_create(perm.data(), hi - lo, false, f_h, &st.h_full) != MG_OK) {
+                st.h_full = nullptr; // optional: the bucket tables serve
+                (void)hipGetLastError();
+            }
             if (rc) return rc;
         }
         return MG_OK;
