@@ -803,6 +803,13 @@ def prove_bench(args, env, shape="private_transfer", full=True):
            "workload": f"Groth16 prove, shape-exact synthetic {shape} circuit (D={D}, V={V}, P={P}), BN254, valid key, "
                        "assignment in page-locked memory; a step = one proof incl. H2D of z and the 128 proof bytes out",
            "setup_s": round(ps.setup_s, 2)}
+    try:
+        tb = ps.ctx.table_bytes()
+        res["key_tables_hbm_bytes"] = {"bucket_tables": tb[0], "full_tables": tb[1],
+                                       "note": "full tables = every multiple of every window of the five queries; passes of ONE proof run on them "
+                                               "(no sort, no bucket reduce), batched passes on the bucket tables; MANTA_FULL_TABLE_GB bounds them per query"}
+    except Exception as e:  # noqa: BLE001
+        res["key_tables_hbm_bytes"] = {"error": str(e)}
     proofs = None
     if full:
         n1 = max(20, min(100, args.steps * 5))

@@ -307,6 +307,10 @@ int mg_groth16_prove_batch(const mg_ctx *ctx, uint64_t k, const uint64_t *z_mont
 /* h = R1CStoQAP::witness_map(z): D x 4 u64 Montgomery coefficients (tests / parity) */
 int mg_witness_map(const mg_ctx *ctx, const uint64_t *z_mont, uint64_t *h_out_mont);
 uint64_t mg_ctx_domain_size(const mg_ctx *ctx);
+/* HBM held by the context's key tables, bytes: out[0] = bucket tables (2^(c*w)*P per window, two widths), out[1] = FULL tables
+ * (every multiple of every window; single proofs run on them; MANTA_FULL_TABLE_GB bounds them per query, 0 = none). The h
+ * tables exist once mg_ctx_set_r1cs has run. Summed over the devices of a sharded context. */
+int mg_ctx_table_bytes(const mg_ctx *ctx, uint64_t out2[2]);
 uint64_t mg_ctx_num_variables(const mg_ctx *ctx); /* V: the length every assignment must have */
 uint64_t mg_ctx_num_inputs(const mg_ctx *ctx);    /* P */
 int mg_ctx_num_shards(const mg_ctx *ctx);

@@ -61,7 +61,7 @@ EXPORTS = [
     "mg_init", "mg_strerror", "mg_last_error", "mg_device_count", "mg_malloc", "mg_free", "mg_memcpy_h2d",
     "mg_memcpy_d2h", "mg_device_synchronize", "mg_host_alloc", "mg_host_free", "mg_set_kernel_timing", "mg_last_accumulate_ms", "mg_bases_create", "mg_bases_destroy", "mg_bases_device_bytes",
     "mg_msm", "mg_msm_launch", "mg_msm_finish", "mg_points_sum", "mg_fixed_base_mul", "mg_ec_elementwise", "mg_point_serialize", "mg_ntt",
-    "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size",
+    "mg_ntt_device", "mg_groth16_setup", "mg_ctx_create", "mg_ctx_create_from_bytes", "mg_ctx_set_r1cs", "mg_groth16_prove", "mg_groth16_prove_batch", "mg_witness_map", "mg_ctx_domain_size", "mg_ctx_table_bytes",
     "mg_ctx_destroy", "mg_bases_create_sharded", "mg_bases_num_shards", "mg_bases_shard", "mg_msm_launch_sharded",
     "mg_ctx_create_sharded", "mg_ctx_create_from_bytes_sharded", "mg_ctx_num_variables", "mg_ctx_num_inputs",
     "mg_ctx_num_shards", "mg_field_op", "mg_vk_create", "mg_vk_create_from_bytes", "mg_vk_encoded_size", "mg_vk_encode",
@@ -597,6 +597,12 @@ class ProvingContext:
     @property
     def domain_size(self):
         return LIB.mg_ctx_domain_size(self.handle)
+
+    def table_bytes(self):
+        """HBM bytes of the key tables: (bucket tables, full tables)"""
+        v = (ctypes.c_uint64 * 2)()
+        _chk(LIB.mg_ctx_table_bytes(self.handle, v), "mg_ctx_table_bytes")
+        return int(v[0]), int(v[1])
 
     # ---- process-per-GPU sharding: partial results on the device, gathered by a collective, assembled on the host
     @property

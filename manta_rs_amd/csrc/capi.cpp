@@ -585,6 +585,11 @@ MG_API int mg_witness_map(const mg_ctx *ctx, const uint64_t *z, uint64_t *h_out)
     MG_CATCH
 }
 MG_API uint64_t mg_ctx_domain_size(const mg_ctx *ctx) { return ctx ? ctx->p->domain_size() : 0; }
+MG_API int mg_ctx_table_bytes(const mg_ctx *ctx, uint64_t out2[2]) {
+    if (!ctx || !out2) return MG_ERROR_INVALID_ARGUMENT;
+    ctx->p->table_bytes(out2);
+    return MG_OK;
+}
 MG_API uint64_t mg_ctx_num_variables(const mg_ctx *ctx) { return ctx ? ctx->p->n_vars() : 0; }
 MG_API uint64_t mg_ctx_num_inputs(const mg_ctx *ctx) { return ctx ? ctx->p->n_inputs() : 0; }
 MG_API int mg_ctx_num_shards(const mg_ctx *ctx) { return ctx ? (int)ctx->p->n_shards() : 0; }

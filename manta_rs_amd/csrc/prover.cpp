@@ -210,6 +210,18 @@ class ProverImpl : public Prover {
         M = DevCsr();
     }
     u64 domain_size() const override { return have_r1cs_ ? (u64)1 << log_d_ : 0; }
+    void table_bytes(u64 out2[2]) const override {
+        out2[0] = out2[1] = 0;
+        for (const BaseSet *b : {a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_, a_bs_wide_, b1_bs_wide_, b2_bs_wide_, l_bs_wide_, h_bs_wide_})
+            if (b) out2[0] += b->bytes;
+        for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, h_bs_full_})
+            if (b) out2[1] += b->bytes;
+        for (const ProverImpl *q : peers_) {
+            u64 t[2];
+            q->table_bytes(t);
+            out2[0] += t[0], out2[1] += t[1];
+        }
+    }
 
     // window bits for precomputed tables, by MSM length (HBM is plentiful: trade table size for fewer
     // buckets to fold and no doubling chain -- tuned on MI355X)

@@ -61,6 +61,7 @@ class Prover {
     virtual int prove_batch(u64 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) = 0;
     virtual int witness_map_host(const uint64_t *z, uint64_t *h_out) = 0;
     virtual u64 domain_size() const = 0;
+    virtual void table_bytes(u64 out2[2]) const = 0; // bucket tables, full tables (all shards)
     virtual u64 n_vars() const = 0;
     virtual u64 n_inputs() const = 0;
     virtual u32 n_shards() const = 0;

@@ -286,6 +286,7 @@ extern "C" {
     ) -> c_int;
     pub fn mg_witness_map(ctx: *const mg_ctx, z_mont: *const u64, h_out_mont: *mut u64) -> c_int;
     pub fn mg_ctx_domain_size(ctx: *const mg_ctx) -> u64;
+    pub fn mg_ctx_table_bytes(ctx: *const mg_ctx, out2: *mut u64) -> c_int;
     pub fn mg_ctx_num_variables(ctx: *const mg_ctx) -> u64;
     pub fn mg_ctx_num_inputs(ctx: *const mg_ctx) -> u64;
     pub fn mg_ctx_num_shards(ctx: *const mg_ctx) -> c_int;
