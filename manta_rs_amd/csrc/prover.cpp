@@ -678,7 +678,14 @@ class ProverImpl : public Prover {
         const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
         const size_t hlo = shard_lo(D), hn = shard_hi(D) - hlo;
         const u32 *sz = dz + (1 + zlo) * 8;
-        const bool one = w->k == 1; // a single proof: full tables where the key has them
+        // passes of up to this many proofs run on the full tables where the key has them (MANTA_FULL_MAX_K; a batch sorts its
+        // pairs by proof -- one radix pass -- and needs 32 additions per scalar where the wide bucket tables need 24)
+        static const u32 full_max_k = [] {
+            const char *e = std::getenv("MANTA_FULL_MAX_K");
+            const int v = e ? std::atoi(e) : 1;
+            return (u32)(v >= 0 ? v : 1);
+        }();
+        const bool one = w->k <= full_max_k;
         auto pick = [&](BaseSet *full, BaseSet *wd, BaseSet *narrow) { return one && full ? full : (wide && wd ? wd : narrow); };
         return MsmArgs{{pick(a_bs_full_, a_bs_wide_, a_bs_), pick(b1_bs_full_, b1_bs_wide_, b1_bs_), pick(b2_bs_full_, b2_bs_wide_, b2_bs_),
                         pick(l_bs_full_, l_bs_wide_, l_bs_), pick(h_bs_full_, h_bs_wide_, h_bs_)},
