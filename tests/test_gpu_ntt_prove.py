@@ -81,6 +81,55 @@ def test_prove_real_shape_to_private(gpu):
     assert O.groth16_verify(0, pk, c.z[1:c.P], proof) == 1
 
 
+_TABLES_SCRIPT = '''
+import os, sys
+sys.path.insert(0, r"{root}"); sys.path.insert(0, os.path.join(r"{root}", "tests"))
+import numpy as np
+import helpers as H
+from manta_rs_amd import api as gpu, synth, keygen
+gpu.init(0)
+c = synth.make_shape(0, "to_public")
+pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=5), synth.FR_MODULUS[0]))
+ctx = gpu.ProvingContext(0, pk)
+ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+rs = H.rand_fr_mont(0, 4, seed=99)
+bucket, full = ctx.table_bytes()
+print("TABLES", bucket, full)
+print("PROOF", gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]).hex())
+print("PROOF", gpu.Groth16.prove_with_randomness(ctx, c.z, rs[2], rs[3]).hex())
+'''
+
+
+def test_single_proofs_on_full_and_on_bucket_tables(gpu):
+    """A proof-sized key keeps FULL tables of its queries (every multiple of every window: passes of one proof are plain sums,
+    no sort, no bucket reduce) next to the bucket tables; MANTA_FULL_TABLE_GB bounds them, 0 leaves them out -- the path a
+    context takes when HBM is short. The knob is read once per process, hence the children: the ToPublic shape with the
+    default budget, with a small one (narrower windows, some queries without) and with none must give the oracle's bytes."""
+    import os
+    import subprocess
+    import sys
+    from manta_rs_amd import keygen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = synth.make_shape(0, "to_public")
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=5), synth.FR_MODULUS[0]))
+    rs = H.rand_fr_mont(0, 4, seed=99)
+    want = [O.groth16_prove(c, pk, rs[0], rs[1]).hex(), O.groth16_prove(c, pk, rs[2], rs[3]).hex()]
+    sizes = {}
+    for gb in ("", "2", "0"):
+        env = dict(os.environ)
+        env.pop("MANTA_FULL_TABLE_GB", None)
+        if gb:
+            env["MANTA_FULL_TABLE_GB"] = gb
+        out = subprocess.run([sys.executable, "-c", _TABLES_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        lines = out.stdout.split("\n")
+        assert [ln.split()[1] for ln in lines if ln.startswith("PROOF")] == want, gb
+        sizes[gb] = [int(x) for x in [ln for ln in lines if ln.startswith("TABLES")][0].split()[1:]]
+    assert sizes["0"][1] == 0 and sizes["0"][0] > 0
+    assert 0 < sizes["2"][1] <= 5 * 2e9 and sizes[""][1] > sizes["2"][1]
+    assert sizes[""][0] == sizes["0"][0]
+
+
 def test_prove_real_shape_private_transfer(gpu):
     """Shape-exact PrivateTransfer circuit (D=2^16, V=35175, P=27): bit-exact vs the oracle, pairing-verified,
     and -- like manta-pay/src/test/transfer.rs:346-417 -- a fuzzed public input must invalidate the proof."""
