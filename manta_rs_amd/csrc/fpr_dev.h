@@ -531,6 +531,35 @@ template <class C> struct FpR {
 #pragma unroll
         for (int i = 0; i < K; ++i) p[i] = v[i];
     }
+    // 32 N-bit form of a NORMALISED value below 2^(32 N) (any lazily reduced value < 2p): the LB-bit limbs repacked into N
+    // words, no arithmetic. What an NTT pass leaves in HBM for the next one: 32 B instead of 36 per element, and two adjacent
+    // elements are one aligned 64 B sector where the 72 B of the limb form straddle two.
+    MG_DEV void store_packed(u32 *p) const {
+#pragma unroll
+        for (int w = 0; w < C::N; ++w) {
+            u64 x = 0;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int lo = i * LB - w * 32; // position of limb i relative to word w
+                if (lo > -LB && lo < 32) x |= lo >= 0 ? ((u64)v[i] << lo) : ((u64)v[i] >> (-lo));
+            }
+            p[w] = (u32)x;
+        }
+    }
+    static MG_DEV FpR load_packed(const u32 *p) {
+        u32 t[C::N];
+#pragma unroll
+        for (int w = 0; w < C::N; ++w) t[w] = p[w];
+        FpR r;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int bit = i * LB, w = bit >> 5, o = bit & 31;
+            u64 x = w < C::N ? t[w] : 0;
+            if (w + 1 < C::N) x |= (u64)t[w + 1] << 32;
+            r.v[i] = (u32)(x >> o) & MASK;
+        }
+        return r;
+    }
     // limb i at p[i * stride]: LDS exchange areas keep one limb of all 64 lanes together (no bank conflicts)
     static MG_DEV FpR load_strided(const u32 *p, int stride) {
         FpR r;
