@@ -314,7 +314,8 @@ __global__ __launch_bounds__(256) void gather_only_chunks(const u32 *__restrict_
 template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                       u32 invalid, int final_level, u32 *__restrict__ buckets,
-                                                      u32 *__restrict__ okeys, u32 *__restrict__ opts, u32 n_waves) {
+                                                      u32 *__restrict__ okeys, u32 *__restrict__ opts, u32 n_waves,
+                                                      u32 *__restrict__ std_final) {
     MG_PRIO_FOR(F);
     constexpr size_t XW = XYZZ<F>::WORDS;
     const u32 wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -369,7 +370,9 @@ __global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restri
     const bool cont = lane < 63 && next_kh == kt;
     if (kt != invalid && !cont) {
         if (final_level) {
-            acc.store(buckets + (size_t)kt * XW);
+            // (std_final: one key in all -- a single MSM on full tables --, the last run IS the result: it leaves in the host's format)
+            if (std_final) acc.store_std(std_final + (size_t)kt * XYZZ<typename F::Std>::WORDS);
+            else acc.store(buckets + (size_t)kt * XW);
         } else if (kt == key0) {
             okeys[2 * wave] = kt;
             acc.store(opts + (size_t)(2 * wave) * XW);
@@ -395,6 +398,8 @@ __global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restri
         if (!final_level && kh == key0) {
             okeys[2 * wave] = kh;
             h.store(opts + (size_t)(2 * wave) * XW);
+        } else if (final_level && std_final) {
+            h.store_std(std_final + (size_t)kh * XYZZ<typename F::Std>::WORDS);
         } else {
             h.store(buckets + (size_t)kh * XW);
         }
@@ -407,7 +412,8 @@ __global__ __launch_bounds__(256) MG_TAIL_ATTR void merge_partials(u32 *__restri
 template <class F>
 __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void merge_partials_coop(u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 cnt, u32 G,
                                                            u32 invalid, int final_level, u32 *__restrict__ buckets,
-                                                           u32 *__restrict__ okeys, u32 *__restrict__ opts) {
+                                                           u32 *__restrict__ okeys, u32 *__restrict__ opts,
+                                                           u32 *__restrict__ std_final) {
     MG_PRIO_FOR(F);
     __shared__ __attribute__((aligned(16))) u32 lds[CoopAdd<F>::LDS_WORDS];
     constexpr size_t XW = XYZZ<F>::WORDS;
@@ -466,7 +472,9 @@ __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void merge_partials_coop(u32
     const bool cont = lane < 63 && next_kh == kt;
     if (writer && kt != invalid && !cont) {
         if (final_level) {
-            acc.store(buckets + (size_t)kt * XW);
+            // (std_final: one key in all -- a single MSM on full tables --, the last run IS the result: it leaves in the host's format)
+            if (std_final) acc.store_std(std_final + (size_t)kt * XYZZ<typename F::Std>::WORDS);
+            else acc.store(buckets + (size_t)kt * XW);
         } else if (kt == key0) {
             okeys[2 * wave] = kt;
             acc.store(opts + (size_t)(2 * wave) * XW);
@@ -496,6 +504,8 @@ __global__ __launch_bounds__(256) MG_TAIL_COOP_ATTR void merge_partials_coop(u32
         if (!final_level && kh == key0) {
             okeys[2 * wave] = kh;
             h.store(opts + (size_t)(2 * wave) * XW);
+        } else if (final_level && std_final) {
+            h.store_std(std_final + (size_t)kh * XYZZ<typename F::Std>::WORDS);
         } else {
             h.store(buckets + (size_t)kh * XW);
         }
@@ -1530,7 +1540,21 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (!no_sort && (rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
                                          ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
             return rc;
-        MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
+        // one key in all (full tables, one scalar vector): the run the last merge level closes IS the result -- it is stored in the
+        // host's format straight away (no bucket array, no reduce launch: one node fewer on the latency chain of a proof's MSM)
+#ifdef MG_NO_DIRECT // A/B builds (tools/build_variant.sh)
+        const bool direct = false;
+#else
+        const bool direct = nb == 1;
+#endif
+        constexpr int XWM0 = XW > XW_IO ? XW : XW_IO;
+        if (direct) {
+            if ((rc = ws->redA.reserve((size_t)XWM0 * 4)) || (rc = ws->redS.reserve((size_t)XWM0 * 4))) return rc;
+            MG_HIP(hipMemsetAsync(ws->redS.p, 0, (size_t)XWM0 * 4, s)); // no pair at all: the sum is the point at infinity
+        } else {
+            MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
+        }
+        u32 *const std_final = direct ? ws->redS.as<u32>() : (u32 *)nullptr;
         ws->timed = kernel_timing() && !ws->capturing;
         if (ws->timed) {
             if ((rc = ws->clk.reserve(64))) return rc;
@@ -1566,11 +1590,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if (waves <= coop_waves())
                 hipLaunchKernelGGL((merge_partials_coop<F>), dim3(waves), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
                                    ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
-                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>());
+                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), std_final);
             else
                 hipLaunchKernelGGL((merge_partials<F>), dim3(cdiv(waves, 4)), dim3(256), 0, s, ws->pkeys[src].as<u32>(),
                                    ws->ppts[src].as<u32>(), cnt, G, invalid, fin, ws->buckets.as<u32>(),
-                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves);
+                                   ws->pkeys[1 - src].as<u32>(), ws->ppts[1 - src].as<u32>(), waves, std_final);
             if (fin) break;
             cnt = 2 * waves;
             src ^= 1;
@@ -1680,7 +1704,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
         constexpr int XWM = XW > XW_IO ? XW : XW_IO;
-        if (T0 == 1) { // a single tile per window: its S is the window sum
+        if (direct) { // the last merge level left the result in redS
+            stage_pts = segs;
+            if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
+            ws->d_tail = ws->redS.as<u32>();
+            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+        } else if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
             if (coop_tiles(segs) && rn > 1) // (rn = 1, full tables: the scan kernel has no addition to make, it converts the point)
                 hipLaunchKernelGGL((tile_reduce_coop<F>), dim3(segs), dim3(256), 0, s, rin, rstride, roff, rn, 1u,
