@@ -15,7 +15,7 @@ rs = synth.to_mont([rng.field(p) for _ in range(2)], p, 4)
 for _ in range(3):
     api.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
 t = time.perf_counter()
-N = 10
+N = int(os.environ.get("PROVE_N", "10"))
 for _ in range(N):
     api.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
 print(f"{shape}: {(time.perf_counter()-t)/N*1e3:.3f} ms/proof sequential")
