@@ -254,7 +254,7 @@ def test_msm_reduce_front_levels(gpu, curve, group, pres, env):
     assert out.returncode == 0 and "front levels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
-@pytest.mark.parametrize("curve,group,n,pre", [(0, 1, 300, 5), (0, 1, 4000, 9), (1, 1, 20000, 13), (1, 1, 1 << 15, 16), (0, 2, 900, 6),
+@pytest.mark.parametrize("curve,group,n,pre", [(0, 1, 300, 5), (0, 1, 4000, 9), (0, 1, 3000, -6), (0, 2, 500, -4), (1, 1, 20000, 13), (1, 1, 1 << 15, 16), (0, 2, 900, 6),
                                                 (1, 2, 2500, 8)])
 def test_msm_result_folded_on_the_device(gpu, curve, group, n, pre):
     """`mg_msm_result_to_device`: the host fold of mg_msm_finish done by one kernel behind the MSM -- every staging layout
