@@ -236,6 +236,44 @@ int mg_groth16_setup(mg_curve_t curve, const mg_csr *a, const mg_csr *b, const m
 
 /* Uploads and re-lays the proving key once (lifetime = the Rust ProvingContext). */
 int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
+/* The same with everything a deployment decides per context in ONE struct (the entry points below are shorthands for it):
+ * a signer holds three contexts at once -- `MultiProvingContext { to_private, private_transfer, to_public }`,
+ * manta-accounting/src/transfer/canonical.rs:561-588 -- so what a context may spend on speed is a property of the context,
+ * not of the process.
+ *   struct_size       sizeof(mg_ctx_opts), written by mg_ctx_opts_init: the struct can grow without breaking callers
+ *   exchange          how the partial points of a context sharded over `devices` meet: MG_EXCHANGE_HOST -- through pinned host
+ *                     memory, summed on the host -- or MG_EXCHANGE_RCCL -- every device folds its five partial points per proof
+ *                     on the GPU, one grouped ncclAllGather of 5 x 256 B (BN254) per device and proof over xGMI inside the
+ *                     library (ncclCommInitAll over the list: no duplicate devices), assembly as in mg_groth16_assemble.
+ *                     BASELINE north_star: "final RCCL reduce of partial EC points over xGMI" behind the C ABI; caller
+ *                     manta-accounting/src/transfer/mod.rs:695-715. librccl.so is loaded when first asked for; if it is
+ *                     missing the call fails with MG_ERROR_STATE (no silent fallback).
+ *   full_table_bytes  HBM this context may spend on FULL tables of its five queries together (single proofs run on them:
+ *                     no sort, no bucket reduce on their latency chain), per device: the widest windows that fit are chosen,
+ *                     0 = none (bucket tables only), negative = the default, a tenth of the device's HBM (28.8 GB on an
+ *                     MI355X: three contexts use 30 %). Never more than 40 % of what is free at creation. The environment
+ *                     variable MANTA_FULL_TABLE_GB, when set, overrides it (GB per context).
+ *   devices/n_devices range-shard every MSM over these devices inside this process (mg_ctx_create_sharded)
+ *   shard/n_shards    this process holds one slice (mg_ctx_create_shard); n_shards <= 1: the whole key
+ *   task_mask         mg_ctx_create_task; 0 or 0x1f: all five MSMs
+ * At most one of the three placements may be used. */
+#define MG_EXCHANGE_HOST 0u
+#define MG_EXCHANGE_RCCL 1u
+typedef struct mg_ctx_opts {
+    uint32_t struct_size;
+    uint32_t exchange;
+    int64_t full_table_bytes;
+    const int *devices;
+    int32_t n_devices;
+    int32_t shard, n_shards;
+    uint32_t task_mask;
+} mg_ctx_opts;
+int mg_ctx_opts_init(mg_ctx_opts *opts); /* defaults: host exchange, default table budget, current device, whole key */
+int mg_ctx_create_ex(mg_curve_t curve, const mg_pk_view *pk, const mg_ctx_opts *opts /* NULL = defaults */, mg_ctx **out);
+/* ... and from the key's wire format (mg_ctx_create_from_bytes below), checksum32 = the expected BLAKE3 digest or NULL:
+ * the integrity check of mg_ctx_create_from_bytes_checked in front of EVERY placement. */
+int mg_ctx_create_from_bytes_ex(mg_curve_t curve, const uint8_t *bytes, size_t len, const uint8_t *checksum32,
+                                const mg_ctx_opts *opts, mg_ctx **out);
 /* The proving key range-sharded over a list of devices (BASELINE configs[3]: "PrivateTransfer full proof, MSM
  * sharded across 8 GPUs"): device g holds the g-th contiguous slice of every query with its window tables. A proof
  * uploads the assignment to every device, each recomputes the witness map (cheaper than broadcasting h, SURVEY.md
@@ -255,6 +293,9 @@ int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, siz
  *   mg_groth16_assemble: parts = n_parts gathered copies of [k][5][slot] in HOST memory (one fused all_gather of <= 1.9 KB
  *     per rank and proof); adds them and finishes the proofs exactly like mg_groth16_prove -- bytes identical to the
  *     single-GPU context's. Host-only work: any rank (or all) may call it. */
+/* A shard context with n_shards > 1 holds ONE slice of every query: mg_groth16_prove / mg_groth16_prove_batch on it return
+ * MG_ERROR_STATE (a proof built from one slice's MSMs would be silently invalid); only the partials interface and
+ * mg_witness_map work on it. */
 int mg_ctx_create_shard(mg_curve_t curve, const mg_pk_view *pk, int shard, int n_shards, mg_ctx **out);
 /* The alternative placement of SURVEY.md 8(e): TASK-parallel -- this process holds the whole key and computes the MSMs of
  * task_mask in full (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h; the witness map only when it owns h); for the others
@@ -308,7 +349,7 @@ int mg_groth16_prove_batch(const mg_ctx *ctx, uint64_t k, const uint64_t *z_mont
 int mg_witness_map(const mg_ctx *ctx, const uint64_t *z_mont, uint64_t *h_out_mont);
 uint64_t mg_ctx_domain_size(const mg_ctx *ctx);
 /* HBM held by the context's key tables, bytes: out[0] = bucket tables (2^(c*w)*P per window, two widths), out[1] = FULL tables
- * (every multiple of every window; single proofs run on them; MANTA_FULL_TABLE_GB bounds them per query, 0 = none). The h
+ * (every multiple of every window; single proofs run on them; mg_ctx_opts.full_table_bytes bounds them, 0 = none). The h
  * tables exist once mg_ctx_set_r1cs has run. Summed over the devices of a sharded context. */
 int mg_ctx_table_bytes(const mg_ctx *ctx, uint64_t out2[2]);
 uint64_t mg_ctx_num_variables(const mg_ctx *ctx); /* V: the length every assignment must have */

@@ -69,6 +69,7 @@ EXPORTS = [
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
     "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
+    "mg_ctx_opts_init", "mg_ctx_create_ex", "mg_ctx_create_from_bytes_ex",
 ]
 
 
@@ -507,57 +508,81 @@ def groth16_setup(r1cs: "R1CS", n_vars, toxic_mont, g1_generator, g2_generator) 
     return pk
 
 
+EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
+
+
+class _CtxOpts(ctypes.Structure):
+    """`mg_ctx_opts` (include/mantagpu.h)"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("exchange", ctypes.c_uint32), ("full_table_bytes", ctypes.c_int64),
+                ("devices", ctypes.POINTER(ctypes.c_int)), ("n_devices", ctypes.c_int32), ("shard", ctypes.c_int32),
+                ("n_shards", ctypes.c_int32), ("task_mask", ctypes.c_uint32)]
+
+
+def _ctx_opts(devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None):
+    """-> (mg_ctx_opts, keep-alive) from the keyword arguments of ProvingContext"""
+    o = _CtxOpts()
+    _chk(LIB.mg_ctx_opts_init(ctypes.byref(o)), "mg_ctx_opts_init")
+    assert o.struct_size == ctypes.sizeof(_CtxOpts), "mg_ctx_opts: the Python mirror is out of date"
+    keep = None
+    if devices is not None:
+        keep = (ctypes.c_int * len(devices))(*devices)
+        o.devices, o.n_devices = keep, len(devices)
+    if shard is not None:
+        o.shard, o.n_shards = int(shard[0]), int(shard[1])
+    if task_mask is not None:
+        o.task_mask = int(task_mask)
+    if full_table_bytes is not None:
+        o.full_table_bytes = int(full_table_bytes)
+    if exchange is not None:
+        o.exchange = int(exchange)
+    return o, keep
+
+
 class ProvingContext:
     """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
     device-resident proving key; created once, shared by every proof of the shape."""
 
-    def __init__(self, curve, pk, devices=None, shard=None, task_mask=None):
+    def __init__(self, curve, pk, devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None):
         """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
         b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P.
         devices: list of HIP device indices -> every MSM of a proof is range-sharded over them
         (`mg_ctx_create_sharded`); None -> the current device.
         shard = (g, G): this PROCESS holds slice g of G of every query on the current device (`mg_ctx_create_shard`,
-        one process per GPU; see distributed.ShardedProver)."""
+        one process per GPU; see distributed.ShardedProver).
+        full_table_bytes: HBM budget of the context's full tables (None = the library's default, a tenth of the device's
+        HBM; 0 = bucket tables only); exchange: EXCHANGE_HOST / EXCHANGE_RCCL for a `devices` list (`mg_ctx_opts`)."""
         self.curve = curve
         self._keep = [_u64(getattr(pk, k)) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2",
                                                      "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
         v = _PkView(pk.V, pk.P, self._keep[8].shape[0], *[_p(a) for a in self._keep])
         h = _vp()
-        if task_mask is not None:  # task placement: this process computes the MSMs of the mask in full (`mg_ctx_create_task`)
-            _chk(LIB.mg_ctx_create_task(curve, ctypes.byref(v), ctypes.c_uint(int(task_mask)), ctypes.byref(h)), "mg_ctx_create_task")
-        elif shard is not None:
-            _chk(LIB.mg_ctx_create_shard(curve, ctypes.byref(v), int(shard[0]), int(shard[1]), ctypes.byref(h)), "mg_ctx_create_shard")
-        elif devices is None:
-            _chk(LIB.mg_ctx_create(curve, ctypes.byref(v), ctypes.byref(h)), "mg_ctx_create")
+        if task_mask is not None and int(task_mask) == 0:  # a rank beyond the fifth owns no MSM: the struct reads 0 as "all five"
+            _chk(LIB.mg_ctx_create_task(curve, ctypes.byref(v), ctypes.c_uint(0), ctypes.byref(h)), "mg_ctx_create_task")
         else:
-            dv = (ctypes.c_int * len(devices))(*devices)
-            _chk(LIB.mg_ctx_create_sharded(curve, ctypes.byref(v), dv, len(devices), ctypes.byref(h)), "mg_ctx_create_sharded")
+            o, keep = _ctx_opts(devices, shard, task_mask, full_table_bytes, exchange)
+            _chk(LIB.mg_ctx_create_ex(curve, ctypes.byref(v), ctypes.byref(o), ctypes.byref(h)), "mg_ctx_create_ex")
+            del keep
         self._keep = None  # the library copied everything
         self.handle = h
         self._r1cs_ref = None
 
     @classmethod
-    def decode(cls, curve, data: bytes, devices=None, checksum: bytes = None):
+    def decode(cls, curve, data: bytes, devices=None, checksum: bytes = None, full_table_bytes=None, exchange=None):
         """Mirror of `impl Decode for ProvingContext` (groth16.rs:268-288): arkworks `deserialize_unchecked`
         bytes of the ProvingKey -- the format of manta-parameters' proving-key files. checksum: the file's BLAKE3 digest as
-        manta-parameters' data.checkfile lists it (32 bytes); a mismatch raises before anything is uploaded
-        (`manta_parameters::verify`, manta-parameters/src/lib.rs:173-177)."""
+        manta-parameters' data.checkfile lists it (32 bytes); a mismatch raises before anything is uploaded, whatever the
+        placement (`manta_parameters::verify`, manta-parameters/src/lib.rs:173-177; `mg_ctx_create_from_bytes_ex`)."""
         self = cls.__new__(cls)
         self.curve = curve
         self._keep = None
         self._r1cs_ref = None
         h = _vp()
-        if checksum is not None and devices is None:
-            if len(checksum) != 32:
-                raise ValueError("a BLAKE3 digest is 32 bytes")
-            _chk(LIB.mg_ctx_create_from_bytes_checked(curve, bytes(data), _sz(len(data)), bytes(checksum), ctypes.byref(h)),
-                 "mg_ctx_create_from_bytes_checked")
-        elif devices is None:
-            _chk(LIB.mg_ctx_create_from_bytes(curve, bytes(data), _sz(len(data)), ctypes.byref(h)), "mg_ctx_create_from_bytes")
-        else:
-            dv = (ctypes.c_int * len(devices))(*devices)
-            _chk(LIB.mg_ctx_create_from_bytes_sharded(curve, bytes(data), _sz(len(data)), dv, len(devices), ctypes.byref(h)),
-                 "mg_ctx_create_from_bytes_sharded")
+        if checksum is not None and len(checksum) != 32:
+            raise ValueError("a BLAKE3 digest is 32 bytes")
+        o, keep = _ctx_opts(devices, None, None, full_table_bytes, exchange)
+        _chk(LIB.mg_ctx_create_from_bytes_ex(curve, bytes(data), _sz(len(data)), None if checksum is None else bytes(checksum),
+                                             ctypes.byref(o), ctypes.byref(h)), "mg_ctx_create_from_bytes_ex")
+        del keep
         self.handle = h
         return self
 

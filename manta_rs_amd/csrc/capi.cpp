@@ -477,6 +477,68 @@ MG_API int mg_ctx_create_task(mg_curve_t curve, const mg_pk_view *pk, unsigned t
     return MG_SUCCESS;
     MG_CATCH
 }
+// mg_ctx_opts -> ProverOptions; a struct shorter than ours (an older caller) is read up to its own size
+static int opts_from_abi(const mg_ctx_opts *in, ProverOptions &o) {
+    if (!in) return MG_SUCCESS;
+    mg_ctx_opts t;
+    mg_ctx_opts_init(&t);
+    if (in->struct_size < 8 || in->struct_size > 4096) return MG_ERROR_INVALID_ARGUMENT; // not initialised by mg_ctx_opts_init
+    std::memcpy(&t, in, std::min<size_t>(in->struct_size, sizeof(t)));
+    if (t.n_devices < 0 || (t.n_devices > 0 && !t.devices) || t.shard < 0 || t.n_shards < 0) return MG_ERROR_INVALID_ARGUMENT;
+    o.devices = t.n_devices > 0 ? t.devices : nullptr;
+    o.n_devices = t.n_devices;
+    o.shard = (u32)t.shard;
+    o.n_shards = t.n_shards > 0 ? (u32)t.n_shards : 1;
+    o.task_mask = t.task_mask ? t.task_mask : 0x1f;
+    o.full_table_bytes = t.full_table_bytes;
+    o.exchange = (int)t.exchange;
+    return MG_SUCCESS;
+}
+MG_API int mg_ctx_opts_init(mg_ctx_opts *o) {
+    if (!o) return MG_ERROR_INVALID_ARGUMENT;
+    std::memset(o, 0, sizeof(*o));
+    o->struct_size = (uint32_t)sizeof(*o);
+    o->exchange = MG_EXCHANGE_HOST;
+    o->full_table_bytes = -1;
+    o->n_shards = 1;
+    o->task_mask = 0x1f;
+    return MG_SUCCESS;
+}
+MG_API int mg_ctx_create_ex(mg_curve_t curve, const mg_pk_view *pk, const mg_ctx_opts *opts, mg_ctx **out) {
+    MG_TRY
+    if (!pk || !out) return MG_ERROR_INVALID_ARGUMENT;
+    ProverOptions o;
+    int rc = opts_from_abi(opts, o);
+    if (rc) return rc;
+    Prover *p = nullptr;
+    rc = prover_create_ex((int)curve, pk, o, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
+namespace mg {
+void blake3_hash(const uint8_t *data, size_t len, uint8_t out[32]);
+}
+MG_API int mg_ctx_create_from_bytes_ex(mg_curve_t curve, const uint8_t *bytes, size_t len, const uint8_t *checksum32,
+                                       const mg_ctx_opts *opts, mg_ctx **out) {
+    MG_TRY
+    if (!bytes || !out) return MG_ERROR_INVALID_ARGUMENT;
+    ProverOptions o;
+    int rc = opts_from_abi(opts, o);
+    if (rc) return rc;
+    if (checksum32) { // manta_parameters::verify in front of the loader, whatever the placement
+        uint8_t h[32];
+        blake3_hash(bytes, len, h);
+        if (std::memcmp(h, checksum32, 32) != 0) return MG_ERROR_CHECKSUM;
+    }
+    Prover *p = nullptr;
+    rc = prover_create_from_bytes_ex((int)curve, bytes, len, o, &p);
+    if (rc) return rc;
+    *out = new mg_ctx{p};
+    return MG_SUCCESS;
+    MG_CATCH
+}
 struct mg_partials_job {
     Prover *p;
     void *job;
@@ -518,9 +580,6 @@ MG_API int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *byt
     *out = new mg_ctx{p};
     return MG_SUCCESS;
     MG_CATCH
-}
-namespace mg {
-void blake3_hash(const uint8_t *data, size_t len, uint8_t out[32]);
 }
 MG_API int mg_blake3(const uint8_t *data, size_t len, uint8_t out32[32]) {
     MG_TRY

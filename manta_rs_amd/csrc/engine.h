@@ -40,6 +40,7 @@ enum { MG_OK = 0, MG_ERR_ARG = 1, MG_ERR_HIP = 2, MG_ERR_OOM = 3, MG_ERR_DOMAIN 
         }                                                                                                         \
     } while (0)
 void set_last_hip_error(hipError_t e, const char *expr, const char *file, int line);
+void set_last_error_text(const char *text); // detail for mg_last_error() of a failure that is not a HIP status
 // When on, every MSM brackets its accumulate kernel with HIP events on the launch stream (bench.py's
 // roofline leg); off by default.
 void set_kernel_timing(bool on);

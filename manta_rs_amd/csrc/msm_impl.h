@@ -99,8 +99,24 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
     }
     // k P = (r - k)(-P): the smaller of k and r - k is below 2^(BITS - 1), so ceil(BITS / c) signed windows hold it -- one fewer
     // than the ceil((BITS + 1) / c) a scalar up to r - 1 needs whenever c divides BITS (BLS12-381, 255 bits: 15 windows of 17
-    // bits instead of 16). The sign of every digit flips with the scalar. (Scalars are canonical, mantagpu.h; one that is not
-    // below r is left as it is.)
+    // bits instead of 16). The sign of every digit flips with the scalar.
+    // A scalar that is NOT below r (the ABI says canonical, arkworks' multi_scalar_mul takes any BigInteger256 and treats it as
+    // the integer it is) is first reduced: k P = (k mod r) P, and 2^256 < 6 r on both curves. Without this its top window could
+    // exceed B and drop a carry. Wave-uniform early exit: canonical input pays one borrow chain.
+    for (int it = 0; it < 6; ++it) {
+        u32 t[8], bw = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u64 d = (u64)s[j] - FrC::P[j] - bw;
+            t[j] = (u32)d;
+            bw = (u32)(d >> 63);
+        }
+        if (!__any(!bw)) break; // every lane's scalar is below r
+        if (!bw) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = t[j];
+        }
+    }
     u32 flip = 0;
     {
         u32 t[8], bw = 0;

@@ -82,7 +82,7 @@ template <class C> bool read_vec(Reader &r, int deg, std::vector<uint64_t> &out,
     return true;
 }
 
-template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices, int n_devices) {
+template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, Prover **out, const ProverOptions &o) {
     typedef typename Curve::Fq C;
     typedef host::HFp<C> HF;
     Reader r{bytes, len};
@@ -110,16 +110,21 @@ template <class Curve> int decode(int curve, const uint8_t *bytes, size_t len, P
     v.b_g2_query = b2.data();
     v.h_query = h.data();
     v.l_query = l.data();
-    return devices && n_devices > 0 ? prover_create_sharded(curve, &v, devices, n_devices, out) : prover_create(curve, &v, out);
+    return prover_create_ex(curve, &v, o, out);
 }
 
 } // namespace
 
-int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices, int n_devices) {
+int prover_create_from_bytes_ex(int curve, const uint8_t *bytes, size_t len, const ProverOptions &o, Prover **out) {
     if (!bytes || !out) return MG_ERR_ARG;
-    if (curve == 0) return decode<Bn254>(curve, bytes, len, out, devices, n_devices);
-    if (curve == 1) return decode<Bls381>(curve, bytes, len, out, devices, n_devices);
+    if (curve == 0) return decode<Bn254>(curve, bytes, len, out, o);
+    if (curve == 1) return decode<Bls381>(curve, bytes, len, out, o);
     return MG_ERR_ARG;
+}
+int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices, int n_devices) {
+    ProverOptions o;
+    if (devices && n_devices > 0) o.devices = devices, o.n_devices = n_devices;
+    return prover_create_from_bytes_ex(curve, bytes, len, o, out);
 }
 
 } // namespace mg

@@ -13,6 +13,9 @@
 // An unsatisfied witness is not an error (ark-groth16 only debug_asserts it): a non-verifying proof
 // comes back, exactly like the reference in release builds.
 #include "prover.h"
+#include <rccl/rccl.h> // types and prototypes only: librccl.so is loaded on demand (Rccl::get), never linked
+#include <dlfcn.h>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -40,6 +43,45 @@ FrEngine *get_ntt_engine(int curve) { // one per (device, curve): twiddle and sc
 }
 
 namespace {
+
+// RCCL behind the C ABI (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL): the library is dlopen'ed the first time a context asks for
+// it -- a process that already holds one (PyTorch ships its own librccl.so.1) gets THAT copy, two RCCL runtimes in one
+// process would each claim the devices -- and only the six entry points below are used. MANTA_RCCL_LIB names another file.
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    static Rccl *get() {
+        static Rccl *inst = [] () -> Rccl * {
+            Rccl *r = new Rccl();
+            const char *names[] = {std::getenv("MANTA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char *n : names)
+                if (n && !r->h) r->h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); // already in the process?
+            for (const char *n : names)
+                if (n && !r->h) r->h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!r->h) {
+                delete r;
+                return nullptr;
+            }
+            r->CommInitAll = (decltype(r->CommInitAll))dlsym(r->h, "ncclCommInitAll");
+            r->CommDestroy = (decltype(r->CommDestroy))dlsym(r->h, "ncclCommDestroy");
+            r->AllGather = (decltype(r->AllGather))dlsym(r->h, "ncclAllGather");
+            r->GroupStart = (decltype(r->GroupStart))dlsym(r->h, "ncclGroupStart");
+            r->GroupEnd = (decltype(r->GroupEnd))dlsym(r->h, "ncclGroupEnd");
+            r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->h, "ncclGetErrorString");
+            if (!r->CommInitAll || !r->CommDestroy || !r->AllGather || !r->GroupStart || !r->GroupEnd || !r->GetErrorString) {
+                delete r;
+                return nullptr;
+            }
+            return r;
+        }();
+        return inst;
+    }
+};
 
 // One in-flight proof (or batch of proofs): device scratch for the witness map, its five MSM workspaces (each
 // with its own stream), a pinned copy of z, and -- after two eager runs that size every buffer -- captured
@@ -147,6 +189,10 @@ class ProverImpl : public Prover {
     // in full; the others are some other rank's. Only the partials interface works on such a context; it launches eagerly.
     u32 task_mask_ = 0x1f;
     bool does(int i) const { return (task_mask_ >> i) & 1u; }
+    // a context from prover_create_shard with more than one shard: it holds slice g of every query and nothing of the other
+    // slices (they are other processes'), so a whole proof cannot come out of it -- only partials_launch / assemble work
+    bool lone_range_shard() const { return n_shards_ > 1 && peers_.empty() && shard_owner_ == nullptr; }
+    ProverImpl *shard_owner_ = nullptr; // in-process peers: the shard-0 object that owns this one
     std::vector<ProverImpl *> peers_;  // shard 0 only: shards 1 .. G-1 (owned); a pass runs on all of them, shard 0 assembles
     FrEngine *fr_ = nullptr;
     GroupEngine *g1_ = nullptr, *g2_ = nullptr;
@@ -177,6 +223,7 @@ class ProverImpl : public Prover {
     static constexpr size_t MAX_IDLE_SLOTS = 16; // (eight batch sizes of coalesced calls x two passes in flight) per context: beyond it the least recently used idle slot is destroyed
 
     ~ProverImpl() override {
+        exchange_destroy();
         for (ProverImpl *q : peers_) delete q;
         hipSetDevice(dev_);
         // (h_bs_ is created by set_r1cs)
@@ -237,38 +284,77 @@ class ProverImpl : public Prover {
     }
 
     // FULL tables for the queries single proofs run on (mg_bases_create with a negative width: every multiple of every window
-    // tabulated, the MSM is one plain sum -- no sort, no merge into buckets, no bucket reduce on the latency chain of a proof):
-    // the widest window whose table fits the budget per query. MANTA_FULL_TABLE_GB (default 24: ~80 GB of the 288 for a PrivateTransfer key; 0 = bucket tables only),
-    // MANTA_FULL_C = fixed width. Returns the (negative) width argument, or 0.
-    static int full_c_for(GroupEngine *g, u64 n) {
-        static const double budget = [] {
-            const char *e = std::getenv("MANTA_FULL_TABLE_GB");
-            return e ? std::atof(e) : 24.0;
-        }();
+    // tabulated, the MSM is one plain sum -- no sort, no merge into buckets, no bucket reduce on the latency chain of a proof).
+    // They are bought with HBM, and a signer holds three contexts (`MultiProvingContext`, manta-accounting/src/transfer/
+    // canonical.rs:561-588), so the budget is a property of the CONTEXT (mg_ctx_opts.full_table_bytes; default a tenth of the
+    // device's HBM; 0 = bucket tables only) and covers its five tables together. MANTA_FULL_TABLE_GB overrides it (GB per
+    // context), MANTA_FULL_C fixes the width. A context sharded over several entries of one device splits the budget.
+    int64_t full_budget_ = 0;   // bytes for this shard's five full tables
+    int full_c_plan_[5] = {0, 0, 0, 0, 0}; // planned widths: a, b_g1, b_g2, l, h (0 = none)
+    static u64 full_cost(GroupEngine *g, u64 n, int c) {
+        return ((u64)((g->scalar_bits() + c - 1) / c) << (c - 1)) * n * (u64)g->base_record_bytes();
+    }
+    static bool full_fits_index(GroupEngine *g, u64 n, int c) { return (((u64)((g->scalar_bits() + c - 1) / c) << (c - 1)) * n) < ((u64)1 << 31); }
+    // widths of the five tables under `budget`: the widest uniform width c in 4 .. 8 whose five tables fit together, then single
+    // queries one step wider while they fit, the longest chains first (b_g2, h, a, b_g1, l). n[i] = entries of query i on this shard.
+    void plan_full_tables(const u64 n[5], int64_t budget, int out[5]) const {
+        for (int i = 0; i < 5; ++i) out[i] = 0;
         static const int fixed = [] {
             const char *e = std::getenv("MANTA_FULL_C");
             const int v = e ? std::atoi(e) : 0;
             return v >= 2 && v <= 12 ? v : 0;
         }();
-        if (budget <= 0 || n == 0) return 0;
-        // never more than a twelfth of what is free now per query (five queries: well under half of it), so that a second and a
-        // third context on the same device get narrower tables instead of an allocation failure
-        size_t free_b = 0, total_b = 0;
-        double cap = budget * 1e9;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b / 12.0 < cap) cap = (double)free_b / 12.0;
-        for (int c = fixed ? fixed : 8; c >= (fixed ? fixed : 4); --c) {
-            const u64 per = (u64)((g->scalar_bits() + c - 1) / c) << (c - 1);
-            if (per * n >= ((u64)1 << 31)) continue;
-            if ((double)(per * n) * g->base_record_bytes() <= cap) return -c;
+        if (budget <= 0) return;
+        GroupEngine *ge[5] = {g1_, g1_, g2_, g1_, g1_};
+        auto total = [&](const int c[5]) {
+            u64 t = 0;
+            for (int i = 0; i < 5; ++i)
+                if (c[i] && n[i]) t += full_cost(ge[i], n[i], c[i]);
+            return t;
+        };
+        auto ok = [&](const int c[5]) {
+            for (int i = 0; i < 5; ++i)
+                if (c[i] && n[i] && !full_fits_index(ge[i], n[i], c[i])) return false;
+            return total(c) <= (u64)budget;
+        };
+        int c[5];
+        const int hi = fixed ? fixed : 8, lo = fixed ? fixed : 4;
+        int u = 0;
+        for (int w = hi; w >= lo && !u; --w) {
+            for (int i = 0; i < 5; ++i) c[i] = w;
+            if (ok(c)) u = w;
         }
-        return 0;
+        if (!u) return;
+        for (int i = 0; i < 5; ++i) c[i] = u;
+        if (!fixed) {
+            static const int order[5] = {2, 4, 0, 1, 3};
+            for (int step = 0; step < 5; ++step) {
+                const int i = order[step];
+                if (c[i] >= 8) continue;
+                ++c[i];
+                if (!ok(c)) --c[i];
+            }
+        }
+        for (int i = 0; i < 5; ++i) out[i] = n[i] ? c[i] : 0;
+    }
+    // the budget of this shard: the option (or its default, a tenth of the device's HBM), the environment override, never more
+    // than 40 % of what is free on the device right now, split between the shards of this context that share the device
+    static int64_t resolve_full_budget(int64_t opt_bytes, int shards_on_this_device) {
+        size_t free_b = 0, total_b = 0;
+        const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        double b = opt_bytes >= 0 ? (double)opt_bytes : (have ? (double)total_b / 10.0 : 24e9);
+        if (const char *e = std::getenv("MANTA_FULL_TABLE_GB")) b = std::atof(e) * 1e9;
+        if (have && b > 0.4 * (double)free_b) b = 0.4 * (double)free_b;
+        if (shards_on_this_device > 1) b /= shards_on_this_device;
+        return b > 0 ? (int64_t)b : 0;
     }
 
     // contiguous slice of an n-entry query owned by this shard
     size_t shard_lo(size_t n) const { return n * shard_ / n_shards_; }
     size_t shard_hi(size_t n) const { return n * (shard_ + 1) / n_shards_; }
 
-    int init(int curve, const mg_pk_view *pk, int device, u32 shard = 0, u32 n_shards = 1) {
+    int init(int curve, const mg_pk_view *pk, int device, u32 shard = 0, u32 n_shards = 1, int64_t full_table_bytes = -1,
+             int shards_on_this_device = 1) {
         curve_ = curve;
         dev_ = device;
         shard_ = shard;
@@ -310,8 +396,14 @@ class ProverImpl : public Prover {
         const u32 *b2q = (const u32 *)pk->b_g2_query + (1 + zlo) * w2, *lq = (const u32 *)pk->l_query + llo * w1;
         const int c_z = pre_c_for(V_ - 1);
         const bool proof_sized = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
-        const int f_z1 = proof_sized ? full_c_for(g1_, zn) : 0, f_z2 = proof_sized ? full_c_for(g2_, zn) : 0;
-        const int f_l = proof_sized ? full_c_for(g1_, ln) : 0;
+        if (proof_sized) {
+            full_budget_ = resolve_full_budget(full_table_bytes, shards_on_this_device);
+            u64 D = 1; // the domain the h query was made for: len(h_query) = D - 1 (ark setup) or D (MPC keys)
+            while (D < h_len_) D <<= 1;
+            const u64 nq[5] = {zn, zn, zn, ln, (u64)(D * (shard_ + 1) / n_shards_ - D * shard_ / n_shards_)};
+            plan_full_tables(nq, full_budget_, full_c_plan_);
+        }
+        const int f_z1a = -full_c_plan_[0], f_z1b = -full_c_plan_[1], f_z2 = -full_c_plan_[2], f_l = -full_c_plan_[3];
         if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
         if ((rc = g1_->bases_create(b1q, zn, false, c_z, &b1_bs_, true))) return rc;
         // The G2 MSM is the latency-critical chain of a single proof: 6-bit windows (32 buckets: one tile, no second
@@ -333,8 +425,8 @@ class ProverImpl : public Prover {
             return r;
         };
         if ((rc = try_full(g2_, b2q, zn, f_z2, &b2_bs_full_))) return rc; // the G2 chain first: the longest of a proof
-        if ((rc = try_full(g1_, aq, zn, f_z1, &a_bs_full_))) return rc;
-        if ((rc = try_full(g1_, b1q, zn, f_z1, &b1_bs_full_))) return rc;
+        if ((rc = try_full(g1_, aq, zn, f_z1a, &a_bs_full_))) return rc;
+        if ((rc = try_full(g1_, b1q, zn, f_z1b, &b1_bs_full_))) return rc;
         if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
             int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
@@ -456,7 +548,16 @@ class ProverImpl : public Prover {
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
             if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
-            const int f_h = lg <= 17 && !std::getenv("MANTA_PROVE_CH") ? full_c_for(g1_, hi - lo) : 0;
+            // the h table gets what the budget has left after the four z / l tables: the planned width when the domain is the
+            // one the key was made for, else the widest that still fits
+            int f_h = 0;
+            if (lg <= 17 && !std::getenv("MANTA_PROVE_CH") && full_budget_ > 0) {
+                int64_t left = full_budget_;
+                for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_})
+                    if (b) left -= (int64_t)b->bytes;
+                for (int cc = full_c_plan_[4] ? std::max(full_c_plan_[4], 4) : 0; cc >= 4 && !f_h; --cc)
+                    if (full_fits_index(g1_, hi - lo, cc) && (int64_t)full_cost(g1_, hi - lo, cc) <= left) f_h = -cc;
+            }
             rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &st.h);
             if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &st.h_wide);
             if (!rc && f_h && g1_->bases_create(perm.data(), hi - lo, false, f_h, &st.h_full) != MG_OK) {
@@ -854,7 +955,8 @@ class ProverImpl : public Prover {
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
         if (!z || !r || !s || !proof_out) return MG_ERR_ARG;
         if (task_mask_ != 0x1f) return MG_ERR_STATE; // holds some of the MSMs only: partials_launch / assemble
-        if (coalesce_inflight() == 0 || !peers_.empty()) return prove_pass(1, z, r, s, proof_out);
+        if (lone_range_shard()) return MG_ERR_STATE; // one slice of every query, the others live in other processes: same
+        if (coalesce_inflight() == 0 || !peers_.empty() || ex_) return prove_pass(1, z, r, s, proof_out);
         Req me{z, r, s, proof_out};
         std::unique_lock<std::mutex> lk(cq_mu_);
         cq_.push_back(&me);
@@ -950,7 +1052,7 @@ class ProverImpl : public Prover {
     }
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
-        if (task_mask_ != 0x1f) return MG_ERR_STATE;
+        if (task_mask_ != 0x1f || lone_range_shard()) return MG_ERR_STATE;
         if (k64 <= BATCH_CHUNK) return prove_pass(k64, z, r, s, proofs_out);
         // (passes of exactly BATCH_CHUNK proofs plus one remainder: equalising the pass sizes -- 256 proofs as 9 x 29 instead
         // of 8 x 32 -- was measured and is slower: every distinct pass size needs its own workspaces and captured graphs)
@@ -1015,6 +1117,7 @@ class ProverImpl : public Prover {
         locks.emplace_back(shape_mu_);
         for (ProverImpl *q : peers_) locks.emplace_back(q->shape_mu_);
         if (!have_r1cs_) return MG_ERR_STATE;
+        if (ex_) return prove_pass_rccl((u32)k64, z, r, s, proofs_out, z_list); // the partial points meet through RCCL
         // every shard gets the whole assignment (1.1 MB for PrivateTransfer) and recomputes the witness map -- cheaper
         // than broadcasting h -- then multiplies its slices; shard 0 launches last and assembles
         std::vector<Pass> pp(peers_.size());
@@ -1267,10 +1370,16 @@ class ProverImpl : public Prover {
         if (k64 == 0 || k64 > BATCH_CHUNK || !z || !d_out || !job_out || !peers_.empty()) return MG_ERR_ARG;
         DeviceGuard restore_callers_device;
         std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
+        return partials_launch_locked(k64, z, d_out, consumer, job_out, &shape_lock);
+    }
+    // the caller holds shape_mu_ shared; with `take` the job keeps that lock until partials_finish (the public entry point),
+    // without it the caller keeps holding it for the length of the pass (the in-library exchange of prove_pass)
+    int partials_launch_locked(u64 k64, const uint64_t *z, uint64_t *d_out, void *consumer, void **job_out,
+                               std::shared_lock<std::shared_mutex> *take, const uint64_t *const *z_list = nullptr) {
         if (!have_r1cs_) return MG_ERR_STATE;
         PartialJob *job = new PartialJob();
-        job->shape_lock = std::move(shape_lock);
-        int rc = launch_pass(job->p, (u32)k64, z, nullptr, nullptr, nullptr);
+        if (take) job->shape_lock = std::move(*take);
+        int rc = launch_pass(job->p, (u32)k64, z, nullptr, nullptr, nullptr, z_list);
         ProveWs *w = job->p.w;
         if (rc || !w) {
             if (w) abandon_pass(job->p);
@@ -1340,6 +1449,171 @@ class ProverImpl : public Prover {
         assemble_g1(k, res.data(), bl.data(), r, proofs_out);
         assemble_g2(k, res.data(), bl.data(), proofs_out);
         return MG_OK;
+    }
+
+    // ---- the exchange step of an in-process sharded context over RCCL (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL; BASELINE
+    // north_star "final RCCL reduce of partial EC points over xGMI", reached from the Rust host through mg_ctx_create_ex):
+    // one communicator per shard from ncclCommInitAll over the context's device list; a pass folds its five partial points
+    // per proof on every device (the same partials_launch the process-per-GPU path uses) straight into that device's send
+    // buffer, ONE grouped ncclAllGather moves them (k x 5 x 256 B per device for BN254), shard 0's copy lands in pinned
+    // memory and the usual assembly adds the G copies. RCCL has no user-defined reduction, hence gather + sum. Several
+    // passes may be in flight (the streamed batches run three): each takes a buffer set from a small pool; the enqueue of
+    // the grouped collective is serialised -- communicators want one order of operations on every rank.
+    struct ExSet {
+        std::vector<u32 *> d_send, d_recv; // per shard, on its device
+        std::vector<hipStream_t> st;       // the stream the collective runs on, per shard
+        u32 *h_recv = nullptr;             // pinned: shard 0's gathered copy
+    };
+    struct Exchange {
+        Rccl *api = nullptr;
+        std::vector<ncclComm_t> comm;
+        std::vector<ProverImpl *> shard;
+        std::mutex mu, pool_mu;
+        std::condition_variable pool_cv;
+        std::vector<ExSet *> idle;
+        int made = 0;
+        size_t words = 0; // u32 per shard and set: BATCH_CHUNK proofs x 5 slots
+    };
+    Exchange *ex_ = nullptr;
+    static constexpr int EX_SETS = 4;
+    bool nccl_ok(ncclResult_t r, const char *what) {
+        if (r == ncclSuccess) return true;
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "RCCL: %s failed: %s", what, ex_ && ex_->api ? ex_->api->GetErrorString(r) : "?");
+        set_last_error_text(buf);
+        return false;
+    }
+    int exchange_init() {
+        Rccl *api = Rccl::get();
+        if (!api) {
+            set_last_error_text("MG_EXCHANGE_RCCL: librccl.so.1 could not be loaded (set MANTA_RCCL_LIB)");
+            return MG_ERR_STATE;
+        }
+        Exchange *x = new Exchange();
+        x->api = api;
+        x->shard.push_back(this);
+        x->shard.insert(x->shard.end(), peers_.begin(), peers_.end());
+        const int G = (int)x->shard.size();
+        std::vector<int> devs(G);
+        for (int g = 0; g < G; ++g) devs[g] = x->shard[g]->dev_;
+        for (int g = 0; g < G; ++g)
+            for (int t = 0; t < g; ++t)
+                if (devs[t] == devs[g]) { // RCCL refuses a device twice in one clique; the host exchange serves such lists
+                    delete x;
+                    set_last_error_text("MG_EXCHANGE_RCCL: a device is listed twice");
+                    return MG_ERR_ARG;
+                }
+        x->comm.assign(G, nullptr);
+        x->words = (size_t)BATCH_CHUNK * 5 * slot_words();
+        ex_ = x;
+        if (!nccl_ok(api->CommInitAll(x->comm.data(), G, devs.data()), "ncclCommInitAll")) {
+            x->comm.clear();
+            exchange_destroy();
+            return MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+    void exchange_destroy() {
+        if (!ex_) return;
+        for (ExSet *e : ex_->idle) ex_free(e);
+        for (ncclComm_t c : ex_->comm)
+            if (c) ex_->api->CommDestroy(c);
+        delete ex_;
+        ex_ = nullptr;
+    }
+    void ex_free(ExSet *e) {
+        for (size_t g = 0; g < e->st.size(); ++g) {
+            hipSetDevice(ex_->shard[g]->dev_);
+            if (e->d_send[g]) hipFree(e->d_send[g]);
+            if (e->d_recv[g]) hipFree(e->d_recv[g]);
+            if (e->st[g]) hipStreamDestroy(e->st[g]);
+        }
+        if (e->h_recv) hipHostFree(e->h_recv);
+        delete e;
+    }
+    ExSet *ex_acquire() {
+        std::unique_lock<std::mutex> lk(ex_->pool_mu);
+        for (;;) {
+            if (!ex_->idle.empty()) {
+                ExSet *e = ex_->idle.back();
+                ex_->idle.pop_back();
+                return e;
+            }
+            if (ex_->made < EX_SETS) break;
+            ex_->pool_cv.wait(lk);
+        }
+        ++ex_->made;
+        lk.unlock();
+        const size_t G = ex_->shard.size();
+        ExSet *e = new ExSet();
+        e->d_send.assign(G, nullptr), e->d_recv.assign(G, nullptr), e->st.assign(G, nullptr);
+        bool ok = true;
+        for (size_t g = 0; g < G && ok; ++g) {
+            ok = hipSetDevice(ex_->shard[g]->dev_) == hipSuccess && hipMalloc((void **)&e->d_send[g], ex_->words * 4) == hipSuccess &&
+                 hipMalloc((void **)&e->d_recv[g], G * ex_->words * 4) == hipSuccess &&
+                 hipStreamCreateWithFlags(&e->st[g], hipStreamNonBlocking) == hipSuccess;
+        }
+        ok = ok && hipHostMalloc((void **)&e->h_recv, G * ex_->words * 4, hipHostMallocDefault) == hipSuccess;
+        if (!ok) {
+            (void)hipGetLastError();
+            ex_free(e);
+            std::lock_guard<std::mutex> g2(ex_->pool_mu);
+            --ex_->made;
+            ex_->pool_cv.notify_one();
+            return nullptr;
+        }
+        return e;
+    }
+    void ex_release(ExSet *e) {
+        {
+            std::lock_guard<std::mutex> g(ex_->pool_mu);
+            ex_->idle.push_back(e);
+        }
+        ex_->pool_cv.notify_one();
+    }
+    // one pass of k proofs on every shard with the RCCL exchange; the caller (prove_pass) holds every shard's shape lock
+    int prove_pass_rccl(u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out,
+                        const uint64_t *const *z_list) {
+        const size_t G = ex_->shard.size(), words = (size_t)k * 5 * slot_words();
+        ExSet *e = ex_acquire();
+        if (!e) return MG_ERR_OOM;
+        std::vector<void *> jobs(G, nullptr);
+        int rc = MG_OK;
+        for (size_t g = G; g-- > 0 && !rc;) // shard 0 last, like the host exchange
+            rc = ex_->shard[g]->partials_launch_locked(k, z, (uint64_t *)e->d_send[g], e->st[g], &jobs[g], nullptr, z_list);
+        if (!rc) {
+            std::lock_guard<std::mutex> one_order(ex_->mu);
+            bool ok = nccl_ok(ex_->api->GroupStart(), "ncclGroupStart");
+            for (size_t g = 0; g < G && ok; ++g)
+                ok = nccl_ok(ex_->api->AllGather(e->d_send[g], e->d_recv[g], words / 2, ncclUint64, ex_->comm[g], e->st[g]), "ncclAllGather");
+            ok = nccl_ok(ex_->api->GroupEnd(), "ncclGroupEnd") && ok;
+            if (!ok) rc = MG_ERR_HIP;
+        }
+        if (!rc) {
+            hipSetDevice(dev_);
+            hipError_t he = hipMemcpyAsync(e->h_recv, e->d_recv[0], G * words * 4, hipMemcpyDeviceToHost, e->st[0]);
+            if (he == hipSuccess) he = hipStreamSynchronize(e->st[0]);
+            if (he != hipSuccess) {
+                set_last_hip_error(he, "prove_pass_rccl: gathered points to the host", __FILE__, __LINE__);
+                rc = MG_ERR_HIP;
+            }
+        } else {
+            for (size_t g = 0; g < G; ++g) {
+                hipSetDevice(ex_->shard[g]->dev_);
+                hipStreamSynchronize(e->st[g]);
+            }
+        }
+        for (size_t g = 0; g < G; ++g) // (every rank received the gather: wait for the others' streams before their buffers are reused)
+            if (g && !rc) {
+                hipSetDevice(ex_->shard[g]->dev_);
+                hipStreamSynchronize(e->st[g]);
+            }
+        for (size_t g = 0; g < G; ++g)
+            if (jobs[g]) ex_->shard[g]->partials_finish(jobs[g]);
+        hipSetDevice(dev_);
+        if (!rc) rc = assemble(k, (u32)G, (const uint64_t *)e->h_recv, r, s, proofs_out);
+        ex_release(e);
+        return rc;
     }
 
     int finish_pass(Pass &p, int rc, std::vector<Pass> *peer_passes = nullptr) {
@@ -1420,63 +1694,51 @@ class ProverImpl : public Prover {
 
 } // namespace
 
-int prover_create(int curve, const mg_pk_view *pk, Prover **out) {
-    int dev = 0;
-    MG_HIP(hipGetDevice(&dev));
-    return prover_create_sharded(curve, pk, &dev, 1, out);
-}
-
-// One shard of a context in ITS OWN process (one process per GPU): slice `shard` of `n_shards` of every query on the current
-// device, no peers -- the partial results meet through partials_launch / assemble and a collective (distributed.py).
-int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out) {
-    if (!pk || !out || n_shards == 0 || shard >= n_shards || n_shards > 64) return MG_ERR_ARG;
-    int dev = 0;
-    MG_HIP(hipGetDevice(&dev));
-    ProverImpl *p = new ProverImpl();
-    const int rc = p->init(curve, pk, dev, shard, n_shards);
-    if (rc) {
-        delete p;
-        return rc;
-    }
-    *out = p;
-    return MG_OK;
-}
-
-// Task placement (last row): the context holds the whole key and computes the MSMs of `task_mask` in full (bit
-// i: a, b_g1, b_g2, l, h); the partial results of the ranks -- infinity where a rank does not own an MSM -- meet through the same
-// partials_launch / all_gather / assemble path as the range shards.
-int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **out) {
-    if (!pk || !out || task_mask > 0x1f) return MG_ERR_ARG;
-    int dev = 0;
-    MG_HIP(hipGetDevice(&dev));
-    ProverImpl *p = new ProverImpl();
-    p->task_mask_ = task_mask;
-    const int rc = p->init(curve, pk, dev, 0, 1);
-    if (rc) {
-        delete p;
-        return rc;
-    }
-    *out = p;
-    return MG_OK;
-}
-
-// One context over a list of devices: shard g owns the g-th contiguous slice of every query on devices[g] (a
-// device may be listed more than once -- two shards then share it, which is how the path is tested on a 1-GPU
-// box). Shard 0 is the object handed back; it owns the others.
-int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out) {
-    if (!pk || !devices || n_devices < 1 || n_devices > 64 || !out) return MG_ERR_ARG;
+// Every way a context comes into being goes through here (mg_ctx_create_ex; the older entry points fill a ProverOptions):
+//   devices / n_devices  one process driving several GPUs: shard g owns the g-th contiguous slice of every query on devices[g]
+//                        (a device may be listed more than once -- two shards then share it, which is how the path is tested on
+//                        a 1-GPU box). Shard 0 is the object handed back; it owns the others.
+//   shard / n_shards     one shard of a context in ITS OWN process (one process per GPU): slice `shard` of `n_shards` of every
+//                        query on the current device, no peers -- the partial results meet through partials_launch / assemble
+//                        and a collective (distributed.py).
+//   task_mask            task placement (last row): the whole key, the MSMs of the mask computed in full.
+//   full_table_bytes     HBM budget of the context's full tables (see resolve_full_budget)
+//   exchange             how the partial points of an in-process sharded context meet: host-staged sum, or RCCL all_gather
+int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Prover **out) {
+    if (!pk || !out) return MG_ERR_ARG;
+    if (o.task_mask > 0x1f || o.n_shards == 0 || o.shard >= o.n_shards || o.n_shards > 64) return MG_ERR_ARG;
+    if (o.exchange != 0 && o.exchange != 1) return MG_ERR_ARG;
+    const bool listed = o.devices && o.n_devices > 0;
+    if (listed && (o.n_shards > 1 || o.task_mask != 0x1f)) return MG_ERR_ARG; // one placement at a time
+    if (o.n_shards > 1 && o.task_mask != 0x1f) return MG_ERR_ARG;
+    if (o.n_devices < 0 || o.n_devices > 64) return MG_ERR_ARG;
     int count = 0, prev = 0;
     MG_HIP(hipGetDeviceCount(&count));
     MG_HIP(hipGetDevice(&prev));
-    for (int g = 0; g < n_devices; ++g)
-        if (devices[g] < 0 || devices[g] >= count) return MG_ERR_ARG;
+    if (!listed) {
+        if (o.exchange != 0) return MG_ERR_ARG; // a collective needs a device list
+        ProverImpl *p = new ProverImpl();
+        p->task_mask_ = o.task_mask;
+        const int rc = p->init(curve, pk, prev, o.shard, o.n_shards, o.full_table_bytes, 1);
+        if (rc) {
+            delete p;
+            return rc;
+        }
+        *out = p;
+        return MG_OK;
+    }
+    for (int g = 0; g < o.n_devices; ++g)
+        if (o.devices[g] < 0 || o.devices[g] >= count) return MG_ERR_ARG;
     ProverImpl *p0 = new ProverImpl();
     int rc = MG_OK;
-    for (int g = n_devices - 1; g >= 0 && !rc; --g) { // shard 0 last: it ends up the current device's context
+    for (int g = o.n_devices - 1; g >= 0 && !rc; --g) { // shard 0 last: it ends up the current device's context
         ProverImpl *p = g == 0 ? p0 : new ProverImpl();
-        if (g) p0->peers_.insert(p0->peers_.begin(), p);
-        rc = p->init(curve, pk, devices[g], (u32)g, (u32)n_devices);
+        if (g) p0->peers_.insert(p0->peers_.begin(), p), p->shard_owner_ = p0;
+        int same = 0;
+        for (int t = 0; t < o.n_devices; ++t) same += o.devices[t] == o.devices[g];
+        rc = p->init(curve, pk, o.devices[g], (u32)g, (u32)o.n_devices, o.full_table_bytes, same);
     }
+    if (!rc && o.exchange == 1) rc = p0->exchange_init();
     hipSetDevice(prev);
     if (rc) {
         delete p0;
@@ -1484,6 +1746,24 @@ int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, i
     }
     *out = p0;
     return MG_OK;
+}
+
+int prover_create(int curve, const mg_pk_view *pk, Prover **out) { return prover_create_ex(curve, pk, ProverOptions(), out); }
+int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out) {
+    ProverOptions o;
+    o.shard = shard, o.n_shards = n_shards;
+    return prover_create_ex(curve, pk, o, out);
+}
+int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **out) {
+    ProverOptions o;
+    o.task_mask = task_mask;
+    return prover_create_ex(curve, pk, o, out);
+}
+int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out) {
+    if (!devices || n_devices < 1) return MG_ERR_ARG;
+    ProverOptions o;
+    o.devices = devices, o.n_devices = n_devices;
+    return prover_create_ex(curve, pk, o, out);
 }
 
 } // namespace mg

@@ -71,6 +71,16 @@ class Prover {
     virtual int assemble(u64 k, u32 n_parts, const uint64_t *parts, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) = 0;
     virtual size_t slot_words() const = 0;
 };
+// how a context is placed and what it may spend (mg_ctx_opts of the C ABI)
+struct ProverOptions {
+    const int *devices = nullptr; // in-process range sharding over these devices (nullptr: the current device)
+    int n_devices = 0;
+    u32 shard = 0, n_shards = 1;  // process-per-GPU range sharding: this process holds shard `shard` of `n_shards`
+    u32 task_mask = 0x1f;         // task placement: the MSMs (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h) this context computes
+    int64_t full_table_bytes = -1; // HBM budget of the full tables; < 0: the default (a tenth of the device's HBM)
+    int exchange = 0;             // in-process sharding: 0 = partial points summed through pinned host memory, 1 = RCCL all_gather
+};
+int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Prover **out);
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);
 // every MSM of a proof range-sharded over the listed devices; devices may repeat
 int prover_create_sharded(int curve, const mg_pk_view *pk, const int *devices, int n_devices, Prover **out);
@@ -79,6 +89,7 @@ int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **
 // arkworks `ProvingKey::serialize_unchecked` bytes (ProvingContext::decode, groth16.rs:268-288)
 int prover_create_from_bytes(int curve, const uint8_t *bytes, size_t len, Prover **out, const int *devices = nullptr,
                              int n_devices = 0);
+int prover_create_from_bytes_ex(int curve, const uint8_t *bytes, size_t len, const ProverOptions &o, Prover **out);
 // Groth16 key generation from explicit toxic waste and group generators (setup.cpp)
 int groth16_setup(int curve, const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, u64 n_vars, u64 n_inputs,
                   const u64 *toxic5, const u64 *g1_gen, const u64 *g2_gen, const mg_pk_out *out);

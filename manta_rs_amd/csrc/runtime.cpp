@@ -21,6 +21,7 @@ void set_last_hip_error(hipError_t e, const char *expr, const char *file, int li
     std::snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, expr);
     g_last_error = buf;
 }
+void set_last_error_text(const char *text) { g_last_error = text ? text : ""; }
 const char *last_error_string() { return g_last_error.c_str(); }
 
 static bool g_kernel_timing = false;

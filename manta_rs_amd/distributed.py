@@ -42,7 +42,7 @@ class _Slot:
         self.recv = torch.zeros(world * words, dtype=torch.int64, device=dev)
         self.h_recv = torch.zeros(world * words, dtype=torch.int64).pin_memory()
         self.done = torch.cuda.Event()
-        self.busy = False
+        self.busy = False  # owned by a job from begin() until its wait() has copied h_recv out
 
 
 class PartialPointExchange:
@@ -82,10 +82,13 @@ class PartialPointExchange:
         t = self.torch.from_numpy(np.ascontiguousarray(local_point, dtype=np.uint64).view(np.int64))
         if self.on_gpu:  # nccl cannot gather host tensors: bounce through a device slot (plain bases only take this road)
             sl = self._acquire()
-            sl.send[:self.limbs].copy_(t, non_blocking=True)
-            self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)
-            out = sl.recv.cpu().numpy().view(np.uint64).reshape(self.world, self.words)[:, :self.limbs].copy()
-            sl.busy = False
+            try:
+                sl.send[:self.limbs].copy_(t, non_blocking=True)
+                self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)
+                # .cpu() waits for the gather on the current stream: the slot is ours until the copy below exists
+                out = sl.recv.cpu().numpy().view(np.uint64).reshape(self.world, self.words)[:, :self.limbs].copy()
+            finally:
+                sl.busy = False
             return out
         self.send.copy_(t)
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.pg)
@@ -99,12 +102,18 @@ class PartialPointExchange:
 
     # ------------------------------------------------------------------ device path
     def _acquire(self) -> _Slot:
-        sl = self.slots[self.next]
-        self.next = (self.next + 1) % len(self.slots)
-        if sl.busy:
-            sl.done.synchronize()
-        sl.busy = True
-        return sl
+        """The next buffer set of the ring. A set belongs to the job that began on it until that job's wait() has copied
+        the gathered points out of h_recv: the completion event only says the gather and the copy to pinned memory are done,
+        not that their owner has read them, so a set that is still owned is never handed out again -- more than `ring` jobs
+        in flight is a caller error and raises instead of overwriting an older job's result."""
+        for _ in range(len(self.slots)):
+            sl = self.slots[self.next]
+            self.next = (self.next + 1) % len(self.slots)
+            if not sl.busy:
+                sl.busy = True
+                return sl
+        raise RuntimeError("PartialPointExchange: all %d buffer sets are owned by unfinished jobs -- finish() one before "
+                           "launching another (or build the exchange with a larger ring)" % len(self.slots))
 
     def stream_handle(self) -> int:
         """the raw hipStream_t the collective will be enqueued on (torch's current stream)"""
@@ -120,10 +129,16 @@ class PartialPointExchange:
         sl.h_recv.copy_(sl.recv, non_blocking=True)
         sl.done.record()
 
-    def wait(self, sl: _Slot) -> np.ndarray:
-        """-> [world, words] uint64, once the gather and the copy have completed (the only host wait of the step)"""
+    def wait(self, sl: _Slot, words=None) -> np.ndarray:
+        """-> [world, words] uint64, once the gather and the copy have completed (the only host wait of the step). `words`
+        (<= the buffer's) = how many u64 per rank the producer actually wrote: the tail of a send buffer holds whatever an
+        earlier, larger pass left there and must never reach the consumer."""
         sl.done.synchronize()
-        out = sl.h_recv.numpy().view(np.uint64).reshape(self.world, self.words).copy()
+        w = self.words if words is None else int(words)
+        if w < 0 or w > self.words:
+            sl.busy = False
+            raise ValueError("PartialPointExchange.wait: words out of range")
+        out = sl.h_recv.numpy().view(np.uint64).reshape(self.world, self.words)[:, :w].copy()
         sl.busy = False
         return out
 
@@ -187,7 +202,9 @@ class ShardedProofJob:
         p = self.prover
         parts = self.parts
         if parts is None:
-            parts = p.exchange.wait(self.slot)  # [world, k * 5 * slot limbs]
+            # [world, k * 5 * slot limbs]: only what this pass wrote -- the send buffers are sized for max_batch proofs and
+            # the tail beyond k proofs still holds the partial points of whichever larger pass used the set before
+            parts = p.exchange.wait(self.slot, self.k * 5 * p.slot)
             p.ctx.partials_finish(self.job)
         return p.ctx.assemble(parts, self.rs, self.ss)
 

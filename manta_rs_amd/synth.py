@@ -14,6 +14,22 @@ the exact (D, V, P) of the real manta-pay shapes:
 Rows are a satisfiable mix of multiplication gates, boolean gates (b*(1-b)=0, giving the 0/1-heavy
 witness real circuits have) and linear gates. Pure Python big-int arithmetic + numpy packing; no
 dependency on the oracle.
+
+Witness profiles (`profile=` of make_circuit / make_shape; the density of z decides how much work four of a proof's
+five MSMs have -- arkworks and this library both skip zero scalars):
+
+    "sparse"  the round-1..3 generator: gate kinds drawn at random; multiplication gates over earlier variables
+              cascade zeros, so the RESULTING z is about 69 % zeros / 23 % ones / 8 % anything else -- a lower bound
+              on a proof's MSM work, kept for comparison
+    "W"       SURVEY.md 8(d) config 2's witness-like distribution enforced on the RESULTING z: 40 % zeros, 25 % ones,
+              10 % below 2^64, 25 % uniform field elements -- structurally: boolean gates (the zeros and ones),
+              bit-packing style linear gates over booleans with small coefficients (the small values) and
+              multiplication / linear gates over dense operands only (no zero can enter them), so every further
+              assignment of the same matrices (Reassigner) keeps the distribution
+    "dense"   SURVEY.md 8(d) config 1: a satisfiable multiplication chain over non-zero random values; 0 % trivial
+              scalars (z_0 = 1 aside) -- the upper bound on a proof's MSM work
+
+`histogram(z)` measures what was actually produced; bench.py prints it next to every proofs/s figure.
 """
 from __future__ import annotations
 
@@ -127,6 +143,7 @@ class Circuit:
     C: CSR
     z_int: list     # full assignment as python ints (canonical)
     z: np.ndarray   # uint64 [V, 4] Montgomery
+    profile: str = "sparse"  # witness profile the circuit was generated for (module docstring)
 
 
 def _pack_csr(rows, p, coeff_cache):
@@ -153,9 +170,186 @@ def _pack_csr(rows, p, coeff_cache):
     return CSR(row_ptr, np.asarray(cols, dtype=np.uint32), np.ascontiguousarray(val))
 
 
-def make_circuit(curve: int, m: int, V: int, P: int, seed: int = 0x4D414E5441_0001) -> Circuit:
-    """Satisfiable synthetic R1CS with m rows, V variables, P instance variables (z_0 = 1)."""
+PROFILES = ("sparse", "W", "dense")
+# the W profile's target shares of the resulting z: zeros, ones, below 2^64, uniform
+W_SHARES = (0.40, 0.25, 0.10, 0.25)
+
+
+def histogram(z_int) -> dict:
+    """Shares of an assignment that are 0 / 1 / another value below 2^64 / anything else (the four classes of SURVEY.md
+    8(d)'s W distribution; the number `rust/capture` writes next to a captured witness)."""
+    n = len(z_int)
+    zero = sum(1 for v in z_int if v == 0)
+    one = sum(1 for v in z_int if v == 1)
+    small = sum(1 for v in z_int if 1 < v < (1 << 64))
+    return {"n": n, "zero": zero / n, "one": one / n, "small": small / n, "dense": (n - zero - one - small) / n}
+
+
+def _finish_circuit(curve, m, V, P, A, B, C, z, profile):
+    p = FR_MODULUS[curve]
+    D = 1
+    while D < m + P:
+        D <<= 1
+    cache = {}
+    return Circuit(curve, m, P, V, D, _pack_csr(A, p, cache), _pack_csr(B, p, cache), _pack_csr(C, p, cache), z,
+                   to_mont(z, p, 4), profile)
+
+
+def _nonzero_field(rng, p):
+    v = rng.field(p)
+    return v if v else 1
+
+
+def _extra_rows(rng, p, A, B, C, m, nw, V, bools, coef):
+    """rows beyond the defining ones (m > V - P): identities over existing variables, satisfied by every assignment"""
+    for k in range(nw, m):
+        if bools and rng.below(2):
+            b = bools[rng.below(len(bools))]
+            A.append([(b, 1)])
+            B.append([(b, 1)])
+            C.append([(b, 1)])
+        else:
+            l, r = rng.below(V), rng.below(V)
+            c = coef()
+            row = [(l, 1), (r, c)] if l != r else [(l, (1 + c) % p)]
+            A.append(row)
+            B.append([(0, 1)])
+            C.append(list(row))
+
+
+def _make_dense(curve, m, V, P, seed):
+    """z[P + i] = (ca z[l]) (cb z[r]) over non-zero values -- a multiplication chain; every scalar of
+    every witness MSM is a full-width field element."""
+    p = FR_MODULUS[curve]
+    rng = XorShift(seed)
+    z = [0] * V
+    z[0] = 1
+    for j in range(1, P):
+        z[j] = _nonzero_field(rng, p)
+    A, B, C = [], [], []
+    nw = V - P
+    coeffs = [_nonzero_field(rng, p) for _ in range(8)]
+
+    def coef():
+        return 1 if rng.below(4) else coeffs[rng.below(8)]
+
+    for k in range(min(nw, m)):
+        v = P + k
+        # operands: the previous variable (the chain) and any earlier one; never z_0 on both sides (the product would be a
+        # bare coefficient -- still dense, but keep the chain a chain)
+        l = v - 1 if v - 1 >= 1 else 0
+        r = 1 + rng.below(v - 1) if v > 1 else 0
+        ca, cb = coef(), coef()
+        z[v] = (ca * z[l] % p) * (cb * z[r] % p) % p
+        assert z[v] != 0
+        A.append([(l, ca)])
+        B.append([(r, cb)])
+        C.append([(v, 1)])
+    _extra_rows(rng, p, A, B, C, m, nw, V, [], coef)
+    for k in range(m, nw):
+        z[P + k] = _nonzero_field(rng, p)
+    return _finish_circuit(curve, m, V, P, A, B, C, z, "dense")
+
+
+def _w_plan(V, P, nw_defined):
+    """kinds of the defined witness rows so that the RESULTING z (instance variables and z_0 included) meets W_SHARES
+    exactly: -> (#boolean zeros, #boolean ones, #small, #dense) among the nw_defined rows"""
+    want0 = round(W_SHARES[0] * V)
+    want1 = round(W_SHARES[1] * V) - 1  # z_0 = 1 is one of the ones
+    wants = round(W_SHARES[2] * V)
+    free = V - P - nw_defined           # undefined trailing variables (nw > m): filled dense
+    wantd = nw_defined - want0 - want1 - wants
+    assert want0 >= 0 and want1 >= 0 and wants >= 0 and wantd >= 0, "shape too small for the W shares"
+    _ = free
+    return want0, want1, wants, wantd
+
+
+def _make_w(curve, m, V, P, seed):
+    """SURVEY.md 8(d) config 2's W distribution on the resulting assignment; see the module docstring."""
+    p = FR_MODULUS[curve]
+    rng = XorShift(seed)
+    z = [0] * V
+    z[0] = 1
+    for j in range(1, P):
+        z[j] = _nonzero_field(rng, p)
+    A, B, C = [], [], []
+    nw = V - P
+    nd = min(nw, m)
+    coeffs = [_nonzero_field(rng, p) for _ in range(8)]
+
+    def coef():
+        return 1 if rng.below(4) else coeffs[rng.below(8)]
+
+    n0, n1, ns, ndense = _w_plan(V, P, nd)
+    # a random interleaving of the four kinds with exact counts (Fisher-Yates on the multiset)
+    kinds = [0] * n0 + [1] * n1 + [2] * ns + [3] * ndense
+    for i in range(len(kinds) - 1, 0, -1):
+        j = rng.below(i + 1)
+        kinds[i], kinds[j] = kinds[j], kinds[i]
+    # a small-value gate needs booleans before it and a dense gate prefers dense operands beyond the instance: make sure the
+    # first rows supply both kinds (swap them to the front; the multiset is unchanged)
+    for want_kind, pos in ((0, 0), (1, 1), (3, 2)):
+        if pos < len(kinds) and kinds[pos] != want_kind:
+            for j in range(pos + 1, len(kinds)):
+                if kinds[j] == want_kind:
+                    kinds[pos], kinds[j] = kinds[j], kinds[pos]
+                    break
+    bools, dense = [], list(range(1, P))  # variables known to be boolean / known to be non-zero field elements
+    for k in range(nd):
+        v = P + k
+        kind = kinds[k]
+        if kind <= 1:  # boolean witness: v (1 - v) = 0, value fixed by the plan
+            z[v] = kind
+            A.append([(v, 1)])
+            B.append([(0, 1), (v, p - 1)])
+            C.append([])
+            bools.append(v)
+        elif kind == 2 and bools:  # bit-packing style: z[v] = c0 + sum c_i b_i with small c: 1 < value < 2^64 whatever the bits
+            nt = 1 + rng.below(3)
+            terms = [(0, 2 + rng.below(1 << 60))]
+            for _ in range(nt):
+                terms.append((bools[rng.below(len(bools))], 1 + rng.below(1 << 60)))
+            row = {}
+            for i, cf in terms:
+                row[i] = row.get(i, 0) + cf
+            z[v] = sum(cf * z[i] for i, cf in row.items()) % p
+            assert 1 < z[v] < (1 << 64)
+            A.append(sorted(row.items()))
+            B.append([(0, 1)])
+            C.append([(v, 1)])
+        else:  # dense: product (or sum) of dense operands -- no zero can enter
+            if not dense:
+                dense.append(0)  # P = 1: only the constant is available
+            l, r = dense[rng.below(len(dense))], dense[rng.below(len(dense))]
+            ca, cb = coef(), coef()
+            if rng.below(4):
+                z[v] = (ca * z[l] % p) * (cb * z[r] % p) % p
+                A.append([(l, ca)])
+                B.append([(r, cb)])
+            else:  # linear gate; a sum of two dense values is zero with probability 1/p
+                z[v] = (ca * z[l] + cb * z[r]) % p
+                A.append([(l, ca), (r, cb)] if l != r else [(l, (ca + cb) % p)])
+                B.append([(0, 1)])
+            if z[v] == 0 or z[v] == 1 or z[v] < (1 << 64):  # (probability ~2^-190; keep the classes exact)
+                z[v] = (ca * z[l] % p) * (cb * z[r] % p) % p
+                A[-1], B[-1] = [(l, ca)], [(r, cb)]
+            C.append([(v, 1)])
+            dense.append(v)
+    _extra_rows(rng, p, A, B, C, m, nw, V, bools, coef)
+    for k in range(m, nw):
+        z[P + k] = _nonzero_field(rng, p)
+    return _finish_circuit(curve, m, V, P, A, B, C, z, "W")
+
+
+def make_circuit(curve: int, m: int, V: int, P: int, seed: int = 0x4D414E5441_0001, profile: str = "sparse") -> Circuit:
+    """Satisfiable synthetic R1CS with m rows, V variables, P instance variables (z_0 = 1); `profile`: module docstring."""
     assert V > P >= 1 and m >= 1
+    if profile == "dense":
+        return _make_dense(curve, m, V, P, seed)
+    if profile == "W":
+        return _make_w(curve, m, V, P, seed)
+    if profile != "sparse":
+        raise ValueError("profile is one of %r" % (PROFILES,))
     p = FR_MODULUS[curve]
     rng = XorShift(seed)
     z = [0] * V
@@ -243,12 +437,12 @@ class Reassigner:
         z = [0] * c.V
         z[0] = 1
         for j in range(1, c.P):
-            z[j] = rng.field(p)
+            z[j] = _nonzero_field(rng, p)
         nw = c.V - c.P
         for k in range(min(nw, c.m)):
             v = c.P + k
-            if not C[k]:  # boolean witness: v * (1 - v) = 0
-                z[v] = rng.below(2)
+            if not C[k]:  # boolean witness: v * (1 - v) = 0 (W profile: ones with the share that keeps 40 % / 25 %)
+                z[v] = (1 if rng.below(65) >= 40 else 0) if c.profile == "W" else rng.below(2)
             else:         # gate with output v: (sum A)(sum B) = z[v]
                 sa = sum(cf * z[i] for i, cf in A[k]) % p
                 sb = sum(cf * z[i] for i, cf in B[k]) % p
@@ -264,9 +458,9 @@ def reassign(c: Circuit, seed: int) -> Circuit:
     return Reassigner(c).assign(seed)
 
 
-def make_shape(curve: int, name: str, seed: int = 0x4D414E5441_0001) -> Circuit:
+def make_shape(curve: int, name: str, seed: int = 0x4D414E5441_0001, profile: str = "sparse") -> Circuit:
     D, V, P = SHAPES[name]
-    return make_circuit(curve, D - P, V, P, seed)
+    return make_circuit(curve, D - P, V, P, seed, profile)
 
 
 def check_satisfied(c: Circuit) -> bool:

@@ -201,10 +201,56 @@ impl<E: Mi355xCurve> Drop for GpuProvingContext<E> {
     }
 }
 
+/// How the partial points of a context sharded over several GPUs meet (`mg_ctx_opts.exchange`).
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Exchange {
+    /// through pinned host memory, summed on the host
+    Host,
+    /// folded on every GPU, one grouped `ncclAllGather` over xGMI inside the library (BASELINE north_star)
+    Rccl,
+}
+
+/// Per-context decisions (`mg_ctx_opts`). A signer holds three contexts at once (`MultiProvingContext`,
+/// `manta-accounting/src/transfer/canonical.rs:561-588`): what each may spend on its full tables is stated here, not in
+/// the environment.
+#[derive(Clone, Debug, Default)]
+pub struct ContextOptions<'d> {
+    /// `None` = the current HIP device; `Some(list)` range-shards every query over the listed GPUs
+    pub devices: Option<&'d [i32]>,
+    /// exchange of a sharded context; `None` = `Exchange::Host`
+    pub exchange: Option<Exchange>,
+    /// HBM the context may spend on full tables (single proofs run on them); `None` = a tenth of the device's HBM,
+    /// `Some(0)` = bucket tables only
+    pub full_table_bytes: Option<u64>,
+}
+
 impl<E: Mi355xCurve> GpuProvingContext<E> {
     /// Uploads `proving_key` (the library copies and re-lays everything; no pointer is retained). `devices`: `None`
     /// = the current HIP device; `Some(list)` range-shards every query over the listed GPUs (`mg_ctx_create_sharded`).
     pub fn new(proving_key: &ProvingKey<E>, devices: Option<&[i32]>) -> Result<Self, Error> {
+        Self::with_options(proving_key, &ContextOptions { devices, ..Default::default() })
+    }
+
+    fn abi_options(options: &ContextOptions<'_>) -> Result<sys::mg_ctx_opts, Error> {
+        let mut o = core::mem::MaybeUninit::<sys::mg_ctx_opts>::zeroed();
+        // SAFETY: mg_ctx_opts_init writes every field
+        check(unsafe { sys::mg_ctx_opts_init(o.as_mut_ptr()) })?;
+        let mut o = unsafe { o.assume_init() };
+        if let Some(d) = options.devices {
+            o.devices = d.as_ptr();
+            o.n_devices = d.len() as i32;
+        }
+        if let Some(x) = options.exchange {
+            o.exchange = if x == Exchange::Rccl { sys::MG_EXCHANGE_RCCL } else { sys::MG_EXCHANGE_HOST };
+        }
+        if let Some(b) = options.full_table_bytes {
+            o.full_table_bytes = b.min(i64::MAX as u64) as i64;
+        }
+        Ok(o)
+    }
+
+    /// [`new`](Self::new) with the placement, the exchange and the table budget stated (`mg_ctx_create_ex`).
+    pub fn with_options(proving_key: &ProvingKey<E>, options: &ContextOptions<'_>) -> Result<Self, Error> {
         let pk = proving_key;
         let alpha_g1 = flatten_g1::<E>(&[pk.vk.alpha_g1]);
         let beta_g1 = flatten_g1::<E>(&[pk.beta_g1]);
@@ -233,11 +279,27 @@ impl<E: Mi355xCurve> GpuProvingContext<E> {
         };
         let mut ctx = ptr::null_mut();
         // SAFETY: every pointer of `view` outlives the call; the library copies before returning
+        let opts = Self::abi_options(options)?;
+        // (`options.devices`, which `opts` points into, outlives the call as well)
+        check(unsafe { sys::mg_ctx_create_ex(E::CURVE, &view, &opts, &mut ctx) })?;
+        Ok(Self { ctx, shape: Mutex::new(None), _engine: PhantomData })
+    }
+
+    /// [`from_bytes`](Self::from_bytes) with options and, when `checksum` is given, manta-parameters' integrity check in
+    /// front of it whatever the placement (`mg_ctx_create_from_bytes_ex`).
+    pub fn from_bytes_with_options(bytes: &[u8], checksum: Option<&[u8; 32]>, options: &ContextOptions<'_>) -> Result<Self, Error> {
+        let opts = Self::abi_options(options)?;
+        let mut ctx = ptr::null_mut();
+        // SAFETY: `bytes`, `checksum` and the device list outlive the call
         check(unsafe {
-            match devices {
-                None => sys::mg_ctx_create(E::CURVE, &view, &mut ctx),
-                Some(d) => sys::mg_ctx_create_sharded(E::CURVE, &view, d.as_ptr(), d.len() as i32, &mut ctx),
-            }
+            sys::mg_ctx_create_from_bytes_ex(
+                E::CURVE,
+                bytes.as_ptr(),
+                bytes.len(),
+                checksum.map_or(ptr::null(), |c| c.as_ptr()),
+                &opts,
+                &mut ctx,
+            )
         })?;
         Ok(Self { ctx, shape: Mutex::new(None), _engine: PhantomData })
     }

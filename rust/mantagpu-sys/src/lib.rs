@@ -83,6 +83,23 @@ pub struct mg_pk_view {
 }
 
 /// One matrix of `ConstraintSystemRef::to_matrices()` in CSR form.
+/// `mg_ctx_opts`: what a deployment decides per context (placement, exchange, HBM budget of the full tables). Fill it with
+/// `mg_ctx_opts_init`, then change fields; `struct_size` lets the C side accept an older, shorter struct.
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct mg_ctx_opts {
+    pub struct_size: u32,
+    pub exchange: u32,
+    pub full_table_bytes: i64,
+    pub devices: *const c_int,
+    pub n_devices: i32,
+    pub shard: i32,
+    pub n_shards: i32,
+    pub task_mask: u32,
+}
+pub const MG_EXCHANGE_HOST: u32 = 0;
+pub const MG_EXCHANGE_RCCL: u32 = 1;
+
 #[repr(C)]
 pub struct mg_csr {
     pub row_ptr: *const u32,
@@ -229,6 +246,16 @@ extern "C" {
         out: *const mg_pk_out,
     ) -> c_int;
     pub fn mg_ctx_create(curve: mg_curve_t, pk: *const mg_pk_view, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_ctx_opts_init(opts: *mut mg_ctx_opts) -> c_int;
+    pub fn mg_ctx_create_ex(curve: mg_curve_t, pk: *const mg_pk_view, opts: *const mg_ctx_opts, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_ctx_create_from_bytes_ex(
+        curve: mg_curve_t,
+        bytes: *const u8,
+        len: usize,
+        checksum32: *const u8,
+        opts: *const mg_ctx_opts,
+        out: *mut *mut mg_ctx,
+    ) -> c_int;
     pub fn mg_ctx_create_sharded(
         curve: mg_curve_t,
         pk: *const mg_pk_view,

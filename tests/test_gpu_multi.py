@@ -89,6 +89,46 @@ assert O.groth16_verify(curve, pk, c.z[1:c.P], want) == 1
 zs = np.stack([c.z] * 3)
 got = sp.prove_batch(zs, rs[0:3], rs[3:6])
 assert got == api.Groth16.prove_batch(ctx, zs, rs[0:3], rs[3:6])
+# (advisor r3, high) a pass SMALLER than max_batch after larger ones have used every buffer set of the ring: the tail of the
+# send buffers still holds their partial points and must not reach the assembly
+for i in range(len(sp.exchange.slots)):
+    assert sp.prove_batch(zs, rs[0:3], rs[3:6]) == got
+for i in range(len(sp.exchange.slots) + 2):
+    assert sp.prove(c.z, rs[0], rs[1]) == api.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]), i
+assert sp.prove_batch(zs[:2], rs[0:2], rs[3:5]) == got[:2]
+# (advisor r3, low) a buffer set belongs to its job until finish(): more jobs than sets in flight raises, nothing is overwritten
+jobs = [sp.launch(c.z, rs[0], rs[1]) for _ in range(len(sp.exchange.slots))]
+try:
+    sp.launch(c.z, rs[0], rs[1])
+    raise SystemExit("a ninth job took a buffer set that was still owned")
+except RuntimeError:
+    pass
+want1 = api.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1])
+assert all(j.finish()[0] == want1 for j in jobs)
+# (advisor r3, medium) a lone range shard of more than one cannot prove on its own
+import pytest
+half = api.ProvingContext(curve, pk, shard=(0, 2))
+half.set_r1cs(r1cs)
+with pytest.raises(api.MantaGpuError) as ei:
+    api.Groth16.prove_with_randomness(half, c.z, rs[0], rs[1])
+assert ei.value.status == 5
+with pytest.raises(api.MantaGpuError):
+    api.Groth16.prove_batch(half, zs, rs[0:3], rs[3:6])
+half.close()
+# ---- RCCL INSIDE the library (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL, what the Rust host reaches through mg_ctx_create_ex): a
+# one-device list -> ncclCommInitAll of one rank, partial points folded on the GPU, grouped ncclAllGather, assembly; the
+# process already holds torch's librccl, which the library must pick up instead of loading a second one
+rc = api.ProvingContext(curve, pk, devices=[0], exchange=api.EXCHANGE_RCCL)
+rc.set_r1cs(r1cs)
+for i in range(4):
+    assert api.Groth16.prove_with_randomness(rc, c.z, rs[2 * i], rs[2 * i + 1]) == api.Groth16.prove_with_randomness(ctx, c.z, rs[2 * i], rs[2 * i + 1]), i
+assert api.Groth16.prove_batch(rc, zs, rs[0:3], rs[3:6]) == got
+z40 = np.stack([c.z] * 40)  # longer than a pass: streamed as passes in flight, each with its own exchange buffers
+rs40 = H.rand_fr_mont(curve, 80, seed=7)
+assert api.Groth16.prove_batch(rc, z40, rs40[:40], rs40[40:]) == api.Groth16.prove_batch(ctx, z40, rs40[:40], rs40[40:])
+rc.close()
+with pytest.raises(api.MantaGpuError):  # RCCL refuses one device twice in a clique: the host exchange serves such lists
+    api.ProvingContext(curve, pk, devices=[0, 0], exchange=api.EXCHANGE_RCCL)
 dist.barrier()
 dist.destroy_process_group()
 print("rccl one-rank ok")

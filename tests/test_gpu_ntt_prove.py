@@ -462,3 +462,88 @@ def test_groth16_setup_with_custom_generators(gpu, curve):
     bad[3] = 0  # gamma
     with pytest.raises(gpu.MantaGpuError):
         keygen.generate(c, bad)
+
+
+def test_in_library_rccl_exchange_without_torch(gpu):
+    """mg_ctx_opts.exchange = MG_EXCHANGE_RCCL in a process that has NOT loaded any RCCL yet (no torch.distributed): the library
+    dlopens librccl.so.1 itself, builds a one-rank clique over the device list [0] and runs the partial-point exchange inside
+    `mg_groth16_prove` -- bytes equal the oracle's and the host-exchange context's (caller
+    manta-accounting/src/transfer/mod.rs:695-715 -> groth16.rs:589-600)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, sys
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import oracle_lib as O, helpers as H
+from manta_rs_amd import api, synth
+assert "torch" not in sys.modules
+api.init(0)
+curve = api.BN254
+c = synth.make_circuit(curve, 700, 500, 9, seed=11, profile="W")
+pk = O.groth16_setup(c, H.toxic(curve))
+r1cs = api.R1CS.from_circuit(c)
+rs = H.rand_fr_mont(curve, 8, seed=5)
+rc = api.ProvingContext(curve, pk, devices=[0], exchange=api.EXCHANGE_RCCL)
+rc.set_r1cs(r1cs)
+for i in range(4):
+    assert api.Groth16.prove_with_randomness(rc, c.z, rs[2 * i], rs[2 * i + 1]) == O.groth16_prove(c, pk, rs[2 * i], rs[2 * i + 1]), i
+zs = np.stack([c.z] * 3)
+got = api.Groth16.prove_batch(rc, zs, rs[0:3], rs[3:6])
+assert got == [O.groth16_prove(c, pk, rs[q], rs[3 + q]) for q in range(3)]
+rc.close()
+print("in-library rccl ok")
+""" % (root, root)
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and "in-library rccl ok" in out.stdout, out.stdout[-3000:] + out.stderr[-3000:]
+
+
+def test_three_contexts_on_one_device_within_a_stated_budget(gpu):
+    """A signer holds three contexts at once -- `MultiProvingContext {to_private, private_transfer, to_public}`,
+    manta-accounting/src/transfer/canonical.rs:561-588: with `mg_ctx_opts.full_table_bytes` each states what it may spend on
+    its full tables. Three contexts of 4 GB each on one device: every one stays inside its budget, keeps
+    full tables (narrower windows than the default budget would buy), and proves the oracle's bytes; budget 0 = none."""
+    from manta_rs_amd import keygen
+    budget = 4 << 30
+    ctxs = []
+    for i, shape in enumerate(("to_private", "private_transfer", "to_public")):
+        c = synth.make_shape(0, shape, profile="W")
+        pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=60 + i), synth.FR_MODULUS[0]))
+        ctx = gpu.ProvingContext(0, pk, full_table_bytes=budget)
+        ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+        tb = ctx.table_bytes()
+        assert 0 < tb[1] <= budget, (shape, tb)
+        ctxs.append((c, pk, ctx))
+    O.set_threads(O.usable_cpus())
+    rs = H.rand_fr_mont(0, 2, seed=61)
+    for c, pk, ctx in ctxs:  # all three alive at once
+        want = O.groth16_prove(c, pk, rs[0], rs[1])
+        for _ in range(3):
+            assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) == want
+    c, pk, _ = ctxs[0]
+    none = gpu.ProvingContext(0, pk, full_table_bytes=0)
+    none.set_r1cs(gpu.R1CS.from_circuit(c))
+    assert none.table_bytes()[1] == 0 and none.table_bytes()[0] == ctxs[0][2].table_bytes()[0]
+    assert gpu.Groth16.prove_with_randomness(none, c.z, rs[0], rs[1]) == O.groth16_prove(c, pk, rs[0], rs[1])
+    none.close()
+    for _, _, ctx in ctxs:
+        ctx.close()
+
+
+def test_checksum_is_never_skipped_by_a_device_list(gpu):
+    """(advisor r3) `ProvingContext.decode(..., devices=[...], checksum=...)` used to fall through to the unchecked sharded
+    loader: the digest is now verified in front of every placement (`mg_ctx_create_from_bytes_ex`)."""
+    c = synth.make_circuit(0, 100, 70, 5, seed=3)
+    pk = O.groth16_setup(c, H.toxic(0))
+    data = _pk_bytes(0, pk)
+    good = gpu.blake3(data)
+    for devices in (None, [0], [0, 0]):
+        ctx = gpu.ProvingContext.decode(0, data, devices=devices, checksum=good)
+        ctx.close()
+        with pytest.raises(gpu.MantaGpuError) as ei:
+            gpu.ProvingContext.decode(0, data, devices=devices, checksum=bytes(32))
+        assert ei.value.status == 6
+    with pytest.raises(ValueError):
+        gpu.ProvingContext.decode(0, data, devices=[0], checksum=b"short")
