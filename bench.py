@@ -496,7 +496,7 @@ def config2_bench(env, log_d=20):
     curve, D, P = 1, 1 << log_d, 16
     p = synth.FR_MODULUS[curve]
     t0 = time.perf_counter()
-    c = synth.make_circuit(curve, D - P, D, P, seed=0x4D414E5441_0301)
+    c = synth.make_circuit(curve, D - P, D, P, seed=0x4D414E5441_0301, profile="W")  # the witness-like 40 / 25 / 10 / 25 split
     rng = synth.XorShift(0x4D414E5441_0302)
     pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
     ctx = api.ProvingContext(curve, pk)
@@ -522,7 +522,9 @@ def config2_bench(env, log_d=20):
     api.set_kernel_timing(False)
     ctx.close()
     z.free()
+    hist = synth.histogram(c.z_int)
     return {"workload": "one Groth16 proof, BLS12-381, D = V = 2^%d, P = 16: 3 SpMV + 7 NTT of 2^%d + 4 G1 MSM + 1 G2 MSM of ~2^%d terms" % (log_d, log_d, log_d),
+            "witness_profile": "W", "z_histogram": {k: (round(v, 4) if k != "n" else v) for k, v in hist.items()},
             "prove_ms": round(min(ts) * 1e3, 3), "prove_ms_median": round(float(np.median(ts)) * 1e3, 3), "proofs_per_s": round(1 / min(ts), 2),
             "phases_ms": phases,
             "phases_note": "HIP events between the phases of one proof enqueued with plain launches (the timed runs above replay captured "
@@ -539,7 +541,7 @@ def sharded_proof_bench(args, env):
     from manta_rs_amd import api, synth, keygen, distributed
     curve = synth.BN254
     p = synth.FR_MODULUS[curve]
-    c = synth.make_shape(curve, "private_transfer")
+    c = synth.make_shape(curve, "private_transfer", profile="W")
     rng = synth.XorShift(0x4D414E5441_0002)
     pk = keygen.generate(c, [rng.field(p) for _ in range(5)])  # the same key on every rank (same seed)
     K = 32
@@ -618,14 +620,15 @@ def _assign_worker(seed):
     return _REASSIGNER.assign(seed).z
 
 
-def precompute_assignments(shape, K):
+def precompute_assignments(shape, K, profile="W"):
     """K independent satisfying assignments of the shape's circuit (z_0 = the circuit's own, z_j from
-    seed ...1000+j: fresh public inputs, fresh boolean witnesses, every gate output recomputed). ~0.1 s of Python each, so
-    they are made by a fork pool -- before this process touches the GPU (a forked HIP context is not usable)."""
+    seed ...1000+j: fresh public inputs, fresh boolean witnesses, every gate output recomputed; the witness profile's density is
+    kept, synth.Reassigner). ~0.1 s of Python each, so they are made by a fork pool -- before this process touches the GPU (a
+    forked HIP context is not usable)."""
     global _REASSIGNER
     import multiprocessing as mp
     from manta_rs_amd import synth
-    c = synth.make_shape(synth.BN254, shape)
+    c = synth.make_shape(synth.BN254, shape, profile=profile)
     _REASSIGNER = synth.Reassigner(c)
     try:
         procs = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -638,13 +641,14 @@ def precompute_assignments(shape, K):
 
 
 class ProveSetup:
-    def __init__(self, shape):
+    def __init__(self, shape, profile="W"):
         from manta_rs_amd import api, synth, keygen
-        self.api, self.synth, self.shape = api, synth, shape
+        self.api, self.synth, self.shape, self.profile = api, synth, shape, profile
         curve = self.curve = synth.BN254
         p = self.p = synth.FR_MODULUS[curve]
         t0 = time.perf_counter()
-        self.c, self.zs = _DISTINCT[shape] if shape in _DISTINCT else (synth.make_shape(curve, shape), None)
+        self.c, self.zs = _DISTINCT[shape] if shape in _DISTINCT else (synth.make_shape(curve, shape, profile=profile), None)
+        assert self.c.profile == profile
         self.rng = synth.XorShift(0x4D414E5441_0002)
         toxic = [self.rng.field(p) for _ in range(5)]
         self.pk = keygen.generate(self.c, toxic)
@@ -722,14 +726,72 @@ class ProveSetup:
             [t.join() for t in ts]
         return out
 
-    def timed(self, env, steps, threads, K):
+    def timed(self, env, steps, threads, K, reps=1):
+        """-> (seconds of the MEDIAN repetition of `steps` proofs, the proofs of the last one, [seconds of every repetition]).
+        Thread legs vary by +-15 % from run to run (which calls a pass happens to coalesce), so they are repeated and the line
+        carries median, min and max."""
         # slots capture their graphs on the 3rd call; coalesced single calls use one slot per pass size (2 .. threads)
         self.run(max(4 * K * threads, 8) if threads <= 2 else 60 * threads, threads, K)
-        env.barrier()
-        t0 = time.perf_counter()
-        proofs = self.run(steps, threads, K)
-        env.barrier()
-        return env.max_over_ranks(time.perf_counter() - t0), proofs
+        dts, proofs = [], None
+        for _ in range(reps):
+            env.barrier()
+            t0 = time.perf_counter()
+            proofs = self.run(steps, threads, K)
+            env.barrier()
+            dts.append(env.max_over_ranks(time.perf_counter() - t0))
+        return float(np.median(dts)), proofs, dts
+
+
+def _rate_stats(env, n, dts, extra=None):
+    """proofs/s of the median repetition, with the spread"""
+    rates = sorted(env.world * n / d for d in dts)
+    out = {"proofs_per_s": round(float(np.median(rates)), 2), "repetitions": len(dts), "min": round(rates[0], 2), "max": round(rates[-1], 2)}
+    if extra:
+        out.update(extra)
+    return out
+
+
+BN254_MADS_G1_MIXED_ADD = 6 * 171 + 2 * 135 + 252   # 9 x 29-bit limbs: 2K^2+K per product, squarings K(K+1)/2+K^2+K, one fused a*b+c*d (3K^2+K)
+BN254_MADS_G2_MIXED_ADD = (6 * 3 + 2 * 2) * 171 + 3 * 252  # over Fp2: 3 base products per product (Karatsuba), 2 per squaring, the fused one x 3
+
+
+def proof_work_model(c, cw=11):
+    """Mixed additions of ONE proof's five accumulate kernels on the wide bucket tables batched passes use (z queries c = cw
+    signed windows, h query c = log2(D) - 2), counted on the assignment actually proved: non-zero signed digits of every
+    scalar whose base is not the point at infinity (a variable absent from A / B has an infinity entry in the query and is
+    dropped when the key is loaded). Merges and bucket reduces are left out: the figure is a LOWER bound on the work, the
+    rate derived from it an UPPER bound."""
+    from manta_rs_amd import synth
+    r = synth.FR_MODULUS[c.curve]
+    bits = synth.FR_BITS[c.curve]
+
+    def nz_digits(v, cc):
+        if v > r - v:
+            v = r - v
+        n, carry, half, mask = 0, 0, 1 << (cc - 1), (1 << cc) - 1
+        for _ in range(-(-bits // cc)):
+            d = (v & mask) + carry
+            v >>= cc
+            carry = 1 if d > half else 0
+            n += 1 if (d != 0 and d != (1 << cc)) else 0
+        return n
+    V, P = c.V, c.P
+    in_a = np.zeros(V, dtype=bool)
+    in_a[np.asarray(c.A.col)] = True
+    in_a[:P] = True  # input-consistency rows
+    in_b = np.zeros(V, dtype=bool)
+    in_b[np.asarray(c.B.col)] = True
+    dig = [nz_digits(v, cw) if v else 0 for v in c.z_int]
+    a = sum(dig[i] for i in range(1, V) if in_a[i])
+    b = sum(dig[i] for i in range(1, V) if in_b[i])
+    l = sum(dig[P:])
+    ch = max(8, min(14, c.D.bit_length() - 1 - 2))
+    h = int(c.D * (-(-bits // ch)) * (1 - 2.0 ** -ch))  # h is a dense vector of D coefficients
+    g1, g2 = a + b + l + h, b
+    return {"g1_mixed_additions": int(g1), "g2_mixed_additions": int(g2), "per_msm": {"a": int(a), "b_g1": int(b), "b_g2": int(b), "l": int(l), "h": h},
+            "mads_per_proof": int(g1 * BN254_MADS_G1_MIXED_ADD + g2 * BN254_MADS_G2_MIXED_ADD),
+            "model": "non-zero %d-bit signed digits of z over the non-infinity entries of a / b / l (h: %d-bit windows, dense) x %d multiply-adds per "
+                     "G1 mixed addition, %d per G2 one; merges and bucket reduces not counted" % (cw, ch, BN254_MADS_G1_MIXED_ADD, BN254_MADS_G2_MIXED_ADD)}
 
 
 def verify_bench(ps, proofs, zs=None):
@@ -769,6 +831,7 @@ def verify_bench(ps, proofs, zs=None):
 
 
 def prove_cpu_baseline(ps, proofs, ncpu=8):
+    ncpu = min(ncpu, len(proofs))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O  # checker, here as the timed CPU baseline (and a free byte-parity check)
     c, pk, rs, nrs = ps.c, ps.pk, ps.rs, ps.nrs
@@ -794,44 +857,57 @@ def prove_cpu_baseline(ps, proofs, ncpu=8):
             **host_info()}
 
 
-def prove_bench(args, env, shape="private_transfer", full=True):
-    """The proofs/s half of the metric. full: sequential / 2 threads / batches of 256 (N = 1); else only the batched stream."""
-    ps = ProveSetup(shape)
+def prove_bench(args, env, shape="private_transfer", full=True, profile="W", lite=False):
+    """The proofs/s half of the metric on one witness profile. full: sequential / 2 / 6 threads / batches of 256 (N = 1); lite: the
+    same without the two-thread leg and verification (the profiles next to the headline one); else only the batched stream."""
+    ps = ProveSetup(shape, profile)
     D, V, P = ps.synth.SHAPES[shape]
     first = ps.api.Groth16.prove_with_randomness(ps.ctx, ps.c.z, ps.rs[0][0], ps.rs[0][1])
+    hist = ps.synth.histogram(ps.c.z_int)
     res = {"metric": f"Groth16 proofs/sec (manta-pay {shape} shape)", "unit": "proofs/s", "dtype": "u32", "data": "synthetic",
-           "workload": f"Groth16 prove, shape-exact synthetic {shape} circuit (D={D}, V={V}, P={P}), BN254, valid key, "
-                       "assignment in page-locked memory; a step = one proof incl. H2D of z and the 128 proof bytes out",
+           "workload": f"Groth16 prove, shape-exact synthetic {shape} circuit (D={D}, V={V}, P={P}), BN254, valid key, witness profile "
+                       f"'{profile}', assignment in page-locked memory; a step = one proof incl. H2D of z and the 128 proof bytes out",
+           "witness_profile": profile,
+           "z_histogram": {k: (round(v, 4) if k != "n" else v) for k, v in hist.items()},
+           "z_histogram_note": "shares of the assignment PROVED (synth.histogram of the first of the distinct assignments; the others keep the "
+                               "profile): 0 / 1 / other values below 2^64 / anything else. Zero scalars cost nothing, ones one addition, dense ones "
+                               "a full set of windows -- arkworks and this library alike",
            "setup_s": round(ps.setup_s, 2)}
     try:
         tb = ps.ctx.table_bytes()
         res["key_tables_hbm_bytes"] = {"bucket_tables": tb[0], "full_tables": tb[1],
                                        "note": "full tables = every multiple of every window of the five queries; passes of ONE proof run on them "
-                                               "(no sort, no bucket reduce), batched passes on the bucket tables; MANTA_FULL_TABLE_GB bounds them per query"}
+                                               "(no sort, no bucket reduce), batched passes on the bucket tables; budget = mg_ctx_opts.full_table_bytes, "
+                                               "default a tenth of the device's HBM per context"}
     except Exception as e:  # noqa: BLE001
         res["key_tables_hbm_bytes"] = {"error": str(e)}
     proofs = None
-    if full:
+    if full or lite:
         n1 = max(20, min(100, args.steps * 5))
-        dt, proofs = ps.timed(env, n1, 1, 1)
+        dt, proofs, dts = ps.timed(env, n1, 1, 1, reps=3)
         assert proofs[0] == first
-        res["sequential"] = {"proofs_per_s": round(env.world * n1 / dt, 2), "ms_per_proof": round(dt / n1 * 1e3, 4), "host_threads": 1, "proofs_per_call": 1}
+        res["sequential"] = _rate_stats(env, n1, dts, {"ms_per_proof": round(dt / n1 * 1e3, 4), "host_threads": 1, "proofs_per_call": 1})
+        try:
+            res["sequential"]["host_side_of_the_last_pass_ms"] = ps.api.last_pass_host_ms()
+        except Exception:  # noqa: BLE001
+            pass
         n2 = 3 * n1
-        dt, _ = ps.timed(env, n2, 2, 1)
-        res["two_threads"] = {"proofs_per_s": round(env.world * n2 / dt, 2), "host_threads": 2, "proofs_per_call": 1}
-        dt, _ = ps.timed(env, 2 * n2, 6, 1)  # the reference's simulation: six signer threads on one context (simulation.rs:36-38)
-        res["six_threads"] = {"proofs_per_s": round(env.world * 2 * n2 / dt, 2), "host_threads": 6, "proofs_per_call": 1,
-                              "note": "concurrent single calls are coalesced into batched passes by the library"}
+        if full:
+            dt, _, dts = ps.timed(env, n2, 2, 1, reps=3)
+            res["two_threads"] = _rate_stats(env, n2, dts, {"host_threads": 2, "proofs_per_call": 1})
+        dt, _, dts = ps.timed(env, 2 * n2, 6, 1, reps=3)  # the reference's simulation: six signer threads on one context (simulation.rs:36-38)
+        res["six_threads"] = _rate_stats(env, 2 * n2, dts, {"host_threads": 6, "proofs_per_call": 1,
+                                                             "note": "concurrent single calls are coalesced into batched passes by the library"})
     # configs[4]: batches of 256 proofs streamed through per-GPU pipelines -- one mg_groth16_prove_batch call per batch (the
     # library runs it as passes of ~29 proofs, three in flight); two host threads keep a second batch queued behind the first
     K = 256
     nb = K * (4 if full else 2)
-    dt, pb = ps.timed(env, nb, 2, K)
+    dt, pb, dts = ps.timed(env, nb, 2, K, reps=2 if (full or lite) else 1)
     assert pb[0] == first
-    res["batched"] = {"proofs_per_s": round(env.world * nb / dt, 2), "host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,
+    res["batched"] = _rate_stats(env, nb, dts, {"host_threads": 2, "proofs_per_call": K, "proofs": env.world * nb,
                       "ms_per_proof": round(dt / nb * 1e3, 4),
                       "assignments": ("%d distinct satisfying assignments per call (fresh public inputs and witnesses, synth.Reassigner), "
-                                      "distinct (r, s) per proof" % K) if ps.distinct(K) else "one assignment repeated, distinct (r, s) per proof"}
+                                      "distinct (r, s) per proof" % K) if ps.distinct(K) else "one assignment repeated, distinct (r, s) per proof"})
     res["value"] = res["batched"]["proofs_per_s"]
     if full:  # SURVEY f-2: `Groth16::verify` on the GPU -- one proof at a time and 256 at once by random linear combination
         res["verify"] = verify_bench(ps, pb, ps.zs if ps.distinct(K) else None)
@@ -847,8 +923,20 @@ def prove_bench(args, env, shape="private_transfer", full=True):
                        "algorithmic_bytes_per_proof_without_spmv": algo_bytes, "frac_without_spmv": round(algo_bytes * res["value"] / 1e9 / (HBM_PEAK_GBPS * env.world), 6),
                        "spmv_nnz": nnz,
                        "note": "whole-proof algorithmic bytes (SURVEY.md 8(d)) incl. the SpMV term of the synthetic circuit (%d non-zeros; the survey's "
-                               "~68 MB assumed ~0.5 M of them); integer-multiply and latency bound" % nnz}
-    res["_cpu_todo"] = (ps, proofs if proofs else pb) if (env.rank == 0 and env.world == 1 and not args.no_cpu_baseline) else None
+                               "~68 MB assumed ~0.5 M of them); integer-multiply and latency bound: int_mad is the bound that governs" % nnz}
+    if env.world == 1 and (full or lite):
+        # the bound that governs: multiply-adds of the accumulate kernels of one proof against the issue peak measured NOW
+        try:
+            work = proof_work_model(ps.c)
+            mhz, mad_per_us, _ = ps.api.clock_probe(60000)
+            peak = mad_per_us * 1e6 * 1024 * 64 / 1e12
+            bound = peak * 1e12 / work["mads_per_proof"]
+            res["roofline"]["int_mad"] = dict(work, peak_Tmad_s=round(peak, 2), probe_MHz=round(mhz, 1),
+                                              bound_proofs_per_s=round(bound, 1), batched_frac_of_bound=round(res["value"] / bound, 3),
+                                              peak_how="issue rate measured in this run by mg_clock_probe x 1024 SIMDs x 64 lanes (no clock assumed)")
+        except Exception as e:  # noqa: BLE001
+            res["roofline"]["int_mad"] = {"error": str(e)}
+    res["_cpu_todo"] = (ps, proofs if proofs else pb, 8 if profile != "dense" else 4) if (env.rank == 0 and env.world == 1 and not args.no_cpu_baseline) else None
     ps.release_gpu()  # the CPU baseline needs the host-side circuit / key / randomness only
     return res
 
@@ -887,7 +975,28 @@ def prove_leg_in_child(args, env):
     if out.returncode != 0 or not lines:
         raise RuntimeError("proofs leg failed on rank %d:\n%s" % (env.rank, out.stdout[-2000:] + out.stderr[-2000:]))
     res = json.loads(lines[-1])
-    if env.world == 1 and not args.quick:  # SURVEY a-11: the other two shapes of the reference's benches, batched stream only
+    if env.world == 1 and not args.quick:
+        # the same legs on the other two witness profiles (their own circuits, keys and 256 distinct assignments
+        # each, every one in a child process of its own like the headline profile); `proofs.value` is the W profile's batched rate
+        def summary(r):
+            keep = ("z_histogram", "sequential", "two_threads", "six_threads", "batched", "cpu_baseline", "speedup_vs_cpu_1_thread",
+                    "speedup_vs_cpu_all_cores", "key_tables_hbm_bytes", "setup_s")
+            out = {k: r[k] for k in keep if k in r}
+            if "roofline" in r and "int_mad" in r["roofline"]:
+                out["int_mad"] = r["roofline"]["int_mad"]
+            return out
+        res["witness_profiles"] = {"W": summary(res)}
+        for prof in ("sparse", "dense"):
+            c3 = cmd[:2] + ["--workload", "prove", "--child", "--profile", prof, "--lite", "--gpus", "1", "--steps", str(args.steps),
+                            "--warmup", str(args.warmup)] + (["--no-cpu-baseline"] if args.no_cpu_baseline else [])
+            o3 = subprocess.run(c3, env=cenv, capture_output=True, text=True)
+            l3 = [ln for ln in o3.stdout.splitlines() if ln.startswith("{")]
+            res["witness_profiles"][prof] = summary(json.loads(l3[-1])) if (o3.returncode == 0 and l3) else {"error": (o3.stdout[-500:] + o3.stderr[-800:])}
+        res["witness_profiles"]["note"] = ("sparse = the generator of rounds 1-3 (multiplication gates cascade zeros: ~69 % zeros / 23 % ones -- a lower bound on "
+                                           "the MSM work), W = SURVEY.md 8(d) config 2's 40 / 25 / 10 / 25 split enforced on the resulting z (the headline: "
+                                           "proofs.value), dense = config 1's multiplication chain, no trivial scalar (the upper bound). No real "
+                                           "`private_transfer::prove` witness can be captured in this image (rust/capture writes its histogram the day it runs)")
+        # SURVEY a-11: the other two shapes of the reference's benches, batched stream only
         res["shapes"] = {}
         for shape in ("to_private", "to_public"):
             o2 = subprocess.run(cmd[:2] + ["--workload", "prove", "--child", "--shape", shape, "--batched-only", "--no-cpu-baseline", "--gpus", "1",
@@ -923,14 +1032,18 @@ def main():
                     help="both (default) = the MSM line with the proofs half inside it; msm = configs[1] only; prove = a "
                          "proofs/s line of its own for --shape")
     ap.add_argument("--shape", default="private_transfer", choices=["to_private", "to_public", "private_transfer"])
+    ap.add_argument("--profile", default="W", choices=["sparse", "W", "dense"],
+                    help="witness profile of the proofs legs (manta_rs_amd/synth.py); the headline is W")
+    ap.add_argument("--lite", action="store_true", help=argparse.SUPPRESS)          # internal: sequential / six threads / batched only
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)         # internal: print the proofs object only
     ap.add_argument("--batched-only", action="store_true", help=argparse.SUPPRESS)  # internal: skip the single-proof legs
     args = ap.parse_args()
     if args.workload == "prove" and not args.batched_only and os.environ.get("MANTA_BENCH_DISTINCT", "1") != "0":
-        precompute_assignments(args.shape, 256)  # before anything initialises HIP in this process
+        precompute_assignments(args.shape, 256, args.profile)  # before anything initialises HIP in this process
     env = Env(args)
     if args.workload == "prove":
-        res = prove_bench(args, env, args.shape, full=env.world == 1 and not args.batched_only)
+        res = prove_bench(args, env, args.shape, full=env.world == 1 and not args.batched_only and not args.lite, profile=args.profile,
+                          lite=args.lite and env.world == 1)
         finish_cpu_baselines({"proofs": res})
         if args.child:
             print(json.dumps(res), flush=True)

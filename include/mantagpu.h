@@ -86,6 +86,10 @@ float mg_last_accumulate_mhz(void); /* the shader clock that launch ran at: s_me
 int mg_clock_probe(unsigned iters, double *memtime_mhz, double *mad_issue_per_us_per_simd, double *ms);
 int mg_last_ntt_ms(float out4[4]);
 int mg_last_prove_phases_ms(float out10[10]);
+/* Always on (three clock reads per pass): the HOST side of the calling thread's last proving pass on an unsharded context --
+ * out3 = { staging z and enqueuing the pass (graph launches or ~100 kernel launches), waiting for the GPU, assembly after the
+ * last MSM result arrived } in ms. A pass whose first figure approaches its wall time is bound by launches, not by kernels. */
+int mg_last_pass_host_ms(float out3[3]);
 
 /* ---- variable-base MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars)
  *      (ark-ec 0.3.0 msm/variable_base.rs; called 5x per proof from ark-groth16 create_proof, reached

@@ -69,7 +69,7 @@ EXPORTS = [
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
     "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
-    "mg_ctx_opts_init", "mg_ctx_create_ex", "mg_ctx_create_from_bytes_ex",
+    "mg_ctx_opts_init", "mg_ctx_create_ex", "mg_ctx_create_from_bytes_ex", "mg_last_pass_host_ms",
 ]
 
 
@@ -141,6 +141,13 @@ def last_prove_phases_ms():
     names = ("upload_z", "witness_map", "msm_a", "msm_b_g1", "msm_b_g2", "msm_l", "msm_h", "part_a_upload_to_join", "g2_chain_upload_to_end",
              "host_assembly_after_gpu")
     return {n: round(float(x), 4) for n, x in zip(names, v)}
+
+
+def last_pass_host_ms():
+    """host side of this thread's last proving pass: ms spent enqueuing, waiting for the GPU, assembling (`mg_last_pass_host_ms`)"""
+    v = (ctypes.c_float * 3)()
+    _chk(LIB.mg_last_pass_host_ms(v), "mg_last_pass_host_ms")
+    return {"enqueue": round(float(v[0]), 4), "wait_gpu": round(float(v[1]), 4), "assemble": round(float(v[2]), 4)}
 
 
 def synchronize():

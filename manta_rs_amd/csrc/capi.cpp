@@ -113,6 +113,11 @@ MG_API int mg_last_ntt_ms(float out4[4]) {
     get_last_ntt_ms(out4);
     return MG_SUCCESS;
 }
+MG_API int mg_last_pass_host_ms(float out3[3]) {
+    if (!out3) return MG_ERROR_INVALID_ARGUMENT;
+    get_last_pass_host_ms(out3);
+    return MG_SUCCESS;
+}
 MG_API int mg_last_prove_phases_ms(float out10[10]) {
     if (!out10) return MG_ERROR_INVALID_ARGUMENT;
     get_last_prove_ms(out10);

@@ -55,6 +55,8 @@ float last_accumulate_mhz();
 // the G2 MSM) from upload to join, [8] G2 MSM from upload to its end, [9] host assembly after the GPU (ms)
 void set_last_ntt_ms(const float v[4]);
 void get_last_ntt_ms(float v[4]);
+void set_last_pass_host_ms(const float v[3]); // host side of the calling thread's last pass: enqueue, wait for the GPU, assembly
+void get_last_pass_host_ms(float v[3]);
 void set_last_prove_ms(const float v[10]);
 void get_last_prove_ms(float v[10]);
 // process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)

@@ -1124,7 +1124,9 @@ class ProverImpl : public Prover {
         int rc = MG_OK;
         for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
+        const auto t_enq = std::chrono::steady_clock::now();
         if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list);
+        p.enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enq).count();
         return finish_pass(p, rc, &pp);
     }
 
@@ -1133,6 +1135,7 @@ class ProverImpl : public Prover {
         u32 k = 0;
         const uint64_t *r = nullptr, *s = nullptr;
         uint8_t *out = nullptr;
+        float enqueue_ms = 0.f;
     };
 
     static bool is_page_locked(const void *p) {
@@ -1660,6 +1663,7 @@ class ProverImpl : public Prover {
             }
         };
         // ---- part A is back: the G1 side of the assembly runs while the G2 MSM finishes
+        const auto t_wait0 = std::chrono::steady_clock::now();
         collect(w->stream, true); // every G1 MSM stream has been joined into it
         if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
         // ---- part B: the G2 element
@@ -1674,6 +1678,7 @@ class ProverImpl : public Prover {
             hipEventElapsedTime(&phases[8], w->tev[0], w->tev[14]);
         }
         const auto t_host = std::chrono::steady_clock::now();
+        const float wait_ms = std::chrono::duration<float, std::milli>(t_host - t_wait0).count();
         ws_release(w);
         p.w = nullptr;
         if (peer_passes)
@@ -1684,6 +1689,10 @@ class ProverImpl : public Prover {
             }
         if (rc) return rc;
         assemble_g2(k, res.data(), bl.data(), p.out);
+        {
+            const float hv[3] = {p.enqueue_ms, wait_ms, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host).count()};
+            set_last_pass_host_ms(hv);
+        }
         if (timed) {
             phases[9] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host).count();
             set_last_prove_ms(phases);

@@ -36,6 +36,9 @@ float last_accumulate_mhz() { return g_last_acc_mhz; }
 static thread_local float g_last_ntt_ms[4] = {0, 0, 0, 0}, g_last_prove_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 void set_last_ntt_ms(const float v[4]) { std::memcpy(g_last_ntt_ms, v, sizeof(g_last_ntt_ms)); }
 void get_last_ntt_ms(float v[4]) { std::memcpy(v, g_last_ntt_ms, sizeof(g_last_ntt_ms)); }
+static thread_local float g_last_pass_host_ms[3] = {0, 0, 0};
+void set_last_pass_host_ms(const float v[3]) { std::memcpy(g_last_pass_host_ms, v, sizeof(g_last_pass_host_ms)); }
+void get_last_pass_host_ms(float v[3]) { std::memcpy(v, g_last_pass_host_ms, sizeof(g_last_pass_host_ms)); }
 void set_last_prove_ms(const float v[10]) { std::memcpy(g_last_prove_ms, v, sizeof(g_last_prove_ms)); }
 void get_last_prove_ms(float v[10]) { std::memcpy(v, g_last_prove_ms, sizeof(g_last_prove_ms)); }
 

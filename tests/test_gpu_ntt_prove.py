@@ -503,10 +503,10 @@ print("in-library rccl ok")
 def test_three_contexts_on_one_device_within_a_stated_budget(gpu):
     """A signer holds three contexts at once -- `MultiProvingContext {to_private, private_transfer, to_public}`,
     manta-accounting/src/transfer/canonical.rs:561-588: with `mg_ctx_opts.full_table_bytes` each states what it may spend on
-    its full tables. Three contexts of 4 GB each on one device: every one stays inside its budget, keeps
+    its full tables. Three contexts of 12 GB each on one device: every one stays inside its budget, keeps
     full tables (narrower windows than the default budget would buy), and proves the oracle's bytes; budget 0 = none."""
     from manta_rs_amd import keygen
-    budget = 4 << 30
+    budget = 12 << 30
     ctxs = []
     for i, shape in enumerate(("to_private", "private_transfer", "to_public")):
         c = synth.make_shape(0, shape, profile="W")

@@ -9,7 +9,7 @@ K = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 curve = 0
 p = synth.FR_MODULUS[curve]
-c = synth.make_shape(curve, "private_transfer")
+c = synth.make_shape(curve, "private_transfer", profile=os.environ.get("PROFILE", "sparse"))
 rng = synth.XorShift(5)
 pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
 ctx = api.ProvingContext(curve, pk)

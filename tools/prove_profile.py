@@ -6,7 +6,7 @@ api.init(0)
 shape = sys.argv[1] if len(sys.argv) > 1 else "private_transfer"
 curve = 0
 p = synth.FR_MODULUS[curve]
-c = synth.make_shape(curve, shape)
+c = synth.make_shape(curve, shape, profile=os.environ.get("PROFILE", "sparse"))
 rng = synth.XorShift(5)
 pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
 ctx = api.ProvingContext(curve, pk)
