@@ -42,7 +42,7 @@ template <class F, int A, int B> MG_DEV Bv<F, F::BM> operator*(const Bv<F, A> &a
 }
 template <class F, int A> MG_DEV Bv<F, F::BM> b_sqr(const Bv<F, A> &a) {
     static_assert((long)A * A * F::MULK <= F::LIM, "square of operand bound exceeds the Montgomery headroom");
-    return Bv<F, F::BM>{F::sqr(a.v)};
+    return Bv<F, F::BM>{F::template sqrb<A>(a.v)};
 }
 template <class F, int A, int B> MG_DEV Bv<F, A + B> operator+(const Bv<F, A> &a, const Bv<F, B> &b) {
     return Bv<F, A + B>{F::add(a.v, b.v)};

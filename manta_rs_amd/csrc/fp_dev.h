@@ -173,6 +173,7 @@ template <class C> struct Fp {
     static constexpr int BM = 1, LIM = 1 << 30, MULK = 1, MAXM = 1 << 30, BX = 1, BY = 1, BRED = 1;
     template <int A> static MG_DEV Fp reduce(const Fp &a) { return a; }
     template <int A, int B> static MG_DEV Fp mulb(const Fp &a, const Fp &b) { return mul(a, b); }
+    template <int A> static MG_DEV Fp sqrb(const Fp &a) { return sqr(a); }
     template <int M> static MG_DEV Fp sub(const Fp &a, const Fp &b) { return sub(a, b); }
     template <int M> static MG_DEV Fp sub2(const Fp &a, const Fp &b, const Fp &c) { return sub(sub(a, b), dbl(c)); }
     template <int M> static MG_DEV Fp neg(const Fp &a) { return neg(a); }
@@ -330,6 +331,7 @@ template <class C> struct Fp2 {
     static constexpr int BM = 1, LIM = 1 << 30, MULK = 1, MAXM = 1 << 30, BX = 1, BY = 1, BRED = 1;
     template <int A> static MG_DEV Fp2 reduce(const Fp2 &a) { return a; }
     template <int A, int B> static MG_DEV Fp2 mulb(const Fp2 &a, const Fp2 &b) { return mul(a, b); }
+    template <int A> static MG_DEV Fp2 sqrb(const Fp2 &a) { return sqr(a); }
     template <int M> static MG_DEV Fp2 sub(const Fp2 &a, const Fp2 &b) { return sub(a, b); }
     template <int M> static MG_DEV Fp2 sub2(const Fp2 &a, const Fp2 &b, const Fp2 &c) { return sub(sub(a, b), dbl(c)); }
     template <int M> static MG_DEV Fp2 neg(const Fp2 &a) { return neg(a); }

@@ -368,6 +368,11 @@ template <class C> struct FpR {
     // the same as real functions: for callers whose register budget cannot take the inlined products
     static __device__ __noinline__ FpR mul_call(const FpR a, const FpR b) { return mul(a, b); }
     static __device__ __noinline__ FpR sqr_call(const FpR a) { return sqr(a); }
+    // (operands by REFERENCE: with four 14-limb structs passed by value -- 56 VGPRs of arguments -- hipcc of ROCm 7.2 produced a
+    // function that returned wrong products on gfx950: BLS12-381 G2 MSMs failed against the oracle, the by-reference build of the
+    // same source passes; found by bisecting builds on the GPU, round 4)
+    static __device__ __noinline__ FpR mul_add_call(const FpR &a, const FpR &b, const FpR &c, const FpR &d) { return mul_add(a, b, c, d); }
+    template <int A> static MG_DEV FpR sqrb(const FpR &a) { return sqr(a); }
     // square: cross products once, against the doubled operand
     static MG_DEV FpR sqr(const FpR &a) {
         u64 acc = 0;
@@ -658,7 +663,54 @@ template <class C> struct Fp2R {
     // product of operands with component bounds A, B. Where the headroom allows the operand sums
     // (4 A B <= R'/p) this is Karatsuba -- 3 base products + one cheap reduction of c1 back below 2p -- else
     // the 4-product schoolbook form above. Either way the components of the result are < 4p.
+    static MG_DEV B bmul_add(const B &x, const B &y, const B &z, const B &w) {
+        if constexpr (CALLS) return B::mul_add_call(x, y, z, w);
+        else return B::mul_add(x, y, z, w);
+    }
+    // Round 4: c0 = a0 b0 + a1 (M p - b1) and c1 = a0 b1 + a1 b0 as TWO FUSED products (FpR::mul_add: both double-width
+    // products of a component share the column accumulators and ONE Montgomery reduction) -- 6 K^2 + 2 K multiply-adds, the
+    // same as Karatsuba's three products (3 (2 K^2 + K)), but none of Karatsuba's linear work: two operand sums, the sum
+    // v0 + v1, two subtractions and a reduce<6> (about 200 VALU instructions per product at K = 9) become ONE negation.
+    // The G2 accumulate kernel issued 63 % non-multiply instructions (34 % of the multiply-add issue peak against 67 % for
+    // G1: gpurun r4f). Components of the result are < 2p. Needs (A Bb + A Bb) <= LIM.
+#ifndef MG_FP2_KARATSUBA // A/B builds: the round-1..3 Karatsuba / schoolbook forms
     template <int A, int Bb> static MG_DEV Fp2R mulb(const Fp2R &a, const Fp2R &b) {
+#ifdef MG_FP2_NO_MULB
+        if constexpr (false) {
+#else
+        if constexpr (2L * A * Bb <= LIM && (A <= MAXM || Bb <= MAXM)) {
+#endif
+            if constexpr (Bb <= A || A > MAXM) { // negate the component with the smaller bound (the smaller multiple of p)
+                const B nb1 = B::template neg<Bb>(b.c1);
+                return Fp2R{bmul_add(a.c0, b.c0, a.c1, nb1), bmul_add(a.c0, b.c1, a.c1, b.c0)};
+            } else {
+                const B na1 = B::template neg<A>(a.c1);
+                return Fp2R{bmul_add(a.c0, b.c0, na1, b.c1), bmul_add(a.c0, b.c1, a.c1, b.c0)};
+            }
+        } else {
+            return mulb_karatsuba<A, Bb>(a, b);
+        }
+    }
+    // (a0 + a1)(a0 - a1) and 2 a0 a1: two products where the operand sums fit the headroom (4 A^2 <= LIM), else a0^2 - a1^2 as
+    // one fused product; either way one reduction per component and a result < 2p
+    template <int A> static MG_DEV Fp2R sqrb(const Fp2R &a) {
+#ifdef MG_FP2_NO_SQRB
+        return sqr(a);
+#endif
+        if constexpr (4L * A * A <= LIM && A <= MAXM) {
+            const B s = B::add(a.c0, a.c1), d = B::template sub<A>(a.c0, a.c1);
+            return Fp2R{bmul(s, d), bmul(B::dbl(a.c0), a.c1)};
+        } else if constexpr (2L * A * A <= LIM && A <= MAXM) {
+            return Fp2R{bmul_add(a.c0, a.c0, a.c1, B::template neg<A>(a.c1)), bmul(B::dbl(a.c0), a.c1)};
+        } else {
+            return sqr(a);
+        }
+    }
+#else
+    template <int A, int Bb> static MG_DEV Fp2R mulb(const Fp2R &a, const Fp2R &b) { return mulb_karatsuba<A, Bb>(a, b); }
+    template <int A> static MG_DEV Fp2R sqrb(const Fp2R &a) { return sqr(a); }
+#endif
+    template <int A, int Bb> static MG_DEV Fp2R mulb_karatsuba(const Fp2R &a, const Fp2R &b) {
         if constexpr (4L * A * Bb <= LIM && 2 * A <= 16 && 2 * Bb <= 16) {
             const B v0 = bmul(a.c0, b.c0), v1 = bmul(a.c1, b.c1);
             const B s = bmul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
