@@ -13,6 +13,8 @@
 #include "host_ec.h"
 #include "params_gen.h"
 #include "prover.h"
+#include <algorithm>
+#include <type_traits>
 #include <map>
 #include <mutex>
 
@@ -55,6 +57,15 @@ __global__ __launch_bounds__(256) void powers_kernel(u32 *__restrict__ out, cons
 // is gathered from the arkworks-format input at the bit-reversed index and converted on the way into LDS (times pre[j] for
 // the forward coset transform); with `out_std` the finished tile is scaled (n^-1 of the plain inverse transform), converted
 // back and written in the arkworks format. Both null inside the witness map, which stays in the work form throughout.
+// the butterfly's product: the single-chain coding of fpr_dev.h (mad_chain_*: every multiply-add of a column in one dependent
+// chain, no 64-bit joins) -- 112 instead of 131 VGPRs in the register kernel (four wavefronts per SIMD) and -10 % on the 2^20
+// transform (profiles/r04_ntt_register_stages.txt); MG_NTT_TWO_CHAINS restores the compiler's coding for re-measurement
+#ifdef MG_NTT_TWO_CHAINS
+#define MG_NTT_MUL(x, y) R::mul(x, y)
+#else
+#define MG_NTT_MUL(x, y) R::template mul_t<true>(x, y)
+#endif
+#define MG_NTT_MUL_RR(x, y) MG_NTT_MUL(x, y) // (the stage-per-round-trip kernel: 82 -> 64 VGPRs, DIF passes -4 %)
 struct NttIo {
     const u32 *in_std, *pre_rr;
     u32 *out_std;
@@ -125,12 +136,12 @@ __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *_
             if (DIF) {
                 x = R::add(a, b);                    // < 2B p
                 y = R::template sub<9>(a, b);        // a + 9p - b (b < 8p) < (B + 9) p
-                if (has_w) y = R::mul(y, w);         // < 2p
+                if (has_w) y = MG_NTT_MUL_RR(y, w);  // < 2p
                 else y = R::template reduce<17>(y);  // last DIF stage (w = 1)
                 if (red) x = R::template reduce<16>(x);
             } else {
                 if (has_w) {
-                    b = R::mul(b, w); // < 2p
+                    b = MG_NTT_MUL_RR(b, w); // < 2p
                     x = R::add(a, b);
                     y = R::template sub<2>(a, b);
                 } else { // first DIT stage (w = 1): b < 4p
@@ -164,6 +175,198 @@ __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *_
         u32 *p = data + gi * K;
 #pragma unroll
         for (int l = 0; l < K; ++l) p[l] = v.v[l];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the same pass with the butterflies of up to THREE consecutive stages done in REGISTERS. PMC of the kernel above
+// (profiles/r04_pmc_ntt.txt, 2^20): 394 VALU instructions per butterfly of which 171 are multiply-adds, 40 LDS instructions per
+// butterfly and bank conflicts in 54 % of the LDS-active cycles (stages whose partner distance is below 64 elements touch every
+// other bank) -- the pass runs at 70-80 % of the issue bound of ITS OWN instruction stream, so the stream has to shrink. Here a
+// thread owns the 2^LR (8) tile elements that differ in LR consecutive index bits, fetches them from LDS once, runs the LR stages
+// that pair exactly those bits (12 butterflies, 7 distinct twiddles: index arithmetic and twiddle addressing once per thread and
+// group, not once per butterfly and stage) and puts them back: ceil(ns / LR) LDS round trips and barriers per pass instead of
+// ns. The tile is stored with one pad word per 32 (address t + t / 32): the strided accesses of the low groups -- 8 elements per
+// lane, lane-to-lane stride 8 -- and the unit-stride ones of the high groups are both conflict-free.
+// Same arguments, same bounds bookkeeping and same I/O options as ntt_pass_rr; tiles of at least 64 * 2^LR elements.
+// one butterfly stage on the 2^LR elements a lane holds in registers: pairs the owned bit Q; 2^Q distinct twiddles (the owned
+// bits below Q), each shared by the 2^(LR-1-Q) butterflies that differ in the owned bits above Q
+// lazy (DIT only): the sums a + t and a + 3p - t are left with unnormalised limbs (< 2^31) -- legal wherever they only feed the
+// next stage's product and its normalising additions: 9 x 2^31 x 2^29 + 9 x 2^58 < 2^64 -- which saves the two carry passes
+// (54 of ~330 VALU instructions per butterfly); the subtraction then adds 3p (fpr_dev.h `subl`), one p more than the normalised form
+// only the FIRST of two consecutive in-register DIT stages of a two-bit group: its lazy outputs (limbs < 2^29 + 2^30) meet one
+// normalising stage before they are stored; groups of three would stack two lazy stages (limbs up to 2^29 + 2 x 2^30: too wide)
+template <bool DIF> MG_DEV bool ntt_lazy_stage(int q, int lr, unsigned bit, unsigned first_bit, unsigned gs, unsigned s) {
+#ifdef MG_NTT_NO_LAZY
+    return false;
+#else
+    return !DIF && lr == 2 && q == 0 && gs == 2 && bit == first_bit && s > 1;
+#endif
+}
+template <class FrC, bool DIF, int LR, int Q>
+MG_DEV void ntt_reg_stage(FpR<FrC> (&v)[1 << LR], const u32 *__restrict__ tw, bool has_w, bool red, unsigned b0, u32 e_lo,
+                          u32 lo_bits, u32 col, unsigned tw_shift, bool lazy = false) {
+    typedef FpR<FrC> R;
+#pragma unroll
+    for (int u = 0; u < (1 << Q); ++u) {
+        R w;
+        if (has_w) {
+            const u32 jl = ((u32)u << b0) | e_lo; // the stage bits below the paired one
+            const size_t j = ((size_t)jl << lo_bits) | col;
+            const uint4 *qp = reinterpret_cast<const uint4 *>(tw + (j << tw_shift) * 12); // 48 B records
+            const uint4 q0 = qp[0], q1 = qp[1], q2 = qp[2];
+            w.v[0] = q0.x, w.v[1] = q0.y, w.v[2] = q0.z, w.v[3] = q0.w, w.v[4] = q1.x, w.v[5] = q1.y, w.v[6] = q1.z, w.v[7] = q1.w,
+            w.v[8] = q2.x;
+        }
+#pragma unroll
+        for (int h = 0; h < (1 << (LR - 1 - Q)); ++h) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int i0 = (h << (Q + 1)) | u, i1 = i0 | (1 << Q);
+            const R a = v[i0], b = v[i1];
+            if (DIF) {
+                R x = R::add(a, b);                   // < 2B p
+                R y = R::template sub<9>(a, b);       // a + 9p - b (b < 8p) < (B + 9) p
+                if (has_w) y = MG_NTT_MUL(y, w);      // < 2p
+                else y = R::template reduce<17>(y);   // last DIF stage (w = 1)
+                if (red) x = R::template reduce<16>(x);
+                v[i0] = x, v[i1] = y;
+            } else if (has_w) {
+                const R t = MG_NTT_MUL(b, w); // < 2p
+                if (lazy) {
+#pragma unroll
+                    for (int l = 0; l < R::K; ++l) v[i0].v[l] = a.v[l] + t.v[l];
+                    v[i1] = R::template subl<3>(a, t);
+                } else {
+                    v[i0] = R::add(a, t);
+                    v[i1] = R::template sub<2>(a, t);
+                }
+            } else { // first DIT stage (w = 1): b < 4p
+                v[i0] = R::add(a, b);
+                v[i1] = R::template sub<5>(a, b);
+            }
+        }
+    }
+}
+
+#ifndef MG_NTT_REG_WAVES
+#define MG_NTT_REG_WAVES 2
+#endif
+template <class FrC, bool DIF, int LR>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MG_NTT_REG_WAVES, 8))) void ntt_pass_reg(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
+                                                   const u32 *__restrict__ tw, unsigned lg, unsigned s0, unsigned ns,
+                                                   unsigned cb, const u32 *__restrict__ post, NttIo io) {
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    typedef FpR<FrC> R;
+    constexpr int K = R::K, NE = 1 << LR;
+    static_assert(K == 9 && R::LIM >= 64, "bound analysis of ntt_pass_rr");
+    u32 *__restrict__ data = (blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2)) + ((size_t)blockIdx.z << lg) * K;
+    const u32 E = 1u << ns, TOT = E << cb, CM = (1u << cb) - 1, TOTP = TOT + (TOT >> 5);
+    const u32 lo_bits = s0 - 1;
+    const u32 nlo = (1u << lo_bits) >> cb;
+    const u32 lo_base = (blockIdx.x % nlo) << cb, hi_blk = blockIdx.x / nlo;
+    const size_t base = ((size_t)hi_blk << (lo_bits + ns)) + lo_base;
+    auto pad = [](u32 t) { return t + (t >> 5); };
+    for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
+        const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
+        const u32 o = pad(t);
+        R r;
+        if (io.in_std) { // arkworks format at the bit-reversed index -> work form (< 2p)
+            const u32 j = __brev((u32)gi) >> (32 - lg);
+            r = R::from_std_shift(Fp<FrC>::load(io.in_std + (size_t)j * 8));
+            if (io.pre_rr) r = R::mul(r, R::load(io.pre_rr + (size_t)j * K));
+        } else if (io.packed & 1u) {
+            r = R::load_packed(data + gi * 8);
+        } else {
+            r = R::load(data + gi * K);
+        }
+#pragma unroll
+        for (int l = 0; l < K; ++l) sm[l * TOTP + o] = r.v[l];
+    }
+    __syncthreads();
+    int B = 4; // every value in the tile is < B*p
+    const u32 nthr = TOT >> LR;
+    for (unsigned done = 0; done < ns;) {
+        const unsigned gs = ns - done < (unsigned)LR ? ns - done : (unsigned)LR;
+        // the LR stage bits this group's threads own: [b0, b0 + LR), the gs unprocessed ones among them are bits
+        //   DIT (ascending):  done .. done + gs - 1          DIF (descending): ns - done - gs .. ns - done - 1
+        const unsigned first_bit = DIF ? ns - done - gs : done;
+        unsigned b0 = first_bit + gs >= (unsigned)LR ? (DIF ? first_bit : (first_bit + LR <= ns ? first_bit : ns - LR)) : 0;
+        if (b0 + LR > ns) b0 = ns >= (unsigned)LR ? ns - LR : 0;
+        const unsigned p0 = cb + b0;
+        const int B_in = B;
+        for (u32 vt = threadIdx.x; vt < nthr; vt += blockDim.x) { // (one trip when the workgroup has a thread per 2^LR elements)
+            B = B_in;
+            const u32 lo = vt & ((1u << p0) - 1), hi = vt >> p0;
+            const u32 tb = (hi << (p0 + LR)) | lo;
+            const u32 c = lo & CM, e_lo = lo >> cb; // column; the stage bits below b0
+            R v[NE];
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const u32 o = pad(tb + ((u32)j << p0));
+#pragma unroll
+                for (int l = 0; l < K; ++l) v[j].v[l] = sm[l * TOTP + o];
+            }
+            // the stages of this group, one call per owned bit with the bit as a template constant (every register index static)
+            auto run = [&](auto qc) {
+                constexpr int Q = decltype(qc)::value;
+                const unsigned bit = b0 + (unsigned)Q; // local stage bit; local stage number tl = bit + 1
+                if (bit < first_bit || bit >= first_bit + gs) return; // (uniform) not one of this group's stages
+                const unsigned s = s0 + bit;               // global stage
+                // DIT: a stage whose outputs are consumed by another stage of this group (not stored) may leave them lazy
+                const bool lazy = ntt_lazy_stage<DIF>(Q, LR, bit, first_bit, gs, s);
+                ntt_reg_stage<FrC, DIF, LR, Q>(v, tw, s > 1, DIF && 2 * B > 8, b0, e_lo, lo_bits, lo_base + c, lg - s, lazy);
+                const bool red = DIF && 2 * B > 8;
+                if (DIF) B = red ? 2 : 2 * B;
+                else B = s > 1 ? B + (lazy ? 3 : 2) : B + 5;
+            };
+            if constexpr (DIF) {
+                if constexpr (LR > 2) run(std::integral_constant<int, 2>());
+                run(std::integral_constant<int, 1>());
+                run(std::integral_constant<int, 0>());
+            } else {
+                run(std::integral_constant<int, 0>());
+                run(std::integral_constant<int, 1>());
+                if constexpr (LR > 2) run(std::integral_constant<int, 2>());
+            }
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const u32 o = pad(tb + ((u32)j << p0));
+#pragma unroll
+                for (int l = 0; l < K; ++l) sm[l * TOTP + o] = v[j].v[l];
+            }
+        }
+        { // the bound after this group's stages, the same for every thread (also for those without elements)
+            B = B_in;
+            for (unsigned k = 0; k < gs; ++k) {
+                const unsigned bit = DIF ? first_bit + gs - 1 - k : first_bit + k;
+                const bool has_w = s0 + bit > 1, red = DIF && 2 * B > 8;
+                const bool lazy = ntt_lazy_stage<DIF>((int)(bit - b0), LR, bit, first_bit, gs, s0 + bit);
+                if (DIF) B = red ? 2 : 2 * B;
+                else B = has_w ? B + (lazy ? 3 : 2) : B + 5;
+            }
+        }
+        __syncthreads();
+        done += gs;
+    }
+    for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
+        const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
+        const u32 o = pad(t);
+        R v;
+#pragma unroll
+        for (int l = 0; l < K; ++l) v.v[l] = sm[l * TOTP + o];
+        if (post) v = R::mul(v, R::load(post + gi * K)); // any B <= 27 times a canonical table entry: < 2p
+        else if (DIF ? B > 4 : true) v = R::template reduce<32>(v);
+        if (io.out_std) { // work form (< 4p) -> arkworks format, times the constant of the plain inverse transform first
+            if (io.scale_rr) v = R::mul(v, R::load(io.scale_rr));
+            v.to_std().store(io.out_std + gi * 8);
+            continue;
+        }
+        if (io.packed & 2u) { // (v < 2p and normalised: a product or a reduce made it)
+            v.store_packed(data + gi * 8);
+            continue;
+        }
+        v.store(data + gi * K);
     }
 }
 
@@ -383,6 +586,18 @@ template <class FrC> class FrEngineT : public FrEngine {
         return MG_OK;
     }
 
+    // stages per LDS round trip of the NTT passes. Measured (profiles/r04_ntt_register_stages.txt): the DIT passes gain from two
+    // stages per round trip (2^20 public transform 0.191 -> 0.17 ms; the 3-vector passes of a 32-proof witness map 268 + 428 ->
+    // 248 + 313 us), the DIF passes do not (318 + 415 -> 340 + 433 us: their product comes AFTER the subtraction, the extra live
+    // registers cost occupancy) and three stages per round trip lose everywhere (215-256 VGPRs). MANTA_NTT_R = 0 / 2 / 3 forces one.
+    static int ntt_reg_bits(bool dif) {
+        static const int v = [] {
+            const char *e = getenv("MANTA_NTT_R");
+            const int x = e ? atoi(e) : -1;
+            return x == 0 || x == 2 || x == 3 ? x : -1;
+        }();
+        return v >= 0 ? v : (dif ? 0 : 2);
+    }
     static u32 ntt_threads() {
         static const u32 v = [] {
             const char *e = getenv("MANTA_NTT_THREADS");
@@ -398,6 +613,10 @@ template <class FrC> class FrEngineT : public FrEngine {
         static const bool attr_set = [] { // tiles of 2048 elements x 36 B = 72 KB: above the 64 KB default of dynamic LDS
             hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_rr<FrC, DIF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 36 * 2048);
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_reg<FrC, DIF, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                36 * (2048 + 64));
+            hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_reg<FrC, DIF, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                36 * (2048 + 64));
             return true;
         }();
         (void)attr_set;
@@ -422,6 +641,19 @@ template <class FrC> class FrEngineT : public FrEngine {
             const bool pack = io.in_std && io.out_std && npass > 1 && !DIF;
             NttIo pio{p == 0 ? io.in_std : nullptr, p == 0 ? io.pre_rr : nullptr, last ? io.out_std : nullptr, last ? io.scale_rr : nullptr,
                       pack ? (p > 0 ? 1u : 0u) | (last ? 0u : 2u) : 0u};
+            // round 4: three stages per LDS round trip in registers (ntt_pass_reg) for every tile with a full wavefront of
+            // 8-element lanes; MANTA_NTT_R = 0 restores the stage-per-round-trip kernel, 2 = four elements per lane
+            const int lr = ntt_reg_bits(DIF);
+            if (lr && tot >= (64u << lr) && ns >= (unsigned)lr) {
+                const size_t lds_p = (size_t)(4 * RK) * (tot + (tot >> 5));
+                const u32 th = std::min<u32>(512u, tot >> lr);
+                if (lr == 3)
+                    hipLaunchKernelGGL((ntt_pass_reg<FrC, DIF, 3>), dim3(blocks, nvec, batch), dim3(th), lds_p, s, d0, d1, d2, tw_rr, lg, s0,
+                                       ns, cb, last ? post_rr : (const u32 *)nullptr, pio);
+                else
+                    hipLaunchKernelGGL((ntt_pass_reg<FrC, DIF, 2>), dim3(blocks, nvec, batch), dim3(th), lds_p, s, d0, d1, d2, tw_rr, lg, s0,
+                                       ns, cb, last ? post_rr : (const u32 *)nullptr, pio);
+            } else
             hipLaunchKernelGGL((ntt_pass_rr<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw_rr, lg, s0,
                                ns, cb, last ? post_rr : (const u32 *)nullptr, pio);
             done += ns;
