@@ -43,9 +43,11 @@ WINDOW_BITS = int(os.environ.get("MANTA_BENCH_C", "17"))  # 255 = 15 x 17: fifte
 DEPTH = int(os.environ.get("MANTA_BENCH_DEPTH", "3"))  # MSMs in flight (each on its own stream + workspace)
 ALGO_BYTES_PER_SCALAR = 128  # 32 B scalar + 96 B affine G1 base (BLS12-381)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
-# v_mad_u64_u32 per mixed addition in the 14 x 28-bit representation (ec_dev.h madd_lazy): 6 products x 406 + 2 squarings x
-# 315 + one fused a*b + c*d product with a single reduction (3 x 196 + 14 = 602); round 1 had 8 x 406 + 2 x 315 = 3878
-MADS_PER_MIXED_ADD = 6 * 406 + 2 * 315 + 602
+# v_mad_u64_u32 per mixed addition (ec_dev.h madd_lazy): 6 products + 2 squarings + one fused a*b + c*d product with a single
+# reduction. Round 4: BLS12-381 Fq is 13 limbs of 30 bits -- 2 K^2 + K = 351 per product, K(K+1)/2 + K^2 + K = 273 per squaring,
+# 3 K^2 + K = 520 for the fused one: 3 172 (rounds 2-3, 14 x 28 bits: 6 x 406 + 2 x 315 + 602 = 3 668; round 1: 3 878)
+MADS_PER_MIXED_ADD = 6 * 351 + 2 * 273 + 520
+MADS_PER_MIXED_ADD_R3 = 6 * 406 + 2 * 315 + 602
 PEAK_TMAD_S_ASSUMED = 1024 * 64 / 4.2 * 2.4e9 / 1e12  # 1024 SIMDs x 64 lanes / 4.2 cycles (profiles/r01_ubench2_mad_u64_u32.txt) x an ASSUMED 2.4 GHz
 
 BLS_G1 = (0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
@@ -360,6 +362,10 @@ def msm_bench(args, env):
             ach = m / (k_alone * 1e-3) / 1e12
             mads = {"mads_per_launch_modelled": int(m), "model": "%.2f mixed additions per scalar (%d windows) x %d multiply-adds each (PMC: %d.0 wave-additions per scalar-lane)" % (adds, windows, MADS_PER_MIXED_ADD, windows),
                     "achieved_Tmad_s": round(ach, 2),
+                    "note_round_4": "13 x 30-bit limbs: %d multiply-adds per mixed addition instead of the %d of rounds 2-3 (-13.5 %%) for -2.6 %% of "
+                                    "kernel time on one box (profiles/r04_limbs_13x30_ab.txt): the columns that overflow are flushed, and the carry-free "
+                                    "differences the 14 x 28 layout had room for are normalised again, so the multiply-add share of the instruction "
+                                    "stream fell; at the old count the same launch would read %.2f Tmad/s" % (MADS_PER_MIXED_ADD, MADS_PER_MIXED_ADD_R3, n * adds * MADS_PER_MIXED_ADD_R3 / (k_alone * 1e-3) / 1e12),
                     "peak_Tmad_s": round(peak_meas, 2) if peak_meas else None, "frac": round(ach / peak_meas, 3) if peak_meas else None,
                     "peak_how": "issue rate measured in this run by mg_clock_probe (no clock assumed) x 1024 SIMDs x 64 lanes",
                     "peak_Tmad_s_assuming_2.4GHz": round(PEAK_TMAD_S_ASSUMED, 2), "frac_assuming_2.4GHz": round(ach / PEAK_TMAD_S_ASSUMED, 3)}

@@ -68,6 +68,14 @@ template <class C> struct FpR {
     static constexpr bool EXT = false;
     static constexpr bool LAZY = true;
     static constexpr u32 MASK = (1u << LB) - 1;
+    // Products of two LB-bit limbs a 64-bit column accumulator holds next to a carry-in (< 2^36). 28- and 29-bit limbs never
+    // come near it (a fused column has 3 K <= 42 of them); with 30-bit limbs -- round 4: BLS12-381 Fq as 13 x 30 bits, 2 K^2 + K =
+    // 351 multiply-adds per product instead of the 406 of 14 x 28 -- sixteen 60-bit products overflow, so a column that holds more
+    // is FLUSHED between its product groups: the accumulator's upper part is moved aside (one 64-bit shift, one mask) and joined
+    // again when the column is done. Nine of a product's 25 columns need it; measured per product at the accumulate kernel's
+    // occupancy (tools/ubench_limbs.hip, profiles/r04_ubench_limbs.txt): 1960 against 2183 cycles (-10 %).
+    static constexpr int CAP = LB >= 30 ? 15 : (LB == 29 ? 60 : 250);
+    static constexpr int nprod(int k) { return k < K ? k + 1 : 2 * K - 1 - k; } // limb products a_i b_(k-i) of column k
     // bound bookkeeping consumed by ec_dev.h's Bv<> wrapper (values are "< B*p")
     static constexpr int BM = 2;            // a product is < 2p ...
     static constexpr int LIM = C::RR_LIM;   // ... whenever the operand bounds multiply to <= LIM
@@ -143,10 +151,23 @@ template <class C> struct FpR {
     // a + M*p - b - 2c   (requires b + 2c < M*p)
     template <int M> static MG_DEV FpR sub2(const FpR &a, const FpR &b, const FpR &c) {
         static_assert(M <= C::RR_MAXM, "multiple table too short");
-        int t[K];
+        if constexpr (LB >= 30) { // a + Mp - b - 2c leaves the 32-bit range limb-wise (-3 * 2^30): carry every limb in 64 bits
+            FpR r;
+            long long cy = 0;
 #pragma unroll
-        for (int i = 0; i < K; ++i) t[i] = (int)a.v[i] + (int)C::RR_MULT[M][i] - (int)b.v[i] - 2 * (int)c.v[i];
-        return normalize(t);
+            for (int i = 0; i < K - 1; ++i) {
+                const long long sv = (long long)a.v[i] + (long long)C::RR_MULT[M][i] - (long long)b.v[i] - 2 * (long long)c.v[i] + cy;
+                cy = sv >> LB;
+                r.v[i] = (u32)sv & MASK;
+            }
+            r.v[K - 1] = (u32)((long long)a.v[K - 1] + (long long)C::RR_MULT[M][K - 1] - (long long)b.v[K - 1] - 2 * (long long)c.v[K - 1] + cy);
+            return r;
+        } else {
+            int t[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = (int)a.v[i] + (int)C::RR_MULT[M][i] - (int)b.v[i] - 2 * (int)c.v[i];
+            return normalize(t);
+        }
     }
     template <int M> static MG_DEV FpR neg(const FpR &a) { return sub<M>(zero(), a); }
 
@@ -182,11 +203,12 @@ template <class C> struct FpR {
         return r;
     }
     // (fused products with NORMALISED operands need K * 3 * 2^(2 LB) < 2^64: true for both fields)
-    static_assert((double)K * 3.0 * (double)(1ull << LB) * (double)(1ull << LB) < 18446744073709551616.0, "fused column overflow");
+    static_assert(3 * K <= CAP || LB >= 30, "fused column overflow");
     // ---- fused almost-Montgomery product (a*b + c*d) * R'^-1 with ONE reduction: two double-width products share the
     // column accumulators and the m*p pass -- 3 K^2 + K multiply-adds instead of 4 K^2 + 2 K. Value < 2p whenever
     // Ba*Bb + Bc*Bd <= LIM; limbs of the operands may be lazy when LAZY_LIMBS (column bound above).
     static MG_DEV FpR mul_add(const FpR &a, const FpR &b, const FpR &c, const FpR &d) {
+        if constexpr (3 * K > CAP) return mul_add_flushed(a, b, c, d);
         u64 acc = 0;
         u32 m[K];
         FpR t;
@@ -218,6 +240,99 @@ template <class C> struct FpR {
         t.v[K - 1] = (u32)acc;
         return t;
     }
+    // ---- the three product routines for limbs wide enough that a column overflows (CAP): the products of a column are added group
+    // by group -- a*b, then c*d, then m*p -- and the accumulator is flushed before a group that would not fit (see CAP)
+    static MG_DEV void flush(u64 &acc, u64 &spill) {
+        spill += acc >> LB;
+        acc &= (u64)MASK;
+    }
+    static MG_DEV FpR mul_add_flushed(const FpR &a, const FpR &b, const FpR &c, const FpR &d) {
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            const int lo = k < K ? 0 : k - K + 1, hi = k < K ? k : K - 1, n = hi - lo + 1;
+            u64 spill = 0;
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) acc += (u64)a.v[i] * b.v[k - i];
+            if (2 * n > CAP) flush(acc, spill);
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) acc += (u64)c.v[i] * d.v[k - i];
+            if (2 * n > CAP || 3 * n > CAP) flush(acc, spill);
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (!(k < K && i == k)) acc += (u64)m[i] * C::RR_P[k - i];
+            if (k < K) {
+                m[k] = ((u32)acc * C::RR_INV) & MASK;
+                acc += (u64)m[k] * C::RR_P[0];
+            } else {
+                t.v[k - K] = (u32)acc & MASK;
+            }
+            acc >>= LB;
+            acc += spill;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    static MG_DEV FpR mul_flushed(const FpR &a, const FpR &b) {
+        u64 acc = 0;
+        u32 m[K];
+        FpR t;
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            const int lo = k < K ? 0 : k - K + 1, hi = k < K ? k : K - 1, n = hi - lo + 1;
+            u64 spill = 0;
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) acc += (u64)a.v[i] * b.v[k - i];
+            if (2 * n > CAP) flush(acc, spill);
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (!(k < K && i == k)) acc += (u64)m[i] * C::RR_P[k - i];
+            if (k < K) {
+                m[k] = ((u32)acc * C::RR_INV) & MASK;
+                acc += (u64)m[k] * C::RR_P[0];
+            } else {
+                t.v[k - K] = (u32)acc & MASK;
+            }
+            acc >>= LB;
+            acc += spill;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
+    static MG_DEV FpR sqr_flushed(const FpR &a) {
+        u64 acc = 0;
+        u32 m[K], a2[K];
+        FpR t;
+#pragma unroll
+        for (int i = 0; i < K; ++i) a2[i] = a.v[i] << 1; // (< 2^31: a doubled cross product counts as two)
+#pragma unroll
+        for (int k = 0; k < 2 * K - 1; ++k) {
+            const int lo = k < K ? 0 : k - K + 1, hi = k < K ? k : K - 1, n = hi - lo + 1;
+            u64 spill = 0;
+#pragma unroll
+            for (int i = lo; i <= hi; ++i) {
+                const int j = k - i;
+                if (i < j) acc += (u64)a2[i] * a.v[j];
+                if (i == j) acc += (u64)a.v[i] * a.v[i];
+            }
+            if (2 * n > CAP) flush(acc, spill);
+#pragma unroll
+            for (int i = lo; i <= hi; ++i)
+                if (!(k < K && i == k)) acc += (u64)m[i] * C::RR_P[k - i];
+            if (k < K) {
+                m[k] = ((u32)acc * C::RR_INV) & MASK;
+                acc += (u64)m[k] * C::RR_P[0];
+            } else {
+                t.v[k - K] = (u32)acc & MASK;
+            }
+            acc >>= LB;
+            acc += spill;
+        }
+        t.v[K - 1] = (u32)acc;
+        return t;
+    }
     // value < A*p (A <= 16)  ->  same residue, < 2p: subtract floor-estimate(value / p) * p, the
     // quotient estimated from the top limb (never too large, at most one too small)
     // (valid for any A with A*p < 2^(LB*K): with T the top limb and D = p_top + 1, the estimate q' = floor(T*RECIP/2^32) is
@@ -240,6 +355,7 @@ template <class C> struct FpR {
     template <int A, int B> static MG_DEV FpR mulb(const FpR &a, const FpR &b) { return mul(a, b); }
     // ---- almost-Montgomery product: a*b*R'^-1 mod p, result < 2p (see header for the input bounds)
     static MG_DEV FpR mul(const FpR &a, const FpR &b) {
+        if constexpr (2 * K > CAP) return mul_flushed(a, b);
         u64 acc = 0;
         u32 m[K];
         FpR t;
@@ -270,7 +386,7 @@ template <class C> struct FpR {
     }
     // single-chain codings (see mad_chain_vv) of mul / sqr / mul_add
     template <bool CH> static MG_DEV FpR mul_t(const FpR &a, const FpR &b) {
-        if constexpr (!CH) return mul(a, b);
+        if constexpr (!CH || 2 * K > CAP) return mul(a, b); // (the single-chain codings below have no flushes)
         u64 acc = 0;
         u32 m[K];
         FpR t;
@@ -301,7 +417,7 @@ template <class C> struct FpR {
         return t;
     }
     template <bool CH> static MG_DEV FpR sqr_t(const FpR &a) {
-        if constexpr (!CH) return sqr(a);
+        if constexpr (!CH || 2 * K > CAP) return sqr(a);
         u64 acc = 0;
         u32 m[K], a2[K];
         FpR t;
@@ -332,7 +448,7 @@ template <class C> struct FpR {
         return t;
     }
     template <bool CH> static MG_DEV FpR mul_add_t(const FpR &a, const FpR &b, const FpR &c, const FpR &d) {
-        if constexpr (!CH) return mul_add(a, b, c, d);
+        if constexpr (!CH || 2 * K > CAP) return mul_add(a, b, c, d);
         u64 acc = 0;
         u32 m[K];
         FpR t;
@@ -375,6 +491,7 @@ template <class C> struct FpR {
     template <int A> static MG_DEV FpR sqrb(const FpR &a) { return sqr(a); }
     // square: cross products once, against the doubled operand
     static MG_DEV FpR sqr(const FpR &a) {
+        if constexpr (2 * K > CAP) return sqr_flushed(a);
         u64 acc = 0;
         u32 m[K], a2[K];
         FpR t;
