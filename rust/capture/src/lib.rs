@@ -123,7 +123,52 @@ pub fn encode<E: CaptureCurve>(
     out
 }
 
-/// Writes `dir/name.bin`.
+/// The four classes of SURVEY.md 8(d)'s witness-like distribution, counted on the assignment a real transfer proves: how many
+/// entries of `z` are 0, are 1, are another value below 2^64, are anything else (canonical values, `into_repr`). Zero scalars
+/// cost a prover nothing, ones one addition, the last class a full set of windows -- arkworks and the GPU library alike -- so
+/// these four numbers decide what a proofs/s figure on a SYNTHETIC witness is worth (`manta_rs_amd/synth.py` profiles
+/// `sparse` / `W` / `dense`; `bench.py` prints the same histogram for what it proves).
+pub fn histogram<E: CaptureCurve>(z: &[E::Fr]) -> [u64; 4] {
+    let mut h = [0u64; 4];
+    for x in z {
+        let limbs: [u64; 4] = x.into_repr().0;
+        let class = if limbs == [0, 0, 0, 0] {
+            0
+        } else if limbs == [1, 0, 0, 0] {
+            1
+        } else if limbs[1] == 0 && limbs[2] == 0 && limbs[3] == 0 {
+            2
+        } else {
+            3
+        };
+        h[class] += 1;
+    }
+    h
+}
+
+/// How many entries of each query are the point at infinity (a variable absent from A or B): those scalars are skipped by the
+/// MSMs whatever their value, so the effective density of the a / b MSMs is the histogram above restricted to the others.
+pub fn infinity_counts<E: CaptureCurve>(proving_key: &ProvingKey<E>) -> [u64; 4] {
+    use ark_ec::AffineCurve;
+    [
+        proving_key.a_query.iter().filter(|p| p.is_zero()).count() as u64,
+        proving_key.b_g1_query.iter().filter(|p| p.is_zero()).count() as u64,
+        proving_key.b_g2_query.iter().filter(|p| p.is_zero()).count() as u64,
+        proving_key.l_query.iter().filter(|p| p.is_zero()).count() as u64,
+    ]
+}
+
+/// `name.hist.json` next to the fixture: `{"n": V, "zero": .., "one": .., "small": .., "dense": .., "infinity": {...}}`.
+pub fn histogram_json<E: CaptureCurve>(z: &[E::Fr], proving_key: &ProvingKey<E>) -> String {
+    let h = histogram::<E>(z);
+    let inf = infinity_counts::<E>(proving_key);
+    format!(
+        "{{\"n\": {}, \"zero\": {}, \"one\": {}, \"small\": {}, \"dense\": {}, \"infinity\": {{\"a_query\": {}, \"b_g1_query\": {}, \"b_g2_query\": {}, \"l_query\": {}}}}}\n",
+        z.len(), h[0], h[1], h[2], h[3], inf[0], inf[1], inf[2], inf[3]
+    )
+}
+
+/// Writes `dir/name.bin` and `dir/name.hist.json`.
 pub fn write<E: CaptureCurve>(
     dir: &Path,
     name: &str,
@@ -136,5 +181,6 @@ pub fn write<E: CaptureCurve>(
 ) -> std::io::Result<()> {
     fs::create_dir_all(dir)?;
     let mut f = fs::File::create(dir.join(format!("{name}.bin")))?;
-    f.write_all(&encode::<E>(matrices, z, r, s, proving_key, proof))
+    f.write_all(&encode::<E>(matrices, z, r, s, proving_key, proof))?;
+    fs::write(dir.join(format!("{name}.hist.json")), histogram_json::<E>(z, proving_key))
 }

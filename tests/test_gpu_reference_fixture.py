@@ -45,6 +45,18 @@ def consume(gpu, data: bytes):
 def test_gpu_proof_equals_the_reference_capture(gpu, path):
     fx, got = consume(gpu, open(path, "rb").read())
     assert got == fx.proof, "GPU proof differs from the arkworks proof captured from the reference: " + os.path.basename(path)
+    # the capture also writes the witness histogram of the real transfer (rust/capture `histogram_json`): it must be the histogram
+    # of the z in the fixture -- and it is the number that tells which synthetic profile (synth.py: sparse / W / dense) is closest
+    hist = path[:-4] + ".hist.json"
+    if os.path.exists(hist):
+        import json
+        h = json.load(open(hist))
+        z_int = synth.from_mont(fx.z, synth.FR_MODULUS[fx.curve])
+        mine = synth.histogram(z_int)
+        assert h["n"] == mine["n"] == fx.V
+        for k in ("zero", "one", "small", "dense"):
+            assert h[k] == round(mine[k] * mine["n"]), k
+        print("witness histogram of %s: %s" % (os.path.basename(path), {k: round(h[k] / h["n"], 4) for k in ("zero", "one", "small", "dense")}))
 
 
 @pytest.mark.parametrize("curve", [0, 1])
