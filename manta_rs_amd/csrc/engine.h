@@ -122,6 +122,12 @@ struct BaseSet {
     u32 *d_pts = nullptr; // affine AoS; with precompute: W tables of n points, table w = 2^(c w) * P
     int pre_c = 0, pre_W = 0; // 0 = no precompute
     bool full = false;        // with precompute: the B = 2^(c-1) multiples m 2^(c w) P of every window too, entry ((w n + i) B + m - 1)
+    // Round 4: a set may be the CONCATENATION of n_sets queries of set_len entries each that are multiplied by the SAME scalar
+    // vector (a_query | b_g1_query | l_query of a proving key): entry j belongs to query j / set_len and to scalar j % set_len,
+    // every query gets its own bucket keys, and ONE pass of the pipeline -- one digit kernel, one accumulate launch, one chain of
+    // merge levels -- leaves n_sets results. n_sets = 1: an ordinary set.
+    u32 n_sets = 1;
+    size_t set_len = 0;
     size_t bytes = 0;
 };
 
@@ -180,7 +186,7 @@ class GroupEngine {
     // queries are full of them: every variable absent from B has b_g1_query = b_g2_query = infinity) and
     // never reach the sort or the accumulate kernel; scalars stay indexed by the original positions.
     virtual int bases_create(const u32 *pts, size_t n, bool src_on_device, int precompute_c, BaseSet **out,
-                             bool drop_infinity = false) = 0;
+                             bool drop_infinity = false, u32 n_sets = 1) = 0;
     virtual void bases_destroy(BaseSet *) = 0;
 
     virtual MsmPlan plan_for(const BaseSet *bs, size_t n, int c_override, u32 batch = 1) const = 0;

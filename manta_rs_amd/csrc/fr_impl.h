@@ -630,6 +630,15 @@ template <class FrC> class FrEngineT : public FrEngine {
             unsigned cb = ns >= 11 ? 0 : 11 - ns; // tile <= 2048 elements = 72 KB of LDS (two workgroups per CU)
             if (cb > lo_bits) cb = lo_bits;
             if (cb > 3) cb = 3;
+            // a SINGLE proof's witness map is a latency chain of six passes over three 2^16-element vectors: with 2048-element
+            // tiles a pass is 32-96 workgroups on 256 CUs. Narrower column groups = more, smaller workgroups (the vectors live in
+            // L2: the coalescing the wide groups buy is worth nothing here). MANTA_NTT_MIN_WGS = workgroups a pass should have.
+            static const u32 min_wgs = [] {
+                const char *e = getenv("MANTA_NTT_MIN_WGS");
+                const int v = e ? atoi(e) : 512;
+                return (u32)(v >= 1 ? v : 1);
+            }();
+            while (cb > 0 && ((((size_t)1 << lg) >> (ns + cb)) * (size_t)nvec * batch) < min_wgs && (1u << (ns + cb - 1)) >= 128u) --cb;
             const u32 blocks = (u32)(((size_t)1 << lg) >> (ns + cb));
             const size_t lds = ((size_t)(4 * RK) << (ns + cb));
             const bool last = p + 1 == npass;

@@ -69,14 +69,22 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
                                                      int precomp, u32 tstride, int mont, u32 invalid,
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
                                                      const u32 *__restrict__ map, u32 n_scalars,
-                                                     size_t scalar_stride, u32 seg_keys, u32 *__restrict__ count) {
+                                                     size_t scalar_stride, u32 seg_keys, u32 *__restrict__ count,
+                                                     u32 n_sets = 1, u32 set_len = 0) {
     MG_PRIO_HIGH();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     // blockIdx.y = scalar vector of a batch: its own scalars, its own range of bucket keys; the bases (and so
     // the values) are shared
     scalars += (size_t)blockIdx.y * scalar_stride;
-    const u32 key0 = blockIdx.y * seg_keys;
-    const u32 src = (i < n) ? (map ? map[i] : i) : 0xffffffffu; // which scalar belongs to stored base i
+    u32 src = (i < n) ? (map ? map[i] : i) : 0xffffffffu; // which scalar belongs to stored base i
+    // concatenated queries (BaseSet::n_sets): original entry j = query j / set_len, scalar j % set_len; every (vector, query)
+    // pair has its own range of bucket keys
+    u32 set = 0;
+    if (n_sets > 1 && i < n) {
+        set = src / set_len;
+        src -= set * set_len;
+    }
+    const u32 key0 = (blockIdx.y * n_sets + set) * seg_keys;
     const bool have = i < n && src < n_scalars; // the scalar vector may be shorter than the base set: zip
     u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (have && mont == 2) { // the witness map's reduced-radix work form (9 words): one product with the integer 1
@@ -1171,8 +1179,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 
     // ---------------------------------------------------------------- bases
     int bases_create(const u32 *pts_in, size_t n_in, bool src_on_device, int pre_c, BaseSet **out,
-                     bool drop_infinity = false) override {
-        if (!pts_in || !n_in || !out) return MG_ERR_ARG;
+                     bool drop_infinity = false, u32 n_sets = 1) override {
+        if (!pts_in || !n_in || !out || n_sets == 0 || n_in % n_sets) return MG_ERR_ARG;
         const u32 *pts = pts_in;
         size_t n = n_in;
         std::vector<u32> compact, map;
@@ -1209,6 +1217,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         bs->device = current_device();
         bs->n = n;
         bs->n_orig = n_in;
+        bs->n_sets = n_sets;
+        bs->set_len = n_in / n_sets;
         if (!map.empty()) {
             if (hipMalloc((void **)&bs->d_map, map.size() * 4) != hipSuccess ||
                 hipMemcpy(bs->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1489,17 +1499,19 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                    MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) override {
         if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig || batch == 0 || batch > 65535) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
+        const u32 nsets = bs->n_sets; // concatenated queries over one scalar vector: nsets results per vector
+        if (nsets > 1 && n > bs->set_len) return MG_ERR_ARG;
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
-        if (bs->d_map || n > bs->n) n = bs->n; // entries = stored points; the kernel zips to the shorter side
+        if (bs->d_map || n > bs->n || nsets > 1) n = bs->n; // entries = stored points; the kernel zips to the shorter side
         const MsmPlan pl = plan_for(bs, n, c_override, batch);
         hipStream_t s = ws->run_on ? ws->run_on : ws->stream;
         const size_t M = n * (size_t)pl.W * batch;
         // full tables: a digit addresses its summand, every pair of a scalar vector carries the same key and the "bucket" is the result
         const u32 KB = pl.full ? 1u : pl.B; // bucket keys per bucket window
-        if (M >= (1ull << 31) || (size_t)batch * pl.Wb * KB >= (1ull << 24)) return MG_ERR_ARG;
+        if (M >= (1ull << 31) || (size_t)batch * nsets * pl.Wb * KB >= (1ull << 24)) return MG_ERR_ARG;
         if (pl.full) sparse = true; // compacting digit kernel: no invalid keys, so a single MSM needs no sort at all
-        const u32 seg_keys = (u32)pl.Wb * KB; // bucket keys per scalar vector
-        const u32 nb = batch * seg_keys;        // real buckets; key nb = INVALID
+        const u32 seg_keys = (u32)pl.Wb * KB; // bucket keys per (scalar vector, query)
+        const u32 nb = batch * nsets * seg_keys; // real buckets; key nb = INVALID
         const u32 invalid = nb;
         int rc;
         if ((rc = ws->keys_in.reserve(M * 4)) || (rc = ws->keys_out.reserve(M * 4)) ||
@@ -1552,7 +1564,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, dthreads), batch), dim3(dthreads), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.full ? 2 : (pl.precomp ? 1 : 0), (u32)bs->n, scalar_mode, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
-                           scalar_stride_words, seg_keys, d_count);
+                           scalar_stride_words, seg_keys, d_count, nsets, (u32)bs->set_len);
+        batch *= nsets; // from here on every (vector, query) pair is a vector of its own: its keys, its window sums, its result
         // one key in all (a single MSM on full tables, pairs compacted): any order is sorted
         const bool no_sort = nb == 1 && d_count;
         const u32 *skeys = no_sort ? ws->keys_in.as<u32>() : ws->keys_out.as<u32>();

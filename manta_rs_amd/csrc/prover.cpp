@@ -107,6 +107,9 @@ struct ProveWs {
     hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
     bool graphs_ready = false;
     u32 k = 1; // proofs per pass (the slot's buffers and its captured graph are sized for exactly this batch)
+    // this slot runs the three G1 MSMs over the assignment (a, b_g1, l) as ONE pass of the MSM pipeline over the concatenated
+    // query (ProverImpl::z3_bs_full_) on mw[0]; mw[1] and mw[3] stay idle. Fixed for the slot's lifetime (its graphs capture it).
+    bool z3 = false;
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
@@ -159,7 +162,7 @@ static int prove_streams() {
     static const int n = [] {
         const char *e = std::getenv("MANTA_PROVE_STREAMS");
         const int v = e ? std::atoi(e) : 6;
-        return v == 1 || v == 3 ? v : 6;
+        return v == 1 || v == 3 || v == 4 || v == 5 ? v : 6;
     }();
     return n;
 }
@@ -207,6 +210,13 @@ class ProverImpl : public Prover {
     // the five queries once more as FULL tables (every multiple of every window: the MSM is one plain sum), for passes of ONE
     // proof -- their latency chain loses the sort, the merge into buckets and the bucket reduce; nullptr: bucket tables
     BaseSet *a_bs_full_ = nullptr, *b1_bs_full_ = nullptr, *b2_bs_full_ = nullptr, *l_bs_full_ = nullptr, *h_bs_full_ = nullptr;
+    // Round 4: a_query | b_g1_query | l_query (padded to the a query's indexing) as ONE full table (BaseSet::n_sets = 3). The three
+    // MSMs share the scalar vector z, so a single proof runs them as one digit kernel, one accumulate launch and one chain of
+    // merge levels with three bucket keys instead of three chains on three streams: a captured multi-branch graph starts its
+    // branches one after the other (tools/ubench_graph_branches.hip: 4 branches progress like 3, a fifth waits for a whole
+    // branch), which left the third of these MSMs starting 630 us into a 880 us proof (profiles/r04_proof_timeline_*). Replaces
+    // the three separate full tables of an unsharded context (same HBM); MANTA_Z3=0 keeps them apart.
+    BaseSet *z3_bs_full_ = nullptr;
     HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
     HostPoint a0_alpha_, b10_beta_, b20_beta_; // constant terms of g_a, g1_b, g2_b folded once
     void *delta1_tab_ = nullptr, *delta2_tab_ = nullptr; // fixed-base tables for r*delta, s*delta, rs*delta
@@ -233,6 +243,7 @@ class ProverImpl : public Prover {
         if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
         if (l_bs_) g1_->bases_destroy(l_bs_);
         if (b2_bs_) g2_->bases_destroy(b2_bs_);
+        if (z3_bs_full_) g1_->bases_destroy(z3_bs_full_);
         if (a_bs_full_) g1_->bases_destroy(a_bs_full_);
         if (b1_bs_full_) g1_->bases_destroy(b1_bs_full_);
         if (l_bs_full_) g1_->bases_destroy(l_bs_full_);
@@ -261,7 +272,7 @@ class ProverImpl : public Prover {
         out2[0] = out2[1] = 0;
         for (const BaseSet *b : {a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_, a_bs_wide_, b1_bs_wide_, b2_bs_wide_, l_bs_wide_, h_bs_wide_})
             if (b) out2[0] += b->bytes;
-        for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, h_bs_full_})
+        for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, h_bs_full_, z3_bs_full_})
             if (b) out2[1] += b->bytes;
         for (const ProverImpl *q : peers_) {
             u64 t[2];
@@ -297,7 +308,7 @@ class ProverImpl : public Prover {
     static bool full_fits_index(GroupEngine *g, u64 n, int c) { return (((u64)((g->scalar_bits() + c - 1) / c) << (c - 1)) * n) < ((u64)1 << 31); }
     // widths of the five tables under `budget`: the widest uniform width c in 4 .. 8 whose five tables fit together, then single
     // queries one step wider while they fit, the longest chains first (b_g2, h, a, b_g1, l). n[i] = entries of query i on this shard.
-    void plan_full_tables(const u64 n[5], int64_t budget, int out[5]) const {
+    void plan_full_tables(const u64 n[5], int64_t budget, int out[5], bool tie_abl = false) const {
         for (int i = 0; i < 5; ++i) out[i] = 0;
         static const int fixed = [] {
             const char *e = std::getenv("MANTA_FULL_C");
@@ -327,12 +338,24 @@ class ProverImpl : public Prover {
         if (!u) return;
         for (int i = 0; i < 5; ++i) c[i] = u;
         if (!fixed) {
-            static const int order[5] = {2, 4, 0, 1, 3};
-            for (int step = 0; step < 5; ++step) {
-                const int i = order[step];
-                if (c[i] >= 8) continue;
-                ++c[i];
-                if (!ok(c)) --c[i];
+            if (tie_abl) { // a, b_g1 and l share one concatenated table (z3_bs_full_): one width for the three
+                for (int i : {2, 4}) {
+                    if (c[i] >= 8) continue;
+                    ++c[i];
+                    if (!ok(c)) --c[i];
+                }
+                if (c[0] < 8) {
+                    ++c[0], ++c[1], ++c[3];
+                    if (!ok(c)) --c[0], --c[1], --c[3];
+                }
+            } else {
+                static const int order[5] = {2, 4, 0, 1, 3};
+                for (int step = 0; step < 5; ++step) {
+                    const int i = order[step];
+                    if (c[i] >= 8) continue;
+                    ++c[i];
+                    if (!ok(c)) --c[i];
+                }
             }
         }
         for (int i = 0; i < 5; ++i) out[i] = n[i] ? c[i] : 0;
@@ -401,7 +424,8 @@ class ProverImpl : public Prover {
             u64 D = 1; // the domain the h query was made for: len(h_query) = D - 1 (ark setup) or D (MPC keys)
             while (D < h_len_) D <<= 1;
             const u64 nq[5] = {zn, zn, zn, ln, (u64)(D * (shard_ + 1) / n_shards_ - D * shard_ / n_shards_)};
-            plan_full_tables(nq, full_budget_, full_c_plan_);
+            const char *z3e = std::getenv("MANTA_Z3");
+            plan_full_tables(nq, full_budget_, full_c_plan_, n_shards_ == 1 && task_mask_ == 0x1f && !(z3e && std::atoi(z3e) == 0));
         }
         const int f_z1a = -full_c_plan_[0], f_z1b = -full_c_plan_[1], f_z2 = -full_c_plan_[2], f_l = -full_c_plan_[3];
         if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
@@ -425,9 +449,30 @@ class ProverImpl : public Prover {
             return r;
         };
         if ((rc = try_full(g2_, b2q, zn, f_z2, &b2_bs_full_))) return rc; // the G2 chain first: the longest of a proof
+        static const bool z3_on = [] {
+            const char *e = std::getenv("MANTA_Z3");
+            return !(e && std::atoi(e) == 0);
+        }();
+        const int c_z3 = std::min(full_c_plan_[0], std::min(full_c_plan_[1], full_c_plan_[3]));
+        if (z3_on && n_shards_ == 1 && task_mask_ == 0x1f && c_z3 >= 2 && 3 * (u64)zn * ((u64)((g1_->scalar_bits() + c_z3 - 1) / c_z3) << (c_z3 - 1)) < ((u64)1 << 31)) {
+            // a | b_g1 | l as one table over the scalars z[1 .. V): l_query[i] belongs to z[P + i] = scalar P - 1 + i of that range
+            std::vector<u32> cat((size_t)3 * zn * w1, 0u);
+            std::memcpy(&cat[0], aq, zn * w1 * 4);
+            std::memcpy(&cat[zn * w1], b1q, zn * w1 * 4);
+            std::memcpy(&cat[(2 * zn + (size_t)(P_ - 1)) * w1], lq, ln * w1 * 4);
+            const int r = g1_->bases_create(cat.data(), 3 * zn, false, -c_z3, &z3_bs_full_, true, 3);
+            if (r == MG_ERR_OOM) {
+                z3_bs_full_ = nullptr;
+                (void)hipGetLastError();
+            } else if (r) {
+                return r;
+            }
+        }
+        if (!z3_bs_full_) {
         if ((rc = try_full(g1_, aq, zn, f_z1a, &a_bs_full_))) return rc;
         if ((rc = try_full(g1_, b1q, zn, f_z1b, &b1_bs_full_))) return rc;
         if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
+        }
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
             int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
             if (const char *e = std::getenv("MANTA_PROVE_CW")) cw = std::atoi(e) >= 6 && std::atoi(e) <= 16 ? std::atoi(e) : cw; // tuning override
@@ -594,12 +639,13 @@ class ProverImpl : public Prover {
         have_r1cs_ = true;
     }
 
-    ProveWs *ws_acquire(u32 k = 1) {
+    static u32 slot_key(u32 k, bool z3) { return k | (z3 ? 1u << 16 : 0u); }
+    ProveWs *ws_acquire(u32 k = 1, bool z3 = false) {
         u64 gen;
         {
             std::lock_guard<std::mutex> g(mu_);
             gen = gen_;
-            auto it = ws_free_.find(k);
+            auto it = ws_free_.find(slot_key(k, z3));
             while (it != ws_free_.end() && !it->second.empty()) {
                 ProveWs *w = it->second.back();
                 it->second.pop_back();
@@ -610,6 +656,7 @@ class ProverImpl : public Prover {
         }
         ProveWs *w = new ProveWs();
         w->k = k;
+        w->z3 = z3;
         w->gen = gen;
         w->device = dev_;
         if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
@@ -643,6 +690,14 @@ class ProverImpl : public Prover {
             w->mw[4]->run_on = w->stream;
         } else if (prove_streams() == 1) {
             for (int i = 0; i < 5; ++i) w->mw[i]->run_on = w->stream;
+        } else if (prove_streams() == 4) { // three branches beside the G2 chain: (a, b_g1) back to back | l | witness map + h
+            w->mw[0]->run_on = w->side[1];
+            w->mw[1]->run_on = w->side[1];
+            w->mw[4]->run_on = w->stream;
+        } else if (prove_streams() == 5) { // (a, l) back to back | b_g1 | witness map + h
+            w->mw[0]->run_on = w->side[1];
+            w->mw[3]->run_on = w->side[1];
+            w->mw[4]->run_on = w->stream;
         }
         return w;
     }
@@ -658,7 +713,7 @@ class ProverImpl : public Prover {
                 doomed.push_back(w);
             } else {
                 w->last_use = ++lru_tick_;
-                ws_free_[w->k].push_back(w);
+                ws_free_[slot_key(w->k, w->z3)].push_back(w);
                 ++idle_slots_;
                 while (idle_slots_ > MAX_IDLE_SLOTS) {
                     std::vector<ProveWs *> *from = nullptr;
@@ -788,11 +843,21 @@ class ProverImpl : public Prover {
         }();
         const bool one = w->k <= full_max_k;
         auto pick = [&](BaseSet *full, BaseSet *wd, BaseSet *narrow) { return one && full ? full : (wide && wd ? wd : narrow); };
-        return MsmArgs{{pick(a_bs_full_, a_bs_wide_, a_bs_), pick(b1_bs_full_, b1_bs_wide_, b1_bs_), pick(b2_bs_full_, b2_bs_wide_, b2_bs_),
+        return MsmArgs{{w->z3 ? z3_bs_full_ : pick(a_bs_full_, a_bs_wide_, a_bs_), pick(b1_bs_full_, b1_bs_wide_, b1_bs_), pick(b2_bs_full_, b2_bs_wide_, b2_bs_),
                         pick(l_bs_full_, l_bs_wide_, l_bs_), pick(h_bs_full_, h_bs_wide_, h_bs_)},
                        {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * (size_t)fr_->work_words()},
                        {zn, zn, zn, ln, hn},
                        {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * (size_t)fr_->work_words()}};
+    }
+    // does this slot launch MSM i (a, b_g1, b_g2, l, h)? -- not another rank's (task placement), not folded into the combined one
+    bool runs(const ProveWs *w, int i) const { return does(i) && !(w->z3 && (i == 1 || i == 3)); }
+    bool wants_z3(u32 k) const {
+        static const u32 full_max_k = [] {
+            const char *e = std::getenv("MANTA_FULL_MAX_K");
+            const int v = e ? std::atoi(e) : 1;
+            return (u32)(v >= 0 ? v : 1);
+        }();
+        return z3_bs_full_ && k <= full_max_k && peers_.empty() && !ex_;
     }
     static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
 
@@ -826,14 +891,14 @@ class ProverImpl : public Prover {
         if (does(4) && (rc = launch_witness_map(w, use_graphs))) return rc; // h is only needed by the h MSM
         if (w->timed) MG_HIP(hipEventRecord(w->tev[2], w->stream));
         for (int i = 0; i < 5; ++i) {
-            if (!in_part_a(i) || !does(i)) continue;
+            if (!in_part_a(i) || !runs(w, i)) continue;
             hipStream_t ms = msm_stream(w, i);
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
             if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }
         for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
             hipStream_t ms = msm_stream(w, i);
-            if (in_part_a(i) && does(i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
+            if (in_part_a(i) && runs(w, i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         if (w->timed) MG_HIP(hipEventRecord(w->tev[13], w->stream));
         return MG_OK;
@@ -858,7 +923,7 @@ class ProverImpl : public Prover {
             if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
             MG_HIP(hipGraphLaunch(w->g_g2, g2s));
             MG_HIP(hipGraphLaunch(w->g_all, w->stream));
-            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 1;
+            for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
             return MG_OK;
         }
         if ((rc = enqueue_part_a(w, use_graphs))) return rc;
@@ -900,6 +965,7 @@ class ProverImpl : public Prover {
         bool ok = capture_segment(w->stream, &w->g_wm, [&] { return enqueue_witness_map_body(w); });
         const MsmArgs a = msm_args(w);
         for (int i = 0; ok && i < 5; ++i) {
+            if (!runs(w, i)) continue;
             w->mw[i]->capturing = true; // no event records inside the capture: the replay path records `done`
             ok = capture_segment(msm_stream(w, i), &w->g_msm[i], [&] {
                 return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
@@ -1150,10 +1216,11 @@ class ProverImpl : public Prover {
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
     // (z_list: the k assignments as separate buffers -- coalesced single calls -- gathered into the slot's staging copy)
     int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out,
-                    const uint64_t *const *z_list = nullptr) {
+                    const uint64_t *const *z_list = nullptr, bool whole_proof = true) {
         MG_HIP(hipSetDevice(dev_));
         p.k = k, p.r = r, p.s = s, p.out = out;
-        ProveWs *w = p.w = ws_acquire(k);
+        // (the partials interface folds every MSM on the device by its index: it keeps the five separate MSMs)
+        ProveWs *w = p.w = ws_acquire(k, whole_proof && wants_z3(k));
         if (!w) return MG_ERR_HIP;
         int rc = MG_OK;
         const size_t zbytes = (size_t)k * V_ * 32;
@@ -1239,6 +1306,18 @@ class ProverImpl : public Prover {
         }
         for (int i = 0; i < 5; ++i) {
             if (in_part_a(i) != part_a) continue;
+            if (w->z3 && (i == 1 || i == 3)) continue; // part of the combined MSM on mw[0]
+            if (w->z3 && i == 0 && w->mw[0]->pending) { // three results per proof: a, b_g1, l
+                std::vector<HostPoint> t3((size_t)3 * p.k);
+                int rc2 = w->me[0]->msm_finish(w->mw[0], t3.data(), true);
+                if (!rc) rc = rc2;
+                for (u32 q = 0; q < p.k; ++q) {
+                    res[(size_t)0 * p.k + q] = t3[(size_t)q * 3 + 0];
+                    res[(size_t)1 * p.k + q] = t3[(size_t)q * 3 + 1];
+                    res[(size_t)3 * p.k + q] = t3[(size_t)q * 3 + 2];
+                }
+                continue;
+            }
             if (w->mw[i]->pending) {
                 int rc2 = w->me[i]->msm_finish(w->mw[i], res + (size_t)i * p.k, true);
                 if (!rc) rc = rc2;
@@ -1382,7 +1461,7 @@ class ProverImpl : public Prover {
         if (!have_r1cs_) return MG_ERR_STATE;
         PartialJob *job = new PartialJob();
         if (take) job->shape_lock = std::move(*take);
-        int rc = launch_pass(job->p, (u32)k64, z, nullptr, nullptr, nullptr, z_list);
+        int rc = launch_pass(job->p, (u32)k64, z, nullptr, nullptr, nullptr, z_list, false);
         ProveWs *w = job->p.w;
         if (rc || !w) {
             if (w) abandon_pass(job->p);
@@ -1673,7 +1752,8 @@ class ProverImpl : public Prover {
         if (timed) { // every event has completed: both parts were synchronised above
             hipEventElapsedTime(&phases[0], w->tev[0], w->tev[1]);
             hipEventElapsedTime(&phases[1], w->tev[1], w->tev[2]);
-            for (int i = 0; i < 5; ++i) hipEventElapsedTime(&phases[2 + i], w->tev[3 + 2 * i], w->tev[4 + 2 * i]);
+            for (int i = 0; i < 5; ++i)
+                if (runs(w, i)) hipEventElapsedTime(&phases[2 + i], w->tev[3 + 2 * i], w->tev[4 + 2 * i]); // (z3: "msm_a" is a + b_g1 + l)
             hipEventElapsedTime(&phases[7], w->tev[0], w->tev[13]);
             hipEventElapsedTime(&phases[8], w->tev[0], w->tev[14]);
         }

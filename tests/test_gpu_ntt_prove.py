@@ -549,3 +549,29 @@ def test_checksum_is_never_skipped_by_a_device_list(gpu):
         assert ei.value.status == 6
     with pytest.raises(ValueError):
         gpu.ProvingContext.decode(0, data, devices=[0], checksum=b"short")
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_witness_map_matches_oracle_across_domain_sizes(gpu, curve):
+    """h = R1CStoQAP::witness_map(z) against the oracle for EVERY domain size 2^6 .. 2^17 (W-profile circuits): each size takes
+    its own split of the stages into passes, tile shapes, register / LDS kernels and column groups -- a first version of the
+    round-4 register kernel was wrong from 2^15 up and passed the public-transform tests at 2^13 (this sweep caught it). The
+    context only needs a key of the right lengths: the generators repeated."""
+    O.set_threads(O.usable_cpus())
+    g1, g2 = O.generator(curve, 1), O.generator(curve, 2)
+    for lg in range(6, 18):
+        D, P = 1 << lg, 5
+        c = synth.make_circuit(curve, D - P, max(D // 2, 40), P, seed=lg, profile="W")
+
+        class K:
+            pass
+        k = K()
+        k.V, k.P = c.V, c.P
+        for name, n, g in (("alpha_g1", 1, g1), ("beta_g1", 1, g1), ("delta_g1", 1, g1), ("beta_g2", 1, g2), ("delta_g2", 1, g2),
+                           ("a_query", c.V, g1), ("b_g1_query", c.V, g1), ("b_g2_query", c.V, g2), ("h_query", D - 1, g1),
+                           ("l_query", c.V - c.P, g1)):
+            setattr(k, name, np.tile(np.asarray(g, dtype=np.uint64).reshape(1, -1), (n, 1)))
+        ctx = gpu.ProvingContext(curve, k, full_table_bytes=0)
+        ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+        assert (ctx.witness_map(c.z) == O.witness_map(c)).all(), lg
+        ctx.close()
