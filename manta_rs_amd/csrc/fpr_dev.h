@@ -761,9 +761,16 @@ template <class C> struct Fp2R {
     template <int A> static MG_DEV Fp2R reduce(const Fp2R &a) {
         return Fp2R{B::template reduce<A>(a.c0), B::template reduce<A>(a.c1)};
     }
-    // 14-limb products (BLS12-381) are calls here: four of them inlined per Fp2 product overflow the
+    // 14-limb products (BLS12-381 in rounds 1-3) were calls here: four of them inlined per Fp2 product overflowed the
     // register file in the group operations
+    // (round 4: with 13 limbs the inlined form compiles -- 442 unified registers, one wavefront per SIMD like the calls build -- and
+    // the BLS12-381 G2 accumulate kernel is 1.65x faster without the scratch traffic of the calls: 2^20 G2 MSM 24.0 -> 14.8 ms
+    // uniform, 13.6 -> 8.1 ms witness-like; MG_FP2_CALLS restores the calls)
+#ifdef MG_FP2_CALLS
     static constexpr bool CALLS = B::K > 9;
+#else
+    static constexpr bool CALLS = B::K > 13;
+#endif
     static MG_DEV B bmul(const B &x, const B &y) {
         if constexpr (CALLS) return B::mul_call(x, y);
         else return B::mul(x, y);

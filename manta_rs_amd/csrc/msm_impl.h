@@ -1551,9 +1551,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // rounds of 6 dependent additions where one round of 9 does, and 1.4 wavefronts per SIMD for a batched pass where two
         // balanced ones do. Launch one round of lanes and let the kernel derive the chunk length from the pair count.
         u32 Tl = T, adapt = 0;
+        u32 Lk = pl.L; // the chunk length the kernel starts from
         if (d_count) {
             const u32 tgt = acc_round_lanes(batch);
             if (tgt && Tl > tgt) Tl = tgt, adapt = 1;
+            // one LARGE scalar vector (host chunk length above 6: 2^20 scalars): whatever the lane count came to, the pair count
+            // decides (a batched pass that fits one round keeps its host-side chunk length: measured, -12 % otherwise)
+            else if (tgt && batch == 1 && pl.L > 6) adapt = 1;
+            // The kernel takes max(Lk, ceil(pairs / lanes)). The host's L is sized for ALL n W digits (2^20 scalars: 120 entries per
+            // lane): on a witness of which a tenth survives the compaction it left nine SIMDs in ten idle and the others walking 120
+            // dependent additions -- the 2^20 BLS12-381 G2 accumulate of BASELINE configs[2] took 7.6 ms for 0.9 M pairs
+            // (profiles/r04_config2_timeline.txt). With the round of lanes fixed the pair count alone decides the chunk length.
+            if (adapt && Lk > 6) Lk = 6;
         }
         static const u32 dthreads_sparse = [] {
             const char *e = getenv("MANTA_DIGITS_THREADS");
@@ -1604,11 +1613,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
 #endif
         if (ws->timed)
             hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
-                               svals, (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+                               svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                                ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, ws->clk.as<unsigned long long>(), adapt);
         else
             hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
-                               svals, (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
+                               svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                                ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, (unsigned long long *)nullptr, adapt);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
         u32 cnt = 2 * Tl;

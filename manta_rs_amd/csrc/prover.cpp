@@ -434,7 +434,12 @@ class ProverImpl : public Prover {
         // reduce level) shorten it by four dependent additions (measured +4 % proofs/s); the extra windows only
         // add parallel mixed additions.
         const bool small = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
-        const int c_g2 = small ? 6 : c_z;
+        // large keys (2^20 variables, BASELINE configs[2]): the 2^16 Fp2 buckets of a 17-bit window made the G2 bucket reduce a
+        // 4.4 ms chain of latency-bound kernels next to a 0.7 ms accumulate (profiles/r04_config2_timeline.txt); 13-bit windows
+        // -- 4 096 buckets, 20 windows instead of 15 -- trade a third more mixed additions for a sixteenth of the buckets
+        int c_g2 = small ? 6 : (c_z > 13 ? 13 : c_z);
+        if (const char *e = std::getenv("MANTA_PROVE_CG2"))
+            if (std::atoi(e) >= 4 && std::atoi(e) <= 18) c_g2 = std::atoi(e);
         if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
         if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
         // (an optimisation: a table that does not fit any more is left out, the bucket tables above serve its MSM)
