@@ -890,9 +890,7 @@ class ProverImpl : public Prover {
         if (w->timed && !rc) MG_HIP(hipEventRecord(w->tev[4 + 2 * i], msm_stream(w, i)));
         return rc;
     }
-    // own_z3_graph: the combined a | b_g1 | l MSM of a z3 slot is NOT a branch of this part (it is captured and replayed as a linear
-    // graph of its own on its stream: a branch of a captured graph starts hundreds of microseconds late, see build_graphs)
-    int enqueue_part_a(ProveWs *w, bool use_graphs, bool own_z3_graph = false) {
+    int enqueue_part_a(ProveWs *w, bool use_graphs) {
         int rc;
         const MsmArgs a = msm_args(w);
         MG_HIP(hipEventRecord(w->fork, w->stream)); // z is on the device (upload_z ran on this stream)
@@ -900,14 +898,14 @@ class ProverImpl : public Prover {
         if (does(4) && (rc = launch_witness_map(w, use_graphs))) return rc; // h is only needed by the h MSM
         if (w->timed) MG_HIP(hipEventRecord(w->tev[2], w->stream));
         for (int i = 0; i < 5; ++i) {
-            if (!in_part_a(i) || !runs(w, i) || (own_z3_graph && i == 0)) continue;
+            if (!in_part_a(i) || !runs(w, i)) continue;
             hipStream_t ms = msm_stream(w, i);
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
             if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }
         for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
             hipStream_t ms = msm_stream(w, i);
-            if (in_part_a(i) && runs(w, i) && !(own_z3_graph && i == 0) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
+            if (in_part_a(i) && runs(w, i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
         }
         if (w->timed) MG_HIP(hipEventRecord(w->tev[13], w->stream));
         return MG_OK;
@@ -929,24 +927,9 @@ class ProverImpl : public Prover {
         if (w->g_all && w->g_g2) { // "single" mode replay
             // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
             // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
-            // Three linear graphs in a z3 slot: the h chain (witness map, then a dense MSM) is the longest since the G2 products were
-            // fused and the three G1 MSMs over z became one -- it goes first, the G2 chain second, the combined MSM last (every
-            // hipGraphLaunch is 40-50 us of host time: launched third, the h chain started 100 us into the proof).
-            // MANTA_LAUNCH_ORDER=g2 restores G2 first.
-            static const bool main_first = [] {
-                const char *e = std::getenv("MANTA_LAUNCH_ORDER");
-                return !(e && !std::strcmp(e, "g2"));
-            }();
-            const bool own = w->z3 && w->g_msm[0];
-            if (own && main_first) MG_HIP(hipGraphLaunch(w->g_all, w->stream));
             if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
             MG_HIP(hipGraphLaunch(w->g_g2, g2s));
-            if (own) { // the combined MSM: a linear graph of its own
-                hipStream_t zs = msm_stream(w, 0);
-                if (zs != w->stream) MG_HIP(hipStreamWaitEvent(zs, w->z_ready, 0));
-                MG_HIP(hipGraphLaunch(w->g_msm[0], zs));
-            }
-            if (!(own && main_first)) MG_HIP(hipGraphLaunch(w->g_all, w->stream));
+            MG_HIP(hipGraphLaunch(w->g_all, w->stream));
             for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
             return MG_OK;
         }
@@ -972,21 +955,12 @@ class ProverImpl : public Prover {
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
         if (graph_mode() == GRAPH_SINGLE) {
-            // Round 4: in a z3 slot the combined MSM is captured as a LINEAR graph on its own stream and replayed next to the G2 one;
-            // as a branch of g_all its first kernel ran 210-290 us into the proof although it waits for the upload only (a captured
-            // graph starts its branches late: profiles/r04_graph_branches.txt) -- and g_all is then linear too (witness map, h MSM).
-            static const bool z3_own = [] {
-                const char *e = std::getenv("MANTA_Z3_OWN_GRAPH");
-                return !(e && std::atoi(e) == 0);
-            }();
-            const bool own = w->z3 && z3_own && msm_stream(w, 0) != w->stream;
-            bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_part_a(w, false, own); });
-            if (ok1 && own) {
-                const MsmArgs a = msm_args(w);
-                w->mw[0]->capturing = true; // a linear capture: nothing inside waits on its `done` event
-                ok1 = capture_segment(msm_stream(w, 0), &w->g_msm[0], [&] { return enqueue_msm(w, a, 0, false); });
-                w->mw[0]->capturing = false;
-            }
+            // (Round 4, measured and withdrawn: the combined MSM of a z3 slot captured as a LINEAR graph of its own and replayed next to
+            // the G2 one started with the upload instead of 210-290 us into the proof and was worth 2-3 % of a sequential proof -- but
+            // with other contexts' passes in flight on the GPU the proof's C element came out WRONG, on a pooled high-priority
+            // stream as on the workspace's own (test_rccl_branch_with_a_one_rank_group caught it; the branch form below is right under
+            // the same load). Three graphs per proof are not worth an unexplained dependency on the runtime's graph executor.)
+            bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_part_a(w, false); });
             if (ok1) {
                 w->mw[2]->capturing = true; // a linear capture: nothing waits on its `done` event
                 ok1 = capture_segment(msm_stream(w, 2), &w->g_g2, [&] { return enqueue_part_b(w, false); });
@@ -1338,7 +1312,6 @@ class ProverImpl : public Prover {
         int rc = MG_OK;
         hipSetDevice(dev_);
         hipError_t e = hipStreamSynchronize(part_a ? w->stream : msm_stream(w, 2));
-        if (e == hipSuccess && part_a && w->z3) e = hipStreamSynchronize(msm_stream(w, 0)); // (its own graph: not joined into w->stream)
         if (e != hipSuccess) {
             set_last_hip_error(e, "prove: hipStreamSynchronize", __FILE__, __LINE__);
             rc = MG_ERR_HIP;
