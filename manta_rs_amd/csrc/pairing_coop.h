@@ -117,6 +117,11 @@ template <class K> struct PairingWave {
         for (int i = 0; i < N; ++i) r.v[i] = (t[i] >> 1) | ((i + 1 < N ? t[i + 1] : (u32)c) << 31);
         return r;
     }
+    // operand k of a level's product on lane k: every lane runs the same instruction stream (a chain of `if (lane == ..)`
+    // branches would execute the products one after another)
+    static MG_DEV F2 pick(int k, const F2 &a0, const F2 &a1, const F2 &a2, const F2 &a3, const F2 &a4) {
+        return F2::select(k == 0, a0, F2::select(k == 1, a1, F2::select(k == 2, a2, F2::select(k == 3, a3, a4))));
+    }
     static MG_DEV F2 half2(const F2 &a) { return F2{half(a.c0), half(a.c1)}; }
     static MG_DEV F2 triple(const F2 &a) { return P::add(P::dbl(a), a); }
 
@@ -435,7 +440,7 @@ template <class K> struct PairingWave {
         return dgt;
     }
     // ---- the ring through which wave 1 of the Miller kernel (G2Prepared::from(Q), below) hands line coefficients to wave 0
-    static constexpr int PREP_WORDS_ = 8 * W; // = PREP_SLOTS * W (the enum is declared further down)
+    static constexpr int PREP_WORDS_ = 40 * W; // = PREP_SLOTS * W (the enum is declared further down)
     static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * P::COEFFW;
     static constexpr size_t miller_lds_bytes() { return (size_t)(CNT_OFF + 2) * 4; }
     static MG_DEV volatile u32 *counters() { return (volatile u32 *)(mg_pairing_lds + CNT_OFF); } // [0] produced, [1] consumed
@@ -485,95 +490,247 @@ template <class K> struct PairingWave {
         if constexpr (K::X_NEG) conj12(f);
     }
 
-    // ---- G2Prepared::from(Q) on one wavefront: the doubling / addition steps of pairing_dev.h with their independent
-    // Fq2 products on different lanes (three / four products deep instead of ten / twelve)
-    enum { SX = 0, SY, SZ, T0, T1, T2, T3, T4, PREP_SLOTS };
+    // ---- G2Prepared::from(Q) on one wavefront, ONE Fq PRODUCT PER LANE (round 4). The first version gave every independent
+    // Fq2 product of a doubling / addition step (ark-ec 0.3 models/bn/g2.rs, bls12/g2.rs: doubling_step, addition_step) a lane
+    // of its own: three / four Fq2 products deep, 2.95 us each, 18 us per step on average -- the chain of wave 1, not wave 0's
+    // Miller loop, bounded a verification's e(A, B) (1.54 against 1.1 ms). Here an Fq2 product is four Fq products on four
+    // lanes (a0 b0, a1 b1, a0 b1, a1 b0: 0.94 us) and every linear combination between two product levels -- the
+    // recombination c0 = t0 - t1, c1 = t2 + t3 included -- is ONE stage of signed sums of at most four Fq operands, each on
+    // the lane of one result component. Both kinds of stage are table driven: a lane's operand slots, signs and destination
+    // for every stage are worked out once per kernel (compile-time tables, selected by lane number) and stay in registers, so
+    // all lanes run one instruction stream. The formulas are rearranged so that no stage needs more than four operands
+    // (same field elements, canonical throughout -- the committed keys stay the known-answer test):
+    //   doubling: XY, B = y^2, C = z^2, J = x^2, YZ | E' = -(3 b') C, F = (9 b') C | M = (B - F) / 2, G = (B + F) / 2, H = 2 YZ,
+    //             coefficients i = -E' - B, 3 J, -H | x3 = XY M, G^2, E' F = -3 e^2, z3 = B H | y3 = G^2 + E' F
+    //   addition: qy z, qx z | theta, lambda | theta^2, lambda^2, theta qx, lambda qy | c, d, j = theta qx - lambda qy, -theta |
+    //             e = lambda d, f = z c, g = x d | e, f, g, 2g | h = e + f - 2g, g - h = g + 2g - e - f |
+    //             lambda h, theta (g - h), e y, z e | x3, y3, z3        (-Q: the signs of the qy terms flip, no other change)
+    enum { SX = 0, SY, SZ, XY, BB, CC, JJ, YZ, NE, FV, MM, GG, HH, CB3, CB9, ZERO, QX, QY, TH, LA, AC, AD, AE, AF, AG, AG2, AH, GH,
+           QP = 30, PREP_SLOTS = 40 }; // Fq2 slots; QP .. QP + 9 hold the (up to twenty) Fq products of a level
     static constexpr size_t prep_lds_bytes() { return (size_t)PREP_SLOTS * W * 4; }
-    // operand k of this level's product on lane k: every lane runs the same instruction stream (a chain of `if (lane == ..)`
-    // branches would execute the products one after another)
-    static MG_DEV F2 pick(int k, const F2 &a0, const F2 &a1, const F2 &a2, const F2 &a3, const F2 &a4) {
-        return F2::select(k == 0, a0, F2::select(k == 1, a1, F2::select(k == 2, a2, F2::select(k == 3, a3, a4))));
+    struct Lin {
+        u32 ops, dst;
+    };
+    static constexpr u32 NONE = 0xffffffffu, NEG = 0x80u, OUT = 0x80u, HALF = 0x100u;
+    static constexpr u32 fq(int slot, int comp) { return 2u * (u32)slot + (u32)comp; } // Fq slot: component comp of an Fq2 slot
+    static constexpr u32 tq(int p, int k) { return fq(QP, 0) + 4u * (u32)p + (u32)k; } // product k of Fq2 product p
+    static constexpr u32 ZQ = fq(ZERO, 0);
+    static constexpr u32 ops(u32 a, u32 b = ZQ, u32 c = ZQ, u32 d = ZQ) { return a | b << 8 | c << 16 | d << 24; } // a + b + c + d, NEG: minus
+    // lane l of a product level: product l / 4 = (Fq2 slot sa) x (Fq2 slot sb), Fq product l % 4 of it
+    static constexpr u32 pent(int l, int sa, int sb) {
+        const int k = l & 3;
+        return fq(sa, k & 1) | fq(sb, (k == 1 || k == 2) ? 1 : 0) << 8;
     }
-    static __device__ __noinline__ void doubling_step(u32 *out) {
-        const F2 x = ld(SX), y = ld(SY), z = ld(SZ), yz = P::add(y, z);
-        if (lane_id() < 5) st(T0 + lane_id(), mul2(pick(lane_id(), x, y, z, x, yz), pick(lane_id(), y, y, z, x, yz))); // xy, y^2, z^2, x^2, (y+z)^2
-        sync();
-        const F2 a = half2(ld(T0)), b = ld(T1), c = ld(T2), j = ld(T3), s = ld(T4);
-        sync();
-        if (lane_id() == 0) st(T0, mul2(P::f2const(K::B2), triple(c)));
-        sync();
-        const F2 e = ld(T0), f = triple(e), g = half2(P::add(b, f)), h = P::sub(s, P::add(b, c)), i = P::sub(e, b);
-        sync();
-        if (lane_id() < 4) st(T0 + lane_id(), mul2(pick(lane_id(), a, g, e, b, b), pick(lane_id(), P::sub(b, f), g, e, h, h))); // x3, g^2, e^2, z3
-        if (lane_id() == 4) {
-            const F2 j3 = triple(j), nh = P::neg(h);
-            if constexpr (K::TWIST_D) P::store_coeff(typename P::Coeff{nh, j3, i}, out);
-            else P::store_coeff(typename P::Coeff{i, j3, nh}, out);
+    // component c of Fq2 product p as two signed operands: c0 = t0 - t1, c1 = t2 + t3
+    static constexpr u32 re0(int p, int c) { return c ? tq(p, 2) : tq(p, 0); }
+    static constexpr u32 re1(int p, int c) { return c ? tq(p, 3) : (tq(p, 1) | NEG); }
+    static constexpr Lin rec(int p, int c, int dst_slot) { return Lin{ops(re0(p, c), re1(p, c)), fq(dst_slot, c)}; }
+    static constexpr int CO_DBL_NH = K::TWIST_D ? 0 : 2, CO_DBL_I = K::TWIST_D ? 2 : 0; // (-h, 3j, i) or (i, 3j, -h)
+    static constexpr int CO_ADD_LA = K::TWIST_D ? 0 : 2, CO_ADD_J = K::TWIST_D ? 2 : 0; // (lambda, -theta, j) or (j, -theta, lambda)
+    // -- doubling
+    static constexpr u32 d_s1(int l) {
+        constexpr int a[5] = {SX, SY, SZ, SX, SY}, b[5] = {SY, SY, SZ, SX, SZ};
+        return l < 20 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    }
+    static constexpr Lin d_r1(int l) {
+        constexpr int d[5] = {XY, BB, CC, JJ, YZ};
+        return l < 10 ? rec(l >> 1, l & 1, d[l >> 1]) : Lin{0, NONE};
+    }
+    static constexpr u32 d_s2(int l) { return l < 8 ? pent(l, (l >> 2) ? CB9 : CB3, CC) : NONE; } // E = 3b' C, F = 9b' C
+    static constexpr Lin d_r2(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return c ? Lin{ops(ZQ, tq(0, 2) | NEG, tq(0, 3) | NEG), fq(NE, 1)} : Lin{ops(tq(0, 1), tq(0, 0) | NEG), fq(NE, 0)}; // -E
+        case 1: return rec(1, c, FV);
+        case 2: return Lin{ops(fq(BB, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(MM, c) | HALF}; // (B - F) / 2
+        case 3: return Lin{ops(fq(BB, c), re0(1, c), re1(1, c)), fq(GG, c) | HALF};             // (B + F) / 2
+        case 4: return Lin{ops(re0(0, c), re1(0, c), fq(BB, c) | NEG), fq(CO_DBL_I, c) | OUT};  // i = E - B
+        case 5: return Lin{ops(fq(YZ, c), fq(YZ, c)), fq(HH, c)};                               // h = (y + z)^2 - b - c = 2 y z
+        case 6: return Lin{ops(ZQ, fq(YZ, c) | NEG, fq(YZ, c) | NEG), fq(CO_DBL_NH, c) | OUT};
+        case 7: return Lin{ops(fq(JJ, c), fq(JJ, c), fq(JJ, c)), fq(1, c) | OUT};
+        default: return Lin{0, NONE};
         }
-        sync();
-        const F2 x3 = ld(T0), y3 = P::sub(ld(T1), triple(ld(T2))), z3 = ld(T3);
-        sync();
-        if (lane_id() < 3) st(SX + lane_id(), pick(lane_id(), x3, y3, z3, z3, z3));
+    }
+    static constexpr u32 d_s3(int l) {
+        constexpr int a[4] = {XY, GG, NE, BB}, b[4] = {MM, GG, FV, HH};
+        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    }
+    static constexpr Lin d_r3(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return rec(0, c, SX);
+        case 1: return Lin{ops(re0(1, c), re1(1, c), re0(2, c), re1(2, c)), fq(SY, c)}; // g^2 - 3 e^2
+        case 2: return rec(3, c, SZ);
+        default: return Lin{0, NONE};
+        }
+    }
+    // -- addition of (QX, +-QY)
+    static constexpr u32 a_s1(int l) { return l < 8 ? pent(l, (l >> 2) ? QX : QY, SZ) : NONE; }
+    static constexpr Lin a_r1(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return Lin{ops(fq(SY, c), re0(0, c) ^ NEG, re1(0, c) ^ NEG), fq(TH, c)};
+        case 1: return Lin{ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(LA, c)};
+        case 2: return Lin{ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(CO_ADD_LA, c) | OUT};
+        default: return Lin{0, NONE};
+        }
+    }
+    static constexpr u32 a_r1_flip(int l) { return (l >> 1) == 0 ? (NEG << 8 | NEG << 16) : 0u; } // -Q: theta = y + qy z
+    static constexpr u32 a_s2(int l) {
+        constexpr int a[4] = {TH, LA, TH, LA}, b[4] = {TH, LA, QX, QY};
+        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    }
+    static constexpr Lin a_r2(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return rec(0, c, AC);
+        case 1: return rec(1, c, AD);
+        case 2: return Lin{ops(re0(2, c), re1(2, c), re0(3, c) ^ NEG, re1(3, c) ^ NEG), fq(CO_ADD_J, c) | OUT};
+        case 3: return Lin{ops(ZQ, fq(TH, c) | NEG), fq(1, c) | OUT};
+        default: return Lin{0, NONE};
+        }
+    }
+    static constexpr u32 a_r2_flip(int l) { return (l >> 1) == 2 ? (NEG << 16 | NEG << 24) : 0u; } // -Q: j = theta qx + lambda qy
+    static constexpr u32 a_s3(int l) {
+        constexpr int a[3] = {LA, SZ, SX}, b[3] = {AD, AC, AD};
+        return l < 12 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    }
+    static constexpr Lin a_r3a(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return rec(0, c, AE);
+        case 1: return rec(1, c, AF);
+        case 2: return rec(2, c, AG);
+        case 3: return Lin{ops(re0(2, c), re1(2, c), re0(2, c), re1(2, c)), fq(AG2, c)};
+        default: return Lin{0, NONE};
+        }
+    }
+    static constexpr Lin a_r3b(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return Lin{ops(fq(AE, c), fq(AF, c), fq(AG2, c) | NEG), fq(AH, c)};
+        case 1: return Lin{ops(fq(AG, c), fq(AG2, c), fq(AE, c) | NEG, fq(AF, c) | NEG), fq(GH, c)};
+        default: return Lin{0, NONE};
+        }
+    }
+    static constexpr u32 a_s4(int l) {
+        constexpr int a[4] = {LA, TH, AE, SZ}, b[4] = {AH, GH, SY, AE};
+        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    }
+    static constexpr Lin a_r4(int l) {
+        const int c = l & 1;
+        switch (l >> 1) {
+        case 0: return rec(0, c, SX);
+        case 1: return Lin{ops(re0(1, c), re1(1, c), re0(2, c) ^ NEG, re1(2, c) ^ NEG), fq(SY, c)};
+        case 2: return rec(3, c, SZ);
+        default: return Lin{0, NONE};
+        }
+    }
+    // this lane's entry of a table (twenty lanes at most take part in a stage)
+    template <u32 (*T)(int)> static MG_DEV u32 lane_u32() {
+        u32 v = T(63);
+#pragma unroll
+        for (int l = 0; l < 20; ++l) v = (lane_id() == l) ? T(l) : v;
+        return v;
+    }
+    template <Lin (*T)(int)> static MG_DEV Lin lane_lin() {
+        Lin v = T(63);
+#pragma unroll
+        for (int l = 0; l < 20; ++l) {
+            const Lin t = T(l);
+            v.ops = (lane_id() == l) ? t.ops : v.ops, v.dst = (lane_id() == l) ? t.dst : v.dst;
+        }
+        return v;
+    }
+    static MG_DEV F ldq(u32 q) { return F::load(base() + q * N); }
+    // u + v or u - v (canonical in and out): p - v stands in for -v (p itself when v = 0; u + p comes back to u)
+    static MG_DEV F addsub(const F &u, const F &v, bool neg) {
+        F w;
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const u64 d = (u64)K::Fq::P[i] - v.v[i] - bw;
+            w.v[i] = neg ? (u32)d : v.v[i];
+            bw = (u32)(d >> 63);
+        }
+        return F::add(u, w);
+    }
+    static MG_DEV void prod_stage(u32 e) {
+        if (e != NONE) F::mul(ldq(e & 255u), ldq((e >> 8) & 255u)).store(base() + (fq(QP, 0) + (u32)lane_id()) * N);
         sync();
     }
-    static __device__ __noinline__ void addition_step(const F2 &qx, const F2 &qy, u32 *out) {
-        const F2 x = ld(SX), y = ld(SY), z = ld(SZ);
-        if (lane_id() < 2) st(T0 + lane_id(), mul2(pick(lane_id(), qy, qx, qx, qx, qx), z));
-        sync();
-        const F2 theta = P::sub(y, ld(T0)), lambda = P::sub(x, ld(T1));
-        sync();
-        if (lane_id() < 4) // theta^2, lambda^2, theta qx, lambda qy
-            st(T0 + lane_id(), mul2(pick(lane_id(), theta, lambda, theta, lambda, lambda), pick(lane_id(), theta, lambda, qx, qy, qy)));
-        sync();
-        const F2 c = ld(T0), d = ld(T1), jj = P::sub(ld(T2), ld(T3));
-        sync();
-        if (lane_id() < 3) st(T0 + lane_id(), mul2(pick(lane_id(), lambda, z, x, x, x), pick(lane_id(), d, c, d, d, d))); // e, f, g
-        sync();
-        const F2 e = ld(T0), f = ld(T1), g = ld(T2), h = P::sub(P::add(e, f), P::dbl(g));
-        sync();
-        if (lane_id() < 4) // x3, theta (g - h), e y, z3
-            st(T0 + lane_id(), mul2(pick(lane_id(), lambda, theta, e, z, z), pick(lane_id(), h, P::sub(g, h), y, e, e)));
-        if (lane_id() == 4) {
-            const F2 nt = P::neg(theta);
-            if constexpr (K::TWIST_D) P::store_coeff(typename P::Coeff{lambda, nt, jj}, out);
-            else P::store_coeff(typename P::Coeff{jj, nt, lambda}, out);
+    template <int NOPS, bool MAY_HALVE = false> static MG_DEV void lin_stage(const Lin e, u32 *out) {
+        if (e.dst != NONE) {
+            F v[NOPS];
+#pragma unroll
+            for (int k = 0; k < NOPS; ++k) v[k] = ldq((e.ops >> (8 * k)) & 127u);
+            F r = v[0];
+#pragma unroll
+            for (int k = 1; k < NOPS; ++k) r = addsub(r, v[k], ((e.ops >> (8 * k + 7)) & 1u) != 0);
+            if constexpr (MAY_HALVE) r = F::select((e.dst & HALF) != 0, half(r), r);
+            r.store((e.dst & OUT) ? out + (e.dst & 127u) * N : base() + (e.dst & 127u) * N);
         }
-        sync();
-        const F2 x3 = ld(T0), y3 = P::sub(ld(T1), ld(T2)), z3 = ld(T3);
-        sync();
-        if (lane_id() < 3) st(SX + lane_id(), pick(lane_id(), x3, y3, z3, z3, z3));
         sync();
     }
     // NCOEFF triples (Q affine, not infinity), in the order the Miller loop consumes them
     template <bool TO_RING> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out) {
         static_assert(PREP_SLOTS * W == PREP_WORDS_, "layout");
-        if (lane_id() == 0) st(SX, qx), st(SY, qy), st(SZ, F2::one());
+        static_assert(fq(PREP_SLOTS, 0) <= 128, "seven bits per operand");
+        const u32 ds1 = lane_u32<d_s1>(), ds2 = lane_u32<d_s2>(), ds3 = lane_u32<d_s3>();
+        const Lin dr1 = lane_lin<d_r1>(), dr2 = lane_lin<d_r2>(), dr3 = lane_lin<d_r3>();
+        const u32 as1 = lane_u32<a_s1>(), as2 = lane_u32<a_s2>(), as3 = lane_u32<a_s3>(), as4 = lane_u32<a_s4>();
+        const Lin ar1 = lane_lin<a_r1>(), ar2 = lane_lin<a_r2>(), ar3a = lane_lin<a_r3a>(), ar3b = lane_lin<a_r3b>(), ar4 = lane_lin<a_r4>();
+        const u32 f1 = lane_u32<a_r1_flip>(), f2 = lane_u32<a_r2_flip>();
+        if (lane_id() == 0) {
+            const F2 b3 = triple(P::f2const(K::B2));
+            st(SX, qx), st(SY, qy), st(SZ, F2::one()), st(QX, qx), st(QY, qy), st(ZERO, F2::zero()), st(CB3, b3), st(CB9, triple(b3));
+        }
         sync();
-        const F2 nqy = P::neg(qy);
         int o = 0;
         auto dst = [&]() { return TO_RING ? ring_reserve(o) : out + (size_t)o * P::COEFFW; };
         auto done = [&]() {
             if constexpr (TO_RING) ring_publish(o);
             ++o;
         };
+        auto doubling = [&]() {
+            u32 *c = dst();
+            prod_stage(ds1);
+            lin_stage<2>(dr1, c);
+            prod_stage(ds2);
+            lin_stage<3, true>(dr2, c);
+            prod_stage(ds3);
+            lin_stage<4>(dr3, c);
+            done();
+        };
+        auto addition = [&](bool minus) {
+            u32 *c = dst();
+            prod_stage(as1);
+            lin_stage<3>(Lin{ar1.ops ^ (minus ? f1 : 0u), ar1.dst}, c);
+            prod_stage(as2);
+            lin_stage<4>(Lin{ar2.ops ^ (minus ? f2 : 0u), ar2.dst}, c);
+            prod_stage(as3);
+            lin_stage<4>(ar3a, c);
+            lin_stage<4>(ar3b, c);
+            prod_stage(as4);
+            lin_stage<4>(ar4, c);
+            done();
+        };
 #pragma unroll 1
         for (int i = K::LOOP_LEN - 2; i >= 0; --i) {
-            doubling_step(dst());
-            done();
+            doubling();
             const signed char dgt = loop_digit(i);
-            if (dgt != 0) {
-                addition_step(qx, dgt > 0 ? qy : nqy, dst());
-                done();
-            }
+            if (dgt != 0) addition(dgt < 0);
         }
         if constexpr (K::BN) { // + pi(Q) - pi^2(Q)
             const F2 tx = P::f2const(K::TWQ_X), ty = P::f2const(K::TWQ_Y);
             const F2 q1x = mul2(P::conj(qx), tx), q1y = mul2(P::conj(qy), ty);
             const F2 q2x = mul2(P::conj(q1x), tx), q2y = P::neg(mul2(P::conj(q1y), ty));
-            addition_step(q1x, q1y, dst());
-            done();
-            addition_step(q2x, q2y, dst());
-            done();
+            if (lane_id() == 0) st(QX, q1x), st(QY, q1y);
+            sync();
+            addition(false);
+            if (lane_id() == 0) st(QX, q2x), st(QY, q2y);
+            sync();
+            addition(false);
         }
     }
 };
