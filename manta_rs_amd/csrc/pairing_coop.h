@@ -227,20 +227,49 @@ template <class K> struct PairingWave {
         sync();
     }
     // f *= line(P), arkworks `ell`: D-type twist (BN254) c0 py + (c1 px) w + c2 w^3 (mul_by_034), M-type (BLS12-381)
-    // c0 + (c1 px) w^2 + (c2 py) w^3 (mul_by_014); co = the coefficient triple in global memory
-    static __device__ __noinline__ void ell(int f, const u32 *co, const F &px, const F &py) {
-        if (lane_id() < 18) {
-            const int i = lane_id() / 3, t = lane_id() - 3 * i;
-            F2 c = F2::load(co + t * W);
-            const int plain = K::TWIST_D ? 2 : 0, with_py = K::TWIST_D ? 0 : 2;
-            if (t != plain) c = mul2_fp(c, F::select(t == with_py, py, px));
-            const int j = K::TWIST_D ? (t == 2 ? 3 : t) : (t == 0 ? 0 : t + 1);
-            F2 v = mul2(ld(f + slot_of(i)), c);
-            if (i + j >= 6) v = mul2_xi(v);
-            st(PROD + 6 * i + j, v);
+    // c0 + (c1 px) w^2 + (c2 py) w^3 (mul_by_014). Round 4: ONE Fq PRODUCT PER LANE. The line arrives as a ring entry made by
+    // wave 1 (below): the three coefficients L_t already scaled by px / py, and xi L_t for the two that can wrap around
+    // w^6 = xi -- so the eighteen Fq2 products f_i L_t are 54 Karatsuba products on 54 lanes (one product deep), stage B puts
+    // the 36 Fq components together (t0 - t1, t2 - t0 - t1) and stage C adds the three that make up each component of the
+    // result: 2.1 us against the 7.9 of the first version (an Fq2-by-Fq product, an Fq2 product and the xi multiple, all
+    // on the lane of one coefficient product).
+    static constexpr int LINE_J(int t) { return K::TWIST_D ? (t == 2 ? 3 : t) : (t == 0 ? 0 : t + 1); } // L_t sits at w^LINE_J(t)
+    static constexpr int RINGW = 5 * W; // ring entry: L_0, L_1, L_2, xi L_1, xi L_2
+    static __device__ __noinline__ void ell(int f, int o) {
+        const int l = lane_id();
+        const u32 *e = ring_slot(o);
+        u32 *q = base() + PROD * W; // Fq slot s = q + s N (72 of them)
+        if (l < 54) {
+            const int pr = l / 3, k = l - 3 * pr, i = pr / 3, t = pr - 3 * i;
+            const int j = t == 0 ? LINE_J(0) : (t == 1 ? LINE_J(1) : LINE_J(2));
+            const F2 fi = ld(f + slot_of(i)), lt = F2::load(e + ((i + j >= 6) ? 2 + t : t) * W);
+            const F x = F::select(k == 0, fi.c0, F::select(k == 1, fi.c1, F::add(fi.c0, fi.c1)));
+            const F y = F::select(k == 0, lt.c0, F::select(k == 1, lt.c1, F::add(lt.c0, lt.c1)));
+            F::mul(x, y).store(q + l * N);
         }
         sync();
-        fold(f, K::TWIST_D ? 0x0bu : 0x0du);
+        F v = F::zero();
+        if (l < 36) { // component (l & 1) of product l / 2; written over the products once every lane has read its three
+            const int pr = l >> 1, comp = l & 1;
+            const F t0 = F::load(q + 3 * pr * N), t1 = F::load(q + (3 * pr + 1) * N), t2 = F::load(q + (3 * pr + 2) * N);
+            const F d = F::sub(F::select(comp != 0, t2, t0), F::select(comp != 0, t0, t1));
+            v = F::select(comp != 0, F::sub(d, t1), d);
+        }
+        sync();
+        if (l < 36) v.store(q + l * N);
+        sync();
+        if (l < 12) { // component comp of the coefficient of w^m: the products f_i L_t with i + LINE_J(t) = m (mod 6)
+            const int m = l >> 1, comp = l & 1;
+            F acc[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                int i = m - LINE_J(t);
+                i += i < 0 ? 6 : 0;
+                acc[t] = F::load(q + (2 * (3 * i + t) + comp) * N);
+            }
+            F::add(F::add(acc[0], acc[1]), acc[2]).store(base() + (f + slot_of(m)) * W + comp * N);
+        }
+        sync();
     }
     static MG_DEV void set_one(int d) {
         if (lane_id() < 6) st(d + lane_id(), lane_id() == 0 ? F2::one() : F2::zero());
@@ -439,22 +468,24 @@ template <class K> struct PairingWave {
         for (int k = 0; k < K::LOOP_LEN; ++k) dgt = (k == i) ? K::LOOP[k] : dgt;
         return dgt;
     }
-    // ---- the ring through which wave 1 of the Miller kernel (G2Prepared::from(Q), below) hands line coefficients to wave 0
-    static constexpr int PREP_WORDS_ = 40 * W; // = PREP_SLOTS * W (the enum is declared further down)
-    static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * P::COEFFW;
+    // ---- the ring through which wave 1 of the Miller kernel hands lines to wave 0. An entry is what `ell` multiplies with
+    // (RINGW words: the scaled coefficients and their xi multiples); wave 1 makes it either from G2Prepared::from(Q) as that
+    // runs (prepare<true>, below) or from a stored coefficient table (scale_stored)
+    static constexpr int PREP_WORDS_ = 46 * W; // = PREP_SLOTS * W (the enum is declared further down)
+    static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * RINGW;
     static constexpr size_t miller_lds_bytes() { return (size_t)(CNT_OFF + 2) * 4; }
     static MG_DEV volatile u32 *counters() { return (volatile u32 *)(mg_pairing_lds + CNT_OFF); } // [0] produced, [1] consumed
-    static MG_DEV u32 *ring_slot(int o) { return mg_pairing_lds + RING_OFF + (o % RING) * P::COEFFW; }
-    static MG_DEV const u32 *ring_acquire(int o) { // consumer: triple number o is complete
+    static MG_DEV u32 *ring_slot(int o) { return mg_pairing_lds + RING_OFF + (o % RING) * RINGW; }
+    static MG_DEV const u32 *ring_acquire(int o) { // consumer: entry number o is complete
         while ((int)counters()[0] <= o) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return ring_slot(o);
     }
-    static MG_DEV void ring_release(int o) { // consumer: done with triples 0..o
+    static MG_DEV void ring_release(int o) { // consumer: done with entries 0..o
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane_id() == 0) counters()[1] = (u32)(o + 1);
     }
-    static MG_DEV u32 *ring_reserve(int o) { // producer: the slot of triple o is free again
+    static MG_DEV u32 *ring_reserve(int o) { // producer: the slot of entry o is free again
         while (o - (int)counters()[1] >= RING) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         return ring_slot(o);
@@ -463,18 +494,14 @@ template <class K> struct PairingWave {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane_id() == 0) counters()[0] = (u32)(o + 1);
     }
-    // register f := Miller loop of ONE pair: P affine G1 (px, py); Q as prepared coefficients in memory, or (FRESH) as they
-    // come out of wave 1's G2 arithmetic
-    template <bool FRESH> static __device__ void miller(int f, const F &px, const F &py, const u32 *coeffs) {
+    // register f := Miller loop of ONE pair; the NCOEFF lines come through the ring in the order of G2Prepared's table
+    static __device__ void miller(int f) {
         set_one(f);
         int o = 0;
         auto line = [&]() {
-            if constexpr (FRESH) {
-                ell(f, ring_acquire(o), px, py);
-                ring_release(o);
-            } else {
-                ell(f, coeffs + (size_t)o * P::COEFFW, px, py);
-            }
+            ring_acquire(o);
+            ell(f, o);
+            ring_release(o);
             ++o;
         };
 #pragma unroll 1
@@ -489,7 +516,28 @@ template <class K> struct PairingWave {
         }
         if constexpr (K::X_NEG) conj12(f);
     }
-
+    // wave 1, Q prepared in advance (the verifying key's -gamma, -delta; arkworks' table of NCOEFF triples in global memory):
+    // scale each triple by P's coordinates, add the xi multiples, hand it on -- well ahead of wave 0, which so never waits
+    // for a global load
+    static constexpr int T_PLAIN = K::TWIST_D ? 2 : 0, T_PY = K::TWIST_D ? 0 : 2; // t = 1 is scaled by px on both twists
+    static __device__ void scale_stored(const u32 *co, const F &px, const F &py) {
+        const int l = lane_id();
+        const F one = F::one();
+#pragma unroll 1
+        for (int o = 0; o < P::NCOEFF; ++o) {
+            F raw = F::zero();
+            const int t = l >> 1, comp = l & 1;
+            if (l < 6) raw = F::load(co + (size_t)o * P::COEFFW + t * W + comp * N);
+            u32 *e = ring_reserve(o);
+            if (l < 6) F::mul(raw, F::select(t == T_PLAIN, one, F::select(t == T_PY, py, px))).store(e + t * W + comp * N);
+            sync();
+            if (l >= 2 && l < 6) { // xi L_t, t = 1, 2
+                const F a = F::load(e + t * W + comp * N), b = F::load(e + t * W + (comp ^ 1) * N);
+                addsub(xi_real(a), b, comp == 0).store(e + (2 + t) * W + comp * N);
+            }
+            ring_publish(o);
+        }
+    }
     // ---- G2Prepared::from(Q) on one wavefront, ONE Fq PRODUCT PER LANE (round 4). The first version gave every independent
     // Fq2 product of a doubling / addition step (ark-ec 0.3 models/bn/g2.rs, bls12/g2.rs: doubling_step, addition_step) a lane
     // of its own: three / four Fq2 products deep, 2.95 us each, 18 us per step on average -- the chain of wave 1, not wave 0's
@@ -506,140 +554,193 @@ template <class K> struct PairingWave {
     //             e = lambda d, f = z c, g = x d | e, f, g, 2g | h = e + f - 2g, g - h = g + 2g - e - f |
     //             lambda h, theta (g - h), e y, z e | x3, y3, z3        (-Q: the signs of the qy terms flip, no other change)
     enum { SX = 0, SY, SZ, XY, BB, CC, JJ, YZ, NE, FV, MM, GG, HH, CB3, CB9, ZERO, QX, QY, TH, LA, AC, AD, AE, AF, AG, AG2, AH, GH,
-           QP = 30, PREP_SLOTS = 40 }; // Fq2 slots; QP .. QP + 9 hold the (up to twenty) Fq products of a level
+           CR0, CR1, CR2, // line coefficients before their scaling by px / py
+           SL1, SL2,      // L_1, L_2 once more, for the stage that makes xi L_t
+           PXY,           // (px, py)
+           QP,            // QP .. QP + 11 hold the (up to twenty-four) Fq products of a level
+           PREP_SLOTS = QP + 12 };
     static constexpr size_t prep_lds_bytes() { return (size_t)PREP_SLOTS * W * 4; }
+    static constexpr int LANES = 24; // lanes that take part in a stage, at most
     struct Lin {
         u32 ops, dst;
     };
-    static constexpr u32 NONE = 0xffffffffu, NEG = 0x80u, OUT = 0x80u, HALF = 0x100u;
+    static constexpr u32 NONE = 0xffffffffu, NEG = 0x80u, OUT = 0x80u, HALF = 0x100u, XI = 0x200u, DEFAULT_DST = 0xffu;
     static constexpr u32 fq(int slot, int comp) { return 2u * (u32)slot + (u32)comp; } // Fq slot: component comp of an Fq2 slot
     static constexpr u32 tq(int p, int k) { return fq(QP, 0) + 4u * (u32)p + (u32)k; } // product k of Fq2 product p
     static constexpr u32 ZQ = fq(ZERO, 0);
     static constexpr u32 ops(u32 a, u32 b = ZQ, u32 c = ZQ, u32 d = ZQ) { return a | b << 8 | c << 16 | d << 24; } // a + b + c + d, NEG: minus
-    // lane l of a product level: product l / 4 = (Fq2 slot sa) x (Fq2 slot sb), Fq product l % 4 of it
-    static constexpr u32 pent(int l, int sa, int sb) {
-        const int k = l & 3;
-        return fq(sa, k & 1) | fq(sb, (k == 1 || k == 2) ? 1 : 0) << 8;
-    }
     // component c of Fq2 product p as two signed operands: c0 = t0 - t1, c1 = t2 + t3
     static constexpr u32 re0(int p, int c) { return c ? tq(p, 2) : tq(p, 0); }
     static constexpr u32 re1(int p, int c) { return c ? tq(p, 3) : (tq(p, 1) | NEG); }
-    static constexpr Lin rec(int p, int c, int dst_slot) { return Lin{ops(re0(p, c), re1(p, c)), fq(dst_slot, c)}; }
-    static constexpr int CO_DBL_NH = K::TWIST_D ? 0 : 2, CO_DBL_I = K::TWIST_D ? 2 : 0; // (-h, 3j, i) or (i, 3j, -h)
-    static constexpr int CO_ADD_LA = K::TWIST_D ? 0 : 2, CO_ADD_J = K::TWIST_D ? 2 : 0; // (lambda, -theta, j) or (j, -theta, lambda)
+    struct ProdTab { // a product level: lane l multiplies Fq slots (e & 255) and (e >> 8 & 255); result to QP's slot l, or where e >> 16 says
+        u32 e[LANES] = {};
+        int n = 0;
+        constexpr void put(u32 a, u32 b, u32 dst = DEFAULT_DST) { e[n++] = a | b << 8 | dst << 16; }
+        constexpr void product(int sa, int sb) { // Fq2 slot sa x Fq2 slot sb on four lanes: a0 b0, a1 b1, a0 b1, a1 b0
+            for (int k = 0; k < 4; ++k) put(fq(sa, k & 1), fq(sb, (k == 1 || k == 2) ? 1 : 0));
+        }
+        // ring mode: coefficient t (raw in Fq2 slot raw) times px / py, to the ring entry and -- t = 1, 2 -- to SL_t
+        constexpr void scale(int t, int raw) {
+            for (int c = 0; c < 2; ++c) {
+                put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), OUT | fq(t, c));
+                if (t >= 1) put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), fq(t == 1 ? SL1 : SL2, c));
+            }
+        }
+    };
+    struct LinTab { // a linear level: lane l adds up (at most four) signed Fq slots
+        Lin e[LANES] = {};
+        u32 flip[LANES] = {}; // sign changes of the operands when -Q is added instead of Q
+        int n = 0;
+        constexpr void put(u32 o, u32 dst, u32 fl = 0) { e[n] = Lin{o, dst}, flip[n] = fl, ++n; }
+        constexpr void rec(int p, int dst_slot) { // Fq2 product p put together
+            for (int c = 0; c < 2; ++c) put(ops(re0(p, c), re1(p, c)), fq(dst_slot, c));
+        }
+        // component c of line coefficient t: arkworks' table (raw mode) / the ring entry or the slot its scaling reads (ring mode)
+        constexpr void coeff(bool ring, int t, int c, u32 o, u32 fl = 0) {
+            if (!ring || t == T_PLAIN) {
+                put(o, OUT | fq(t, c), fl);
+                if (ring && t >= 1) put(o, fq(t == 1 ? SL1 : SL2, c), fl);
+            } else {
+                put(o, fq(CR0 + t, c), fl);
+            }
+        }
+        constexpr void xi_multiples() { // ring mode: xi L_t = (U0 c0 - c1) + (U0 c1 + c0) u, t = 1, 2
+            for (int t = 1; t <= 2; ++t) {
+                const int sl = t == 1 ? SL1 : SL2;
+                put(ops(fq(sl, 0), fq(sl, 1) | NEG), OUT | XI | fq(2 + t, 0));
+                put(ops(fq(sl, 1), fq(sl, 0)), OUT | XI | fq(2 + t, 1));
+            }
+        }
+    };
+    static constexpr int T_DBL_NH = K::TWIST_D ? 0 : 2, T_DBL_I = K::TWIST_D ? 2 : 0; // (-h, 3j, i) or (i, 3j, -h)
+    static constexpr int T_ADD_LA = K::TWIST_D ? 0 : 2, T_ADD_J = K::TWIST_D ? 2 : 0; // (lambda, -theta, j) or (j, -theta, lambda)
     // -- doubling
-    static constexpr u32 d_s1(int l) {
-        constexpr int a[5] = {SX, SY, SZ, SX, SY}, b[5] = {SY, SY, SZ, SX, SZ};
-        return l < 20 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    static constexpr ProdTab d_s1() {
+        ProdTab t;
+        t.product(SX, SY), t.product(SY, SY), t.product(SZ, SZ), t.product(SX, SX), t.product(SY, SZ);
+        return t;
     }
-    static constexpr Lin d_r1(int l) {
-        constexpr int d[5] = {XY, BB, CC, JJ, YZ};
-        return l < 10 ? rec(l >> 1, l & 1, d[l >> 1]) : Lin{0, NONE};
+    static constexpr LinTab d_r1() {
+        LinTab t;
+        t.rec(0, XY), t.rec(1, BB), t.rec(2, CC), t.rec(3, JJ), t.rec(4, YZ);
+        return t;
     }
-    static constexpr u32 d_s2(int l) { return l < 8 ? pent(l, (l >> 2) ? CB9 : CB3, CC) : NONE; } // E = 3b' C, F = 9b' C
-    static constexpr Lin d_r2(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return c ? Lin{ops(ZQ, tq(0, 2) | NEG, tq(0, 3) | NEG), fq(NE, 1)} : Lin{ops(tq(0, 1), tq(0, 0) | NEG), fq(NE, 0)}; // -E
-        case 1: return rec(1, c, FV);
-        case 2: return Lin{ops(fq(BB, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(MM, c) | HALF}; // (B - F) / 2
-        case 3: return Lin{ops(fq(BB, c), re0(1, c), re1(1, c)), fq(GG, c) | HALF};             // (B + F) / 2
-        case 4: return Lin{ops(re0(0, c), re1(0, c), fq(BB, c) | NEG), fq(CO_DBL_I, c) | OUT};  // i = E - B
-        case 5: return Lin{ops(fq(YZ, c), fq(YZ, c)), fq(HH, c)};                               // h = (y + z)^2 - b - c = 2 y z
-        case 6: return Lin{ops(ZQ, fq(YZ, c) | NEG, fq(YZ, c) | NEG), fq(CO_DBL_NH, c) | OUT};
-        case 7: return Lin{ops(fq(JJ, c), fq(JJ, c), fq(JJ, c)), fq(1, c) | OUT};
-        default: return Lin{0, NONE};
+    static constexpr ProdTab d_s2() { // E = 3b' C, F = 9b' C
+        ProdTab t;
+        t.product(CB3, CC), t.product(CB9, CC);
+        return t;
+    }
+    template <bool RG> static constexpr LinTab d_r2() {
+        LinTab t;
+        t.put(ops(tq(0, 1), tq(0, 0) | NEG), fq(NE, 0)), t.put(ops(ZQ, tq(0, 2) | NEG, tq(0, 3) | NEG), fq(NE, 1)); // -E
+        t.rec(1, FV);
+        for (int c = 0; c < 2; ++c) {
+            t.put(ops(fq(BB, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(MM, c) | HALF); // (B - F) / 2
+            t.put(ops(fq(BB, c), re0(1, c), re1(1, c)), fq(GG, c) | HALF);             // (B + F) / 2
+            t.put(ops(fq(YZ, c), fq(YZ, c)), fq(HH, c));                               // h = (y + z)^2 - b - c = 2 y z
+            t.coeff(RG, T_DBL_I, c, ops(re0(0, c), re1(0, c), fq(BB, c) | NEG));       // i = E - B
+            t.coeff(RG, T_DBL_NH, c, ops(ZQ, fq(YZ, c) | NEG, fq(YZ, c) | NEG));
+            t.coeff(RG, 1, c, ops(fq(JJ, c), fq(JJ, c), fq(JJ, c)));
         }
+        return t;
     }
-    static constexpr u32 d_s3(int l) {
-        constexpr int a[4] = {XY, GG, NE, BB}, b[4] = {MM, GG, FV, HH};
-        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    template <bool RG> static constexpr ProdTab d_s3() {
+        ProdTab t;
+        t.product(XY, MM), t.product(GG, GG), t.product(NE, FV), t.product(BB, HH);
+        if (RG) t.scale(T_PY, CR0 + T_PY), t.scale(1, CR1);
+        return t;
     }
-    static constexpr Lin d_r3(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return rec(0, c, SX);
-        case 1: return Lin{ops(re0(1, c), re1(1, c), re0(2, c), re1(2, c)), fq(SY, c)}; // g^2 - 3 e^2
-        case 2: return rec(3, c, SZ);
-        default: return Lin{0, NONE};
-        }
+    template <bool RG> static constexpr LinTab d_r3() {
+        LinTab t;
+        t.rec(0, SX);
+        for (int c = 0; c < 2; ++c) t.put(ops(re0(1, c), re1(1, c), re0(2, c), re1(2, c)), fq(SY, c)); // g^2 - 3 e^2
+        t.rec(3, SZ);
+        if (RG) t.xi_multiples();
+        return t;
     }
     // -- addition of (QX, +-QY)
-    static constexpr u32 a_s1(int l) { return l < 8 ? pent(l, (l >> 2) ? QX : QY, SZ) : NONE; }
-    static constexpr Lin a_r1(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return Lin{ops(fq(SY, c), re0(0, c) ^ NEG, re1(0, c) ^ NEG), fq(TH, c)};
-        case 1: return Lin{ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(LA, c)};
-        case 2: return Lin{ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(CO_ADD_LA, c) | OUT};
-        default: return Lin{0, NONE};
+    static constexpr ProdTab a_s1() {
+        ProdTab t;
+        t.product(QY, SZ), t.product(QX, SZ);
+        return t;
+    }
+    template <bool RG> static constexpr LinTab a_r1() {
+        LinTab t;
+        for (int c = 0; c < 2; ++c) {
+            t.put(ops(fq(SY, c), re0(0, c) ^ NEG, re1(0, c) ^ NEG), fq(TH, c), NEG << 8 | NEG << 16); // -Q: theta = y + qy z
+            t.put(ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), fq(LA, c));
+            if (!RG) t.put(ops(fq(SX, c), re0(1, c) ^ NEG, re1(1, c) ^ NEG), OUT | fq(T_ADD_LA, c));
         }
+        return t;
     }
-    static constexpr u32 a_r1_flip(int l) { return (l >> 1) == 0 ? (NEG << 8 | NEG << 16) : 0u; } // -Q: theta = y + qy z
-    static constexpr u32 a_s2(int l) {
-        constexpr int a[4] = {TH, LA, TH, LA}, b[4] = {TH, LA, QX, QY};
-        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    static constexpr ProdTab a_s2() {
+        ProdTab t;
+        t.product(TH, TH), t.product(LA, LA), t.product(TH, QX), t.product(LA, QY);
+        return t;
     }
-    static constexpr Lin a_r2(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return rec(0, c, AC);
-        case 1: return rec(1, c, AD);
-        case 2: return Lin{ops(re0(2, c), re1(2, c), re0(3, c) ^ NEG, re1(3, c) ^ NEG), fq(CO_ADD_J, c) | OUT};
-        case 3: return Lin{ops(ZQ, fq(TH, c) | NEG), fq(1, c) | OUT};
-        default: return Lin{0, NONE};
+    template <bool RG> static constexpr LinTab a_r2() {
+        LinTab t;
+        t.rec(0, AC), t.rec(1, AD);
+        for (int c = 0; c < 2; ++c) {
+            t.coeff(RG, T_ADD_J, c, ops(re0(2, c), re1(2, c), re0(3, c) ^ NEG, re1(3, c) ^ NEG), NEG << 16 | NEG << 24); // -Q: + lambda qy
+            t.coeff(RG, 1, c, ops(ZQ, fq(TH, c) | NEG));
         }
+        return t;
     }
-    static constexpr u32 a_r2_flip(int l) { return (l >> 1) == 2 ? (NEG << 16 | NEG << 24) : 0u; } // -Q: j = theta qx + lambda qy
-    static constexpr u32 a_s3(int l) {
-        constexpr int a[3] = {LA, SZ, SX}, b[3] = {AD, AC, AD};
-        return l < 12 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    template <bool RG> static constexpr ProdTab a_s3() {
+        ProdTab t;
+        t.product(LA, AD), t.product(SZ, AC), t.product(SX, AD);
+        if (RG) t.scale(T_PY, LA), t.scale(1, CR1); // (lambda is the coefficient that py scales on either twist)
+        return t;
     }
-    static constexpr Lin a_r3a(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return rec(0, c, AE);
-        case 1: return rec(1, c, AF);
-        case 2: return rec(2, c, AG);
-        case 3: return Lin{ops(re0(2, c), re1(2, c), re0(2, c), re1(2, c)), fq(AG2, c)};
-        default: return Lin{0, NONE};
+    template <bool RG> static constexpr LinTab a_r3a() {
+        LinTab t;
+        t.rec(0, AE), t.rec(1, AF), t.rec(2, AG);
+        for (int c = 0; c < 2; ++c) t.put(ops(re0(2, c), re1(2, c), re0(2, c), re1(2, c)), fq(AG2, c));
+        if (RG) t.xi_multiples();
+        return t;
+    }
+    static constexpr LinTab a_r3b() {
+        LinTab t;
+        for (int c = 0; c < 2; ++c) {
+            t.put(ops(fq(AE, c), fq(AF, c), fq(AG2, c) | NEG), fq(AH, c));
+            t.put(ops(fq(AG, c), fq(AG2, c), fq(AE, c) | NEG, fq(AF, c) | NEG), fq(GH, c));
         }
+        return t;
     }
-    static constexpr Lin a_r3b(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return Lin{ops(fq(AE, c), fq(AF, c), fq(AG2, c) | NEG), fq(AH, c)};
-        case 1: return Lin{ops(fq(AG, c), fq(AG2, c), fq(AE, c) | NEG, fq(AF, c) | NEG), fq(GH, c)};
-        default: return Lin{0, NONE};
-        }
+    static constexpr ProdTab a_s4() {
+        ProdTab t;
+        t.product(LA, AH), t.product(TH, GH), t.product(AE, SY), t.product(SZ, AE);
+        return t;
     }
-    static constexpr u32 a_s4(int l) {
-        constexpr int a[4] = {LA, TH, AE, SZ}, b[4] = {AH, GH, SY, AE};
-        return l < 16 ? pent(l, a[l >> 2], b[l >> 2]) : NONE;
+    static constexpr LinTab a_r4() {
+        LinTab t;
+        t.rec(0, SX);
+        for (int c = 0; c < 2; ++c) t.put(ops(re0(1, c), re1(1, c), re0(2, c) ^ NEG, re1(2, c) ^ NEG), fq(SY, c));
+        t.rec(3, SZ);
+        return t;
     }
-    static constexpr Lin a_r4(int l) {
-        const int c = l & 1;
-        switch (l >> 1) {
-        case 0: return rec(0, c, SX);
-        case 1: return Lin{ops(re0(1, c), re1(1, c), re0(2, c) ^ NEG, re1(2, c) ^ NEG), fq(SY, c)};
-        case 2: return rec(3, c, SZ);
-        default: return Lin{0, NONE};
-        }
-    }
-    // this lane's entry of a table (twenty lanes at most take part in a stage)
-    template <u32 (*T)(int)> static MG_DEV u32 lane_u32() {
-        u32 v = T(63);
+    static_assert(T_ADD_LA == T_PY, "lambda is the coefficient scaled by py");
+    // this lane's entry of a table (worked out once per kernel: a chain of selects over compile-time values)
+    template <class Tab> static MG_DEV u32 lane_prod(const Tab t) {
+        u32 v = NONE;
 #pragma unroll
-        for (int l = 0; l < 20; ++l) v = (lane_id() == l) ? T(l) : v;
+        for (int l = 0; l < LANES; ++l) v = (l < t.n && lane_id() == l) ? t.e[l] : v;
         return v;
     }
-    template <Lin (*T)(int)> static MG_DEV Lin lane_lin() {
-        Lin v = T(63);
+    static MG_DEV Lin lane_lin(const LinTab t) {
+        Lin v{0u, NONE};
 #pragma unroll
-        for (int l = 0; l < 20; ++l) {
-            const Lin t = T(l);
-            v.ops = (lane_id() == l) ? t.ops : v.ops, v.dst = (lane_id() == l) ? t.dst : v.dst;
+        for (int l = 0; l < LANES; ++l) {
+            const bool me = l < t.n && lane_id() == l;
+            v.ops = me ? t.e[l].ops : v.ops, v.dst = me ? t.e[l].dst : v.dst;
         }
+        return v;
+    }
+    static MG_DEV u32 lane_flip(const LinTab t) {
+        u32 v = 0;
+#pragma unroll
+        for (int l = 0; l < LANES; ++l) v = (l < t.n && lane_id() == l) ? t.flip[l] : v;
         return v;
     }
     static MG_DEV F ldq(u32 q) { return F::load(base() + q * N); }
@@ -655,63 +756,71 @@ template <class K> struct PairingWave {
         }
         return F::add(u, w);
     }
-    static MG_DEV void prod_stage(u32 e) {
-        if (e != NONE) F::mul(ldq(e & 255u), ldq((e >> 8) & 255u)).store(base() + (fq(QP, 0) + (u32)lane_id()) * N);
+    static MG_DEV u32 *dst_of(u32 d, u32 *out) { return (d & OUT) ? out + (d & 127u) * N : base() + (d & 127u) * N; }
+    static MG_DEV void prod_stage(u32 e, u32 *out) {
+        if (e != NONE) {
+            const u32 d = (e >> 16) & 255u;
+            F::mul(ldq(e & 255u), ldq((e >> 8) & 255u)).store(d == DEFAULT_DST ? base() + (fq(QP, 0) + (u32)lane_id()) * N : dst_of(d, out));
+        }
         sync();
     }
-    template <int NOPS, bool MAY_HALVE = false> static MG_DEV void lin_stage(const Lin e, u32 *out) {
+    template <int NOPS, bool MAY_HALVE = false, bool MAY_XI = false> static MG_DEV void lin_stage(const Lin e, u32 *out) {
         if (e.dst != NONE) {
             F v[NOPS];
 #pragma unroll
             for (int k = 0; k < NOPS; ++k) v[k] = ldq((e.ops >> (8 * k)) & 127u);
             F r = v[0];
+            if constexpr (MAY_XI) r = F::select((e.dst & XI) != 0, xi_real(r), r);
 #pragma unroll
             for (int k = 1; k < NOPS; ++k) r = addsub(r, v[k], ((e.ops >> (8 * k + 7)) & 1u) != 0);
             if constexpr (MAY_HALVE) r = F::select((e.dst & HALF) != 0, half(r), r);
-            r.store((e.dst & OUT) ? out + (e.dst & 127u) * N : base() + (e.dst & 127u) * N);
+            r.store(dst_of(e.dst, out));
         }
         sync();
     }
-    // NCOEFF triples (Q affine, not infinity), in the order the Miller loop consumes them
-    template <bool TO_RING> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out) {
+    // The NCOEFF line-coefficient triples of Q (affine, not infinity) in the order the Miller loop consumes them: as arkworks'
+    // table in global memory (RG = false: g2_prepare_kernel), or as ring entries for wave 0's Miller loop with P = (px, py)
+    template <bool RG> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out, const F &px, const F &py) {
         static_assert(PREP_SLOTS * W == PREP_WORDS_, "layout");
         static_assert(fq(PREP_SLOTS, 0) <= 128, "seven bits per operand");
-        const u32 ds1 = lane_u32<d_s1>(), ds2 = lane_u32<d_s2>(), ds3 = lane_u32<d_s3>();
-        const Lin dr1 = lane_lin<d_r1>(), dr2 = lane_lin<d_r2>(), dr3 = lane_lin<d_r3>();
-        const u32 as1 = lane_u32<a_s1>(), as2 = lane_u32<a_s2>(), as3 = lane_u32<a_s3>(), as4 = lane_u32<a_s4>();
-        const Lin ar1 = lane_lin<a_r1>(), ar2 = lane_lin<a_r2>(), ar3a = lane_lin<a_r3a>(), ar3b = lane_lin<a_r3b>(), ar4 = lane_lin<a_r4>();
-        const u32 f1 = lane_u32<a_r1_flip>(), f2 = lane_u32<a_r2_flip>();
+        const u32 ds1 = lane_prod(d_s1()), ds2 = lane_prod(d_s2()), ds3 = lane_prod(d_s3<RG>());
+        const Lin dr1 = lane_lin(d_r1()), dr2 = lane_lin(d_r2<RG>()), dr3 = lane_lin(d_r3<RG>());
+        const u32 as1 = lane_prod(a_s1()), as2 = lane_prod(a_s2()), as3 = lane_prod(a_s3<RG>()), as4 = lane_prod(a_s4());
+        const Lin ar1 = lane_lin(a_r1<RG>()), ar2 = lane_lin(a_r2<RG>()), ar3a = lane_lin(a_r3a<RG>()), ar3b = lane_lin(a_r3b()),
+                  ar4 = lane_lin(a_r4());
+        const u32 f1 = lane_flip(a_r1<RG>()), f2 = lane_flip(a_r2<RG>());
         if (lane_id() == 0) {
             const F2 b3 = triple(P::f2const(K::B2));
             st(SX, qx), st(SY, qy), st(SZ, F2::one()), st(QX, qx), st(QY, qy), st(ZERO, F2::zero()), st(CB3, b3), st(CB9, triple(b3));
+            st(PXY, F2{px, py});
         }
         sync();
         int o = 0;
-        auto dst = [&]() { return TO_RING ? ring_reserve(o) : out + (size_t)o * P::COEFFW; };
+        auto dst = [&]() { return RG ? ring_reserve(o) : out + (size_t)o * P::COEFFW; };
         auto done = [&]() {
-            if constexpr (TO_RING) ring_publish(o);
+            if constexpr (RG) ring_publish(o);
             ++o;
         };
         auto doubling = [&]() {
             u32 *c = dst();
-            prod_stage(ds1);
+            prod_stage(ds1, c);
             lin_stage<2>(dr1, c);
-            prod_stage(ds2);
+            prod_stage(ds2, c);
             lin_stage<3, true>(dr2, c);
-            prod_stage(ds3);
-            lin_stage<4>(dr3, c);
+            prod_stage(ds3, c);
+            lin_stage<4, false, RG>(dr3, c);
             done();
         };
         auto addition = [&](bool minus) {
             u32 *c = dst();
-            prod_stage(as1);
+            prod_stage(as1, c);
             lin_stage<3>(Lin{ar1.ops ^ (minus ? f1 : 0u), ar1.dst}, c);
-            prod_stage(as2);
+            prod_stage(as2, c);
             lin_stage<4>(Lin{ar2.ops ^ (minus ? f2 : 0u), ar2.dst}, c);
-            prod_stage(as3);
-            lin_stage<4>(ar3a, c);
+            prod_stage(as3, c);
+            lin_stage<4, false, RG>(ar3a, c);
             lin_stage<4>(ar3b, c);
-            prod_stage(as4);
+            prod_stage(as4, c);
             lin_stage<4>(ar4, c);
             done();
         };

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void g2_prepare_kernel(const u32 *__restrict__ 
         for (int k = threadIdx.x; k < P::NCOEFF * P::COEFFW; k += 64) o[k] = 0;
         return;
     }
-    w::template prepare<false>(qx, qy, o);
+    w::template prepare<false>(qx, qy, o, P::F::zero(), P::F::zero());
 }
 
 // workgroup i (two wavefronts): f_i = Miller(P_i, Q_i); a pair with an infinity member contributes 1 (ark-ec filters such
@@ -44,16 +44,14 @@ __global__ __launch_bounds__(128) void miller_kernel(const u32 *__restrict__ p, 
     const bool one = skip[i] || (px.is_zero() && py.is_zero());
     if (threadIdx.x == 0) w::counters()[0] = 0, w::counters()[1] = 0;
     __syncthreads(); // the only workgroup barrier: from here on the two wavefronts run different programs
-    if (w::wave_id() == 1) {
-        if (!co && !one) {
-            const u32 *qi = q + i * 2 * P::F2W;
-            w::template prepare<true>(P::F2::load(qi), P::F2::load(qi + P::F2W), nullptr);
-        }
+    if (w::wave_id() == 1) { // the lines, as ring entries: from the stored table of Q, or from G2Prepared::from(Q) as it runs
+        if (one) return;
+        if (co) w::scale_stored(co, px, py);
+        else w::template prepare<true>(P::F2::load(q + i * 2 * P::F2W), P::F2::load(q + i * 2 * P::F2W + P::F2W), nullptr, px, py);
         return;
     }
     if (one) w::set_one(PW::R(0));
-    else if (co) w::template miller<false>(PW::R(0), px, py, co);
-    else w::template miller<true>(PW::R(0), px, py, nullptr);
+    else w::miller(PW::R(0));
     if (threadIdx.x < 6) w::ld(PW::R(0) + threadIdx.x).store(out + i * P::F12W + threadIdx.x * P::F2W);
 }
 
