@@ -226,6 +226,121 @@ template <class K> struct PairingWave {
         }
         sync();
     }
+    // d = a^2 for a in the cyclotomic subgroup (everything after the easy part of the final exponentiation), Granger-Scott as in
+    // ark-ff's Fp12::cyclotomic_square, d may be a. With a = sum a_i w^i:  t0 = a0^2 + xi a3^2, t1 = 2 a0 a3, t2 = a1^2 + xi a4^2,
+    // t3 = 2 a1 a4, t4 = a2^2 + xi a5^2, t5 = 2 a2 a5;  a0' = 3 t0 - 2 a0, a2' = 3 t2 - 2 a2, a4' = 3 t4 - 2 a4, a3' = 3 t1 + 2 a3,
+    // a5' = 3 t3 + 2 a5, a1' = 3 xi t5 + 2 a1. Stage A, 24 lanes, one Fq product each: the six squares as P_i = (x + y)(x - y) and
+    // Q_i = (x + x) y, the three cross products doubled as (x_i + x_i) x_j, (y_i + y_i) y_j, (x_i + x_i) y_j, (y_i + y_i) x_j.
+    // Stage B, 12 lanes, one component of the result each, all on the pattern T = X + U0 Y +- Z with X, Y, Z a product or
+    // the sum / difference of two, then 3 T +- 2 a: 2.8 us against sqr12's 5.2 (57 products and two recombination stages).
+    // (sum of c_m w_m) mod p for small per-lane integers c_m = cp_m - cn_m (one of the two zero, either sum below 256), canonical
+    // in and out: the two sums as 64-bit columns without carries, t = pos + 256 p - neg in N + 1 words, one quotient estimate from
+    // its top 64 bits (never above floor(t / p), at most one below -- as in times9), one conditional subtraction. A chain of
+    // modular additions costs ~90 instructions per operand (sum, comparison with p, selection); this is two multiply-adds per
+    // operand word and ~150 instructions at the end, and small multiples (3 T - 2 a, xi = 9 + u) come for free.
+    template <int M> static MG_DEV F lincomb(const F *w, const u32 *cp, const u32 *cn) {
+        u64 pos[N], neg[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) pos[i] = 0, neg[i] = 0;
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int i = 0; i < N; ++i) pos[i] += (u64)cp[m] * w[m].v[i], neg[i] += (u64)cn[m] * w[m].v[i];
+        u32 t[N + 1], qn[N + 1];
+        u64 c = 0, e = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const u32 kp = (K::Fq::P[i] << 8) | (i ? K::Fq::P[i - 1] >> 24 : 0u); // word i of 256 p
+            c += pos[i] + kp, e += neg[i];
+            t[i] = (u32)c, qn[i] = (u32)e;
+            c >>= 32, e >>= 32;
+        }
+        t[N] = (u32)c + (K::Fq::P[N - 1] >> 24), qn[N] = (u32)e;
+        u32 bw = 0;
+#pragma unroll
+        for (int i = 0; i <= N; ++i) {
+            const u64 d = (u64)t[i] - qn[i] - bw;
+            t[i] = (u32)d;
+            bw = (u32)(d >> 63);
+        }
+        const u64 top64 = ((u64)t[N] << 32) | t[N - 1];
+        const float inv = (1.0f - 1.0f / 1048576.0f) / (float)((u64)K::Fq::P[N - 1] + 1u);
+        const u32 q = (u32)((float)top64 * inv);
+        F r;
+        u64 mm = 0;
+        bw = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            mm += (u64)q * K::Fq::P[i];
+            const u64 d = (u64)t[i] - (u32)mm - bw;
+            r.v[i] = (u32)d;
+            bw = (u32)(d >> 63);
+            mm >>= 32;
+        }
+        return F::reduce_once(r, t[N] - (u32)mm - bw);
+    }
+    struct CycTab {
+        u32 idx, clo, chi; // stage B of this lane: six product slots, 5 bits each; seven coefficients (six products and a), a byte each: magnitude | 0x80 minus
+    };
+    static constexpr CycTab cyc_entry(int l) {
+        const int m = l >> 1, c = l & 1;
+        u32 w[6] = {0, 0, 0, 0, 0, 0}, k[7] = {0, 0, 0, 0, 0, 0, 0};
+        constexpr u32 MINUS = 0x80u, T3 = 3u, XI3 = 3u * (u32)K::U0; // result = 3 T +- 2 a, T = X + U0 Y +- Z
+        if (!(m & 1)) { // a_m' = 3 (a_i^2 + xi a_j^2) - 2 a_m, i = m / 2, j = i + 3: P_i + U0 P_j - Q_j | Q_i + U0 Q_j + P_j
+            const int i = m >> 1, j = i + 3;
+            w[0] = 2 * i + c, k[0] = T3;
+            w[2] = 2 * j + c, k[2] = XI3;
+            w[4] = 2 * j + (c ^ 1), k[4] = T3 | (c ? 0u : MINUS);
+            k[6] = 2u | MINUS;
+        } else { // a_3' = 3 (2 a0 a3) + 2 a_3, a_5' = 3 (2 a1 a4) + 2 a_5, a_1' = 3 xi (2 a2 a5) + 2 a_1
+            const int base = 12 + 4 * (m == 3 ? 0 : (m == 5 ? 1 : 2));
+            const int o = m == 1 ? 2 : 0; // a_1' takes xi t5: U0 times this component of the product, +- the other one
+            w[o] = base + 2 * c, k[o] = m == 1 ? XI3 : T3;
+            w[o + 1] = base + 2 * c + 1, k[o + 1] = (m == 1 ? XI3 : T3) | (c ? 0u : MINUS); // c0 = U0' - U1', c1 = U2' + U3'
+            if (m == 1) {
+                w[4] = base + 2 * (c ^ 1), k[4] = T3 | (c ? 0u : MINUS);
+                w[5] = base + 2 * (c ^ 1) + 1, k[5] = T3 | MINUS; // c0: -(U2' + U3'); c1: + (U0' - U1')
+            }
+            k[6] = 2u;
+        }
+        return CycTab{w[0] | w[1] << 5 | w[2] << 10 | w[3] << 15 | w[4] << 20 | w[5] << 25, k[0] | k[1] << 8 | k[2] << 16 | k[3] << 24,
+                      k[4] | k[5] << 8 | k[6] << 16};
+    }
+    static MG_DEV CycTab cyc_tab() { // this lane's entry (once per kernel)
+        CycTab v{0u, 0u, 0u};
+#pragma unroll
+        for (int l = 0; l < 12; ++l) {
+            const CycTab t = cyc_entry(l);
+            const bool me = lane_id() == l;
+            v.idx = me ? t.idx : v.idx, v.clo = me ? t.clo : v.clo, v.chi = me ? t.chi : v.chi;
+        }
+        return v;
+    }
+    static __device__ __noinline__ void cyc_sqr12(int d, int a, const CycTab tab) {
+        const int l = lane_id();
+        u32 *q = base() + PROD * W;
+        if (l < 24) {
+            const bool isq = l < 12;
+            const int i = isq ? (l >> 1) : ((l - 12) >> 2), kk = isq ? (l & 1) : ((l - 12) & 3);
+            const F2 ai = ld(a + slot_of(i)), aj = ld(a + slot_of(isq ? i : i + 3));
+            const F s1 = F::select(isq || !(kk & 1), ai.c0, ai.c1), s2 = F::select(isq, F::select(kk != 0, ai.c0, ai.c1), s1);
+            const F vs = F::select(isq, ai.c1, F::select(kk == 0 || kk == 3, aj.c0, aj.c1));
+            F::mul(F::add(s1, s2), F::select(isq && kk == 0, F::sub(ai.c0, ai.c1), vs)).store(q + l * N);
+        }
+        sync();
+        if (l < 12) {
+            F w[7];
+            u32 cp[7], cn[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const u32 cf = ((k < 4 ? tab.clo : tab.chi) >> (8 * (k & 3))) & 255u;
+                cp[k] = (cf & 0x80u) ? 0u : cf, cn[k] = (cf & 0x80u) ? (cf & 0x7fu) : 0u;
+                w[k] = k < 6 ? F::load(q + ((tab.idx >> (5 * k)) & 31u) * N) : F::load(base() + (a + slot_of(l >> 1)) * W + (l & 1) * N);
+            }
+            lincomb<7>(w, cp, cn).store(base() + (d + slot_of(l >> 1)) * W + (l & 1) * N);
+        }
+        sync();
+    }
     // f *= line(P), arkworks `ell`: D-type twist (BN254) c0 py + (c1 px) w + c2 w^3 (mul_by_034), M-type (BLS12-381)
     // c0 + (c1 px) w^2 + (c2 py) w^3 (mul_by_014). Round 4: ONE Fq PRODUCT PER LANE. The line arrives as a ring entry made by
     // wave 1 (below): the three coefficients L_t already scaled by px / py, and xi L_t for the two that can wrap around
@@ -378,29 +493,30 @@ template <class K> struct PairingWave {
         mul12(d, t1, t2);
     }
     // d = a^|x| (d != a)
-    static __device__ __noinline__ void pow_x(int d, int a) {
+    static __device__ __noinline__ void pow_x(int d, int a, const CycTab tab) {
         copy12(d, a);
         int top = 63;
         while (!((K::X >> top) & 1)) --top;
 #pragma unroll 1
         for (int i = top - 1; i >= 0; --i) {
-            sqr12(d, d);
+            cyc_sqr12(d, d, tab);
             if ((K::X >> i) & 1) mul12(d, d, a);
         }
     }
-    static MG_DEV void exp_by_neg_x(int d, int a) {
-        pow_x(d, a);
+    static MG_DEV void exp_by_neg_x(int d, int a, const CycTab tab) {
+        pow_x(d, a, tab);
         if constexpr (!K::X_NEG) conj12(d);
     }
-    static MG_DEV void exp_by_x(int d, int a) {
-        pow_x(d, a);
+    static MG_DEV void exp_by_x(int d, int a, const CycTab tab) {
+        pow_x(d, a, tab);
         if constexpr (K::X_NEG) conj12(d);
     }
     static constexpr int FINAL_EXP_REGS = 19;
     // register 0 := final_exponentiation(register 0); registers 1..18 are scratch. The sequence is pairing_dev.h's
-    // final_exp (ark-ec 0.3 models/{bn,bls12}/mod.rs), squarings as products.
+    // final_exp (ark-ec 0.3 models/{bn,bls12}/mod.rs); squarings of the hard part in the cyclotomic subgroup (cyc_sqr12).
     static __device__ void final_exp() {
         const int f = R(0), f1 = R(1), f2 = R(2), r = R(3);
+        const CycTab ct = cyc_tab();
         copy12(f1, f);
         conj12(f1);
         inv12(f2, f, R(4), R(5));
@@ -411,13 +527,13 @@ template <class K> struct PairingWave {
         if constexpr (K::BN) {
             const int y0 = R(4), y1 = R(5), y2 = R(6), y3 = R(7), y4 = R(8), y5 = R(9), y6 = R(10), y7 = R(11), y8 = R(12),
                       y9 = R(13), y10 = R(14), y11 = R(15), y12 = R(16), y13 = R(17), y14 = R(18), y15 = R(1);
-            exp_by_neg_x(y0, r);
-            sqr12(y1, y0);
-            sqr12(y2, y1);
+            exp_by_neg_x(y0, r, ct);
+            cyc_sqr12(y1, y0, ct);
+            cyc_sqr12(y2, y1, ct);
             mul12(y3, y2, y1);
-            exp_by_neg_x(y4, y3);
-            sqr12(y5, y4);
-            exp_by_neg_x(y6, y5);
+            exp_by_neg_x(y4, y3, ct);
+            cyc_sqr12(y5, y4, ct);
+            exp_by_neg_x(y6, y5, ct);
             conj12(y3);
             conj12(y6);
             mul12(y7, y6, y4);
@@ -436,16 +552,16 @@ template <class K> struct PairingWave {
             mul12(f, y15, y14);
         } else {
             const int y0 = R(4), y1 = R(5), y2 = R(6), y3 = R(7), y4 = R(8), y5 = R(9);
-            sqr12(y0, r);
+            cyc_sqr12(y0, r, ct);
             conj12(y0);
-            exp_by_x(y5, r);
-            sqr12(y1, y5);
+            exp_by_x(y5, r, ct);
+            cyc_sqr12(y1, y5, ct);
             mul12(y3, y0, y5);
-            exp_by_x(y0, y3);
-            exp_by_x(y2, y0);
-            exp_by_x(y4, y2);
+            exp_by_x(y0, y3, ct);
+            exp_by_x(y2, y0, ct);
+            exp_by_x(y4, y2, ct);
             mul12(y4, y4, y1);
-            exp_by_x(y1, y4);
+            exp_by_x(y1, y4, ct);
             conj12(y3);
             mul12(y1, y1, y3);
             mul12(y1, y1, r);
