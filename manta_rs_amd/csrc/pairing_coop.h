@@ -492,27 +492,67 @@ template <class K> struct PairingWave {
         sync();
         mul12(d, t1, t2);
     }
-    // d = a^|x| (d != a)
-    static __device__ __noinline__ void pow_x(int d, int a, const CycTab tab) {
-        copy12(d, a);
-        int top = 63;
-        while (!((K::X >> top) & 1)) --top;
+    // |x| in width-4 non-adjacent form: odd digits in (-8, 8), at most one in any four positions -- BN254's 63-bit x has 14
+    // of them against 28 one bits, and an inverse in the cyclotomic subgroup is a conjugation
+    struct WNaf {
+        u64 nz = 0, neg = 0, m0 = 0, m1 = 0; // digit i: non-zero, negative, magnitude 1 + 2 (m0 + 2 m1)
+        int top = 0;
+    };
+    static constexpr WNaf wnaf4(u64 x) {
+        WNaf r;
+        unsigned __int128 v = x;
+        for (int i = 0; v; ++i, v >>= 1)
+            if (v & 1) {
+                int dgt = (int)(v & 15);
+                if (dgt >= 8) dgt -= 16;
+                v -= dgt; // (v is odd and dgt has its sign: no wrap)
+                const int mag = (dgt < 0 ? -dgt : dgt) >> 1;
+                r.nz |= 1ull << i, r.neg |= (u64)(dgt < 0) << i, r.m0 |= (u64)(mag & 1) << i, r.m1 |= (u64)(mag >> 1) << i, r.top = i;
+            }
+        return r;
+    }
+    static constexpr int popcount64(u64 x) { return x ? 1 + popcount64(x & (x - 1)) : 0; }
+    static constexpr bool X_WINDOW = popcount64(K::X) > 12 && K::X < (1ull << 63); // (BLS12-381's x has six one bits: plain binary)
+    // d = a^|x| for a in the cyclotomic subgroup (d != a; t .. t + 2: three scratch registers for a^3, a^5, a^7)
+    static __device__ __noinline__ void pow_x(int d, int a, int t, const CycTab tab) {
+        if constexpr (X_WINDOW) {
+            constexpr WNaf w = wnaf4(K::X);
+            auto odd = [&](int k) { return k == 0 ? a : t + 6 * (k - 1); }; // a^(2 k + 1)
+            cyc_sqr12(d, a, tab);
+            mul12(odd(1), a, d), mul12(odd(2), odd(1), d), mul12(odd(3), odd(2), d);
+            copy12(d, odd((int)((w.m0 >> w.top) & 1) + 2 * (int)((w.m1 >> w.top) & 1))); // (the leading digit is positive)
 #pragma unroll 1
-        for (int i = top - 1; i >= 0; --i) {
-            cyc_sqr12(d, d, tab);
-            if ((K::X >> i) & 1) mul12(d, d, a);
+            for (int i = w.top - 1; i >= 0; --i) {
+                cyc_sqr12(d, d, tab);
+                if ((w.nz >> i) & 1) {
+                    const int src = odd((int)((w.m0 >> i) & 1) + 2 * (int)((w.m1 >> i) & 1));
+                    const bool inv = (w.neg >> i) & 1;
+                    if (inv) conj12(src);
+                    mul12(d, d, src);
+                    if (inv) conj12(src);
+                }
+            }
+        } else {
+            copy12(d, a);
+            int top = 63;
+            while (!((K::X >> top) & 1)) --top;
+#pragma unroll 1
+            for (int i = top - 1; i >= 0; --i) {
+                cyc_sqr12(d, d, tab);
+                if ((K::X >> i) & 1) mul12(d, d, a);
+            }
         }
     }
     static MG_DEV void exp_by_neg_x(int d, int a, const CycTab tab) {
-        pow_x(d, a, tab);
+        pow_x(d, a, R(FINAL_EXP_REGS - 3), tab);
         if constexpr (!K::X_NEG) conj12(d);
     }
     static MG_DEV void exp_by_x(int d, int a, const CycTab tab) {
-        pow_x(d, a, tab);
+        pow_x(d, a, R(FINAL_EXP_REGS - 3), tab);
         if constexpr (K::X_NEG) conj12(d);
     }
-    static constexpr int FINAL_EXP_REGS = 19;
-    // register 0 := final_exponentiation(register 0); registers 1..18 are scratch. The sequence is pairing_dev.h's
+    static constexpr int FINAL_EXP_REGS = 22; // 0 .. 18: the sequence below; 19 .. 21: pow_x's odd powers
+    // register 0 := final_exponentiation(register 0); registers 1..21 are scratch. The sequence is pairing_dev.h's
     // final_exp (ark-ec 0.3 models/{bn,bls12}/mod.rs); squarings of the hard part in the cyclotomic subgroup (cyc_sqr12).
     static __device__ void final_exp() {
         const int f = R(0), f1 = R(1), f2 = R(2), r = R(3);
