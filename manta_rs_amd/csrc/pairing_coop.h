@@ -158,81 +158,6 @@ template <class K> struct PairingWave {
         sync();
         fold(d, 0x3fu);
     }
-    // d = a^2 (registers; d may be a) with ONE Fq product per lane. With a lone wavefront on its SIMD every instruction costs
-    // ~9 cycles whether or not it depends on the one before (profiles/r02_ubench_pairing.txt: Fq product 0.94 us, the three
-    // interleaved ones of an Fq2 product 2.95), so what counts is the length of the one instruction stream. A square has 21
-    // distinct coefficient products a_i a_j (i <= j): the six squares as (x + y)(x - y) and x y, the fifteen others as Karatsuba's
-    // three -- 57 Fq products = 57 lanes, one product deep. Stage B (42 lanes) puts each coefficient product together -- doubled,
-    // times xi where i + j wraps around w^6 -- and stage C (12 lanes) adds the three or four that make up one Fq component of the
-    // result. Same field elements as mul12(d, a, a), canonical throughout. Measured: 0.5 us less than mul12's 5.7-6.3 (the
-    // modular additions and selects of the two extra stages cost 40 instructions per Fq each): final exponentiation 1.70 -> 1.60 ms.
-    static constexpr u64 SQ_PAIR_I = 0x433222111100000ull, SQ_PAIR_J = 0x554543543254321ull; // (i, j), i < j, a nibble per pair
-    static MG_DEV u32 sq_terms(int m) { // the coefficient products (stage-B numbers, 5 bits each, 31 = none) that add up to w^m
-        constexpr u32 T[6] = {0u | 14u << 5 | 16u << 10 | 3u << 15,  6u | 17u << 5 | 18u << 10 | 31u << 15,
-                              7u | 1u << 5 | 19u << 10 | 4u << 15,   8u | 11u << 5 | 20u << 10 | 31u << 15,
-                              9u | 12u << 5 | 2u << 10 | 5u << 15,   10u | 13u << 5 | 15u << 10 | 31u << 15};
-        u32 t = T[0];
-#pragma unroll
-        for (int k = 1; k < 6; ++k) t = (k == m) ? T[k] : t;
-        return t;
-    }
-    static __device__ __noinline__ void sqr12(int d, int a) {
-        const int l = lane_id();
-        u32 *q = base() + PROD * W; // Fq slot t = q + t N (72 of them)
-        if (l < 57) {
-            const bool sq = l < 12;
-            const int p = sq ? 0 : (l - 12) / 3;
-            const int k = sq ? (l & 1) : (l - 12) - 3 * p;
-            const int i = sq ? (l >> 1) : (int)((SQ_PAIR_I >> (4 * p)) & 15u), j = sq ? i : (int)((SQ_PAIR_J >> (4 * p)) & 15u);
-            const F2 ai = ld(a + slot_of(i)), aj = ld(a + slot_of(j));
-            const F si = F::add(ai.c0, ai.c1), sj = F::add(aj.c0, aj.c1), di = F::sub(ai.c0, ai.c1);
-            // squares: k = 0 (x + y)(x - y), k = 1 x y; pairs: k = 0 x_i x_j, k = 1 y_i y_j, k = 2 (x_i + y_i)(x_j + y_j)
-            const F x = sq ? F::select(k == 0, si, ai.c0) : F::select(k == 0, ai.c0, F::select(k == 1, ai.c1, si));
-            const F y = sq ? F::select(k == 0, di, ai.c1) : F::select(k == 0, aj.c0, F::select(k == 1, aj.c1, sj));
-            F::mul(x, y).store(q + l * N);
-        }
-        sync();
-        F out = F::zero();
-        bool have = false;
-        if (l < 42) {
-            const int t = l >> 1, comp = l & 1;
-            const bool sq = t < 6;
-            const int p = sq ? 0 : t - 6;
-            const int i = sq ? t : (int)((SQ_PAIR_I >> (4 * p)) & 15u), j = sq ? t : (int)((SQ_PAIR_J >> (4 * p)) & 15u);
-            const int s0 = sq ? 2 * t : 12 + 3 * p;
-            const F t0 = F::load(q + s0 * N), t1 = F::load(q + (s0 + 1) * N), t2 = F::load(q + (s0 + 2) * N);
-            const F rp = F::sub(t0, t1), sp = F::sub(F::sub(t2, t0), t1);
-            const F r = F::select(sq, t0, F::dbl(rp)), im = F::dbl(F::select(sq, t1, sp)); // a_i a_j (+ a_j a_i) = r + im u
-            const F u = F::select(comp == 0, r, im), o = F::select(comp == 0, im, r);
-            const F z = xi_real(u); // xi (r + im u) = (U0 r - im) + (U0 im + r) u
-            const F wr = F::select(comp == 0, F::sub(z, o), F::add(z, o));
-            out = F::select(i + j >= 6, wr, u);
-            have = true;
-        }
-        sync(); // every stage-A value has been read
-        if (have) out.store(q + l * N);
-        sync();
-        if (l < 12) {
-            const int m = l >> 1, comp = l & 1;
-            const u32 tt = sq_terms(m);
-            F v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const u32 t = (tt >> (5 * e)) & 31u;
-                v[e] = F::load(q + ((t == 31u ? 0u : t) * 2 + comp) * N);
-                if (t == 31u) v[e] = F::zero();
-            }
-            F::add(F::add(v[0], v[1]), F::add(v[2], v[3])).store(base() + (d + slot_of(m)) * W + comp * N);
-        }
-        sync();
-    }
-    // d = a^2 for a in the cyclotomic subgroup (everything after the easy part of the final exponentiation), Granger-Scott as in
-    // ark-ff's Fp12::cyclotomic_square, d may be a. With a = sum a_i w^i:  t0 = a0^2 + xi a3^2, t1 = 2 a0 a3, t2 = a1^2 + xi a4^2,
-    // t3 = 2 a1 a4, t4 = a2^2 + xi a5^2, t5 = 2 a2 a5;  a0' = 3 t0 - 2 a0, a2' = 3 t2 - 2 a2, a4' = 3 t4 - 2 a4, a3' = 3 t1 + 2 a3,
-    // a5' = 3 t3 + 2 a5, a1' = 3 xi t5 + 2 a1. Stage A, 24 lanes, one Fq product each: the six squares as P_i = (x + y)(x - y) and
-    // Q_i = (x + x) y, the three cross products doubled as (x_i + x_i) x_j, (y_i + y_i) y_j, (x_i + x_i) y_j, (y_i + y_i) x_j.
-    // Stage B, 12 lanes, one component of the result each, all on the pattern T = X + U0 Y +- Z with X, Y, Z a product or
-    // the sum / difference of two, then 3 T +- 2 a: 2.8 us against sqr12's 5.2 (57 products and two recombination stages).
     // (sum of c_m w_m) mod p for small per-lane integers c_m = cp_m - cn_m (one of the two zero, either sum below 256), canonical
     // in and out: the two sums as 64-bit columns without carries, t = pos + 256 p - neg in N + 1 words, one quotient estimate from
     // its top 64 bits (never above floor(t / p), at most one below -- as in times9), one conditional subtraction. A chain of
@@ -278,6 +203,92 @@ template <class K> struct PairingWave {
             mm >>= 32;
         }
         return F::reduce_once(r, t[N] - (u32)mm - bw);
+    }
+    // d = a^2 (registers; d may be a) with ONE Fq product per lane. With a lone wavefront on its SIMD every instruction costs
+    // 5-9 cycles whether or not it depends on the one before (profiles/r02_ubench_pairing.txt), so what counts is the length of
+    // the one instruction stream. A square has 21 distinct coefficient products a_i a_j (i <= j): the six squares as
+    // P_i = (x + y)(x - y) and Q_i = x y, the fifteen others as Karatsuba's three -- 57 Fq products = 57 lanes, one product
+    // deep. Stage B, twelve lanes, one Fq component of the result each: the component is a fixed small-integer combination of
+    // at most ten of those products (doubling, Karatsuba's differences and xi = U0 + u where i + j wraps around w^6 all folded
+    // into the coefficients, |c| <= 2 U0 + 2), one `lincomb`. Round 3 did this in two stages of modular additions (42 + 12
+    // lanes): 5.2 us; now 3.2. Same field elements as mul12(d, a, a), canonical throughout.
+    static constexpr u64 SQ_PAIR_I = 0x433222111100000ull, SQ_PAIR_J = 0x554543543254321ull; // (i, j), i < j, a nibble per pair
+    static constexpr int SQ_OPS = 10;
+    struct SqTab {
+        u32 idx[2], cf[3]; // this lane's stage B: ten product slots (6 bits each), ten coefficients (a byte each: magnitude | 0x80 minus)
+    };
+    static constexpr SqTab sq_entry(int l) {
+        const int m = l >> 1, comp = l & 1, k = K::U0;
+        u32 slot[SQ_OPS] = {}, cf[SQ_OPS] = {};
+        int n = 0, pair = 0;
+        constexpr u32 MINUS = 0x80u;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) {
+                const int p = pair;
+                if (j > i) ++pair;
+                if ((i + j) % 6 != m) continue;
+                const bool wrap = i + j >= 6;
+                if (i == j) { // a_i^2 = P + 2 Q u; times xi: (k P - 2 Q) + (2 k Q + P) u
+                    const u32 P = 2 * i, Q = 2 * i + 1;
+                    if (!wrap) slot[n] = comp ? Q : P, cf[n] = comp ? 2 : 1, ++n;
+                    else if (!comp) slot[n] = P, cf[n] = k, ++n, slot[n] = Q, cf[n] = 2 | MINUS, ++n;
+                    else slot[n] = Q, cf[n] = 2 * k, ++n, slot[n] = P, cf[n] = 1, ++n;
+                } else { // 2 a_i a_j = 2 (t0 - t1) + 2 (t2 - t0 - t1) u; times xi: ((2k+2) t0 - (2k-2) t1 - 2 t2) + (2k t2 - (2k-2) t0 - (2k+2) t1) u
+                    const u32 t0 = 12 + 3 * p, t1 = t0 + 1, t2 = t0 + 2;
+                    if (!wrap && !comp) slot[n] = t0, cf[n] = 2, ++n, slot[n] = t1, cf[n] = 2 | MINUS, ++n;
+                    else if (!wrap) slot[n] = t2, cf[n] = 2, ++n, slot[n] = t0, cf[n] = 2 | MINUS, ++n, slot[n] = t1, cf[n] = 2 | MINUS, ++n;
+                    else if (!comp) {
+                        slot[n] = t0, cf[n] = 2 * k + 2, ++n, slot[n] = t2, cf[n] = 2 | MINUS, ++n;
+                        if (k > 1) slot[n] = t1, cf[n] = (2 * k - 2) | MINUS, ++n;
+                    } else {
+                        slot[n] = t2, cf[n] = 2 * k, ++n, slot[n] = t1, cf[n] = (2 * k + 2) | MINUS, ++n;
+                        if (k > 1) slot[n] = t0, cf[n] = (2 * k - 2) | MINUS, ++n;
+                    }
+                }
+            }
+        SqTab t{{0, 0}, {0, 0, 0}};
+        for (int e = 0; e < SQ_OPS; ++e) t.idx[e / 5] |= slot[e] << (6 * (e % 5)), t.cf[e / 4] |= cf[e] << (8 * (e % 4));
+        return t;
+    }
+    static MG_DEV SqTab sq_tab() { // this lane's entry (once per kernel)
+        SqTab v{{0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int l = 0; l < 12; ++l) {
+            const SqTab t = sq_entry(l);
+            const bool me = lane_id() == l;
+            v.idx[0] = me ? t.idx[0] : v.idx[0], v.idx[1] = me ? t.idx[1] : v.idx[1];
+            v.cf[0] = me ? t.cf[0] : v.cf[0], v.cf[1] = me ? t.cf[1] : v.cf[1], v.cf[2] = me ? t.cf[2] : v.cf[2];
+        }
+        return v;
+    }
+    static __device__ __noinline__ void sqr12(int d, int a, const SqTab tab) {
+        const int l = lane_id();
+        u32 *q = base() + PROD * W; // Fq slot t = q + t N (72 of them)
+        if (l < 57) {
+            const bool sq = l < 12;
+            const int p = sq ? 0 : (l - 12) / 3;
+            const int k = sq ? (l & 1) : (l - 12) - 3 * p;
+            const int i = sq ? (l >> 1) : (int)((SQ_PAIR_I >> (4 * p)) & 15u), j = sq ? i : (int)((SQ_PAIR_J >> (4 * p)) & 15u);
+            const F2 ai = ld(a + slot_of(i)), aj = ld(a + slot_of(j));
+            const F si = F::add(ai.c0, ai.c1), sj = F::add(aj.c0, aj.c1), di = F::sub(ai.c0, ai.c1);
+            // squares: k = 0 (x + y)(x - y), k = 1 x y; pairs: k = 0 x_i x_j, k = 1 y_i y_j, k = 2 (x_i + y_i)(x_j + y_j)
+            const F x = sq ? F::select(k == 0, si, ai.c0) : F::select(k == 0, ai.c0, F::select(k == 1, ai.c1, si));
+            const F y = sq ? F::select(k == 0, di, ai.c1) : F::select(k == 0, aj.c0, F::select(k == 1, aj.c1, sj));
+            F::mul(x, y).store(q + l * N);
+        }
+        sync();
+        if (l < 12) {
+            F w[SQ_OPS];
+            u32 cp[SQ_OPS], cn[SQ_OPS];
+#pragma unroll
+            for (int e = 0; e < SQ_OPS; ++e) {
+                const u32 cf = (tab.cf[e / 4] >> (8 * (e % 4))) & 255u;
+                cp[e] = (cf & 0x80u) ? 0u : cf, cn[e] = (cf & 0x80u) ? (cf & 0x7fu) : 0u;
+                w[e] = F::load(q + ((tab.idx[e / 5] >> (6 * (e % 5))) & 63u) * N);
+            }
+            lincomb<SQ_OPS>(w, cp, cn).store(base() + (d + slot_of(l >> 1)) * W + (l & 1) * N);
+        }
+        sync();
     }
     struct CycTab {
         u32 idx, clo, chi; // stage B of this lane: six product slots, 5 bits each; seven coefficients (six products and a), a byte each: magnitude | 0x80 minus
@@ -343,46 +354,67 @@ template <class K> struct PairingWave {
     }
     // f *= line(P), arkworks `ell`: D-type twist (BN254) c0 py + (c1 px) w + c2 w^3 (mul_by_034), M-type (BLS12-381)
     // c0 + (c1 px) w^2 + (c2 py) w^3 (mul_by_014). Round 4: ONE Fq PRODUCT PER LANE. The line arrives as a ring entry made by
-    // wave 1 (below): the three coefficients L_t already scaled by px / py, and xi L_t for the two that can wrap around
-    // w^6 = xi -- so the eighteen Fq2 products f_i L_t are 54 Karatsuba products on 54 lanes (one product deep), stage B puts
-    // the 36 Fq components together (t0 - t1, t2 - t0 - t1) and stage C adds the three that make up each component of the
-    // result: 2.1 us against the 7.9 of the first version (an Fq2-by-Fq product, an Fq2 product and the xi multiple, all
-    // on the lane of one coefficient product).
+    // wave 1 (below): the three coefficients L_t already scaled by px / py -- so the eighteen Fq2 products f_i L_t are 54
+    // Karatsuba products on 54 lanes (one product deep), and each Fq component of the result is one `lincomb` of the nine
+    // products behind it (Karatsuba's differences and xi, where i + LINE_J(t) wraps around w^6, in the coefficients): 1.9 us
+    // against the 7.9 of the first version (an Fq2-by-Fq product, an Fq2 product and the xi multiple, all on the lane of one
+    // coefficient product, then a fold).
     static constexpr int LINE_J(int t) { return K::TWIST_D ? (t == 2 ? 3 : t) : (t == 0 ? 0 : t + 1); } // L_t sits at w^LINE_J(t)
-    static constexpr int RINGW = 5 * W; // ring entry: L_0, L_1, L_2, xi L_1, xi L_2
-    static __device__ __noinline__ void ell(int f, int o) {
+    static constexpr int RINGW = 3 * W; // ring entry: L_0, L_1, L_2
+    struct EllTab {
+        u32 idx[2], cf[3]; // this lane's second stage: nine product slots (6 bits each) and coefficients (a byte each: magnitude | 0x80 minus)
+    };
+    static constexpr EllTab ell_entry(int l) {
+        const int m = l >> 1, comp = l & 1, k = K::U0;
+        constexpr u32 MINUS = 0x80u;
+        EllTab r{{0, 0}, {0, 0, 0}};
+        for (int t = 0; t < 3; ++t) {
+            int i = m - LINE_J(t);
+            const bool wrap = i < 0;
+            i += wrap ? 6 : 0;
+            const u32 t0 = 3 * (3 * i + t), c0 = !wrap ? (comp ? 1 | MINUS : 1) : (comp ? (k - 1) | MINUS : k + 1),
+                      c1 = !wrap ? 1 | MINUS : (comp ? (k + 1) | MINUS : (k - 1) | MINUS), c2 = !wrap ? (comp ? 1 : 0) : (comp ? k : 1 | MINUS);
+            const u32 sl[3] = {t0, t0 + 1, t0 + 2}, cf[3] = {c0, c1, c2}; // v = (t0 - t1) + (t2 - t0 - t1) u; xi v = ((k+1) t0 - (k-1) t1 - t2) + (k t2 - (k-1) t0 - (k+1) t1) u
+            for (int e = 0; e < 3; ++e) {
+                const int o = 3 * t + e;
+                r.idx[o / 5] |= sl[e] << (6 * (o % 5)), r.cf[o / 4] |= ((cf[e] & 0x7fu) ? cf[e] : 0u) << (8 * (o % 4));
+            }
+        }
+        return r;
+    }
+    static MG_DEV EllTab ell_tab() { // this lane's entry (once per kernel)
+        EllTab v{{0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int l = 0; l < 12; ++l) {
+            const EllTab t = ell_entry(l);
+            const bool me = lane_id() == l;
+            v.idx[0] = me ? t.idx[0] : v.idx[0], v.idx[1] = me ? t.idx[1] : v.idx[1];
+            v.cf[0] = me ? t.cf[0] : v.cf[0], v.cf[1] = me ? t.cf[1] : v.cf[1], v.cf[2] = me ? t.cf[2] : v.cf[2];
+        }
+        return v;
+    }
+    static __device__ __noinline__ void ell(int f, int o, const EllTab tab) {
         const int l = lane_id();
         const u32 *e = ring_slot(o);
         u32 *q = base() + PROD * W; // Fq slot s = q + s N (72 of them)
         if (l < 54) {
             const int pr = l / 3, k = l - 3 * pr, i = pr / 3, t = pr - 3 * i;
-            const int j = t == 0 ? LINE_J(0) : (t == 1 ? LINE_J(1) : LINE_J(2));
-            const F2 fi = ld(f + slot_of(i)), lt = F2::load(e + ((i + j >= 6) ? 2 + t : t) * W);
+            const F2 fi = ld(f + slot_of(i)), lt = F2::load(e + t * W);
             const F x = F::select(k == 0, fi.c0, F::select(k == 1, fi.c1, F::add(fi.c0, fi.c1)));
             const F y = F::select(k == 0, lt.c0, F::select(k == 1, lt.c1, F::add(lt.c0, lt.c1)));
             F::mul(x, y).store(q + l * N);
         }
         sync();
-        F v = F::zero();
-        if (l < 36) { // component (l & 1) of product l / 2; written over the products once every lane has read its three
-            const int pr = l >> 1, comp = l & 1;
-            const F t0 = F::load(q + 3 * pr * N), t1 = F::load(q + (3 * pr + 1) * N), t2 = F::load(q + (3 * pr + 2) * N);
-            const F d = F::sub(F::select(comp != 0, t2, t0), F::select(comp != 0, t0, t1));
-            v = F::select(comp != 0, F::sub(d, t1), d);
-        }
-        sync();
-        if (l < 36) v.store(q + l * N);
-        sync();
-        if (l < 12) { // component comp of the coefficient of w^m: the products f_i L_t with i + LINE_J(t) = m (mod 6)
-            const int m = l >> 1, comp = l & 1;
-            F acc[3];
+        if (l < 12) {
+            F w[9];
+            u32 cp[9], cn[9];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                int i = m - LINE_J(t);
-                i += i < 0 ? 6 : 0;
-                acc[t] = F::load(q + (2 * (3 * i + t) + comp) * N);
+            for (int c = 0; c < 9; ++c) {
+                const u32 cf = (tab.cf[c / 4] >> (8 * (c % 4))) & 255u;
+                cp[c] = (cf & 0x80u) ? 0u : cf, cn[c] = (cf & 0x80u) ? (cf & 0x7fu) : 0u;
+                w[c] = F::load(q + ((tab.idx[c / 5] >> (6 * (c % 5))) & 63u) * N);
             }
-            F::add(F::add(acc[0], acc[1]), acc[2]).store(base() + (f + slot_of(m)) * W + comp * N);
+            lincomb<9>(w, cp, cn).store(base() + (f + slot_of(l >> 1)) * W + (l & 1) * N);
         }
         sync();
     }
@@ -625,9 +657,9 @@ template <class K> struct PairingWave {
         return dgt;
     }
     // ---- the ring through which wave 1 of the Miller kernel hands lines to wave 0. An entry is what `ell` multiplies with
-    // (RINGW words: the scaled coefficients and their xi multiples); wave 1 makes it either from G2Prepared::from(Q) as that
+    // (RINGW words: the coefficients scaled by px / py); wave 1 makes it either from G2Prepared::from(Q) as that
     // runs (prepare<true>, below) or from a stored coefficient table (scale_stored)
-    static constexpr int PREP_WORDS_ = 46 * W; // = PREP_SLOTS * W (the enum is declared further down)
+    static constexpr int PREP_WORDS_ = 44 * W; // = PREP_SLOTS * W (the enum is declared further down)
     static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * RINGW;
     static constexpr size_t miller_lds_bytes() { return (size_t)(CNT_OFF + 2) * 4; }
     static MG_DEV volatile u32 *counters() { return (volatile u32 *)(mg_pairing_lds + CNT_OFF); } // [0] produced, [1] consumed
@@ -652,17 +684,19 @@ template <class K> struct PairingWave {
     }
     // register f := Miller loop of ONE pair; the NCOEFF lines come through the ring in the order of G2Prepared's table
     static __device__ void miller(int f) {
+        const SqTab st = sq_tab();
+        const EllTab et = ell_tab();
         set_one(f);
         int o = 0;
         auto line = [&]() {
             ring_acquire(o);
-            ell(f, o);
+            ell(f, o, et);
             ring_release(o);
             ++o;
         };
 #pragma unroll 1
         for (int i = K::LOOP_LEN - 2; i >= 0; --i) {
-            if (i != K::LOOP_LEN - 2) sqr12(f, f);
+            if (i != K::LOOP_LEN - 2) sqr12(f, f, st);
             line();
             if (loop_digit(i) != 0) line();
         }
@@ -673,7 +707,7 @@ template <class K> struct PairingWave {
         if constexpr (K::X_NEG) conj12(f);
     }
     // wave 1, Q prepared in advance (the verifying key's -gamma, -delta; arkworks' table of NCOEFF triples in global memory):
-    // scale each triple by P's coordinates, add the xi multiples, hand it on -- well ahead of wave 0, which so never waits
+    // scale each triple by P's coordinates and hand it on -- well ahead of wave 0, which so never waits
     // for a global load
     static constexpr int T_PLAIN = K::TWIST_D ? 2 : 0, T_PY = K::TWIST_D ? 0 : 2; // t = 1 is scaled by px on both twists
     static __device__ void scale_stored(const u32 *co, const F &px, const F &py) {
@@ -686,11 +720,6 @@ template <class K> struct PairingWave {
             if (l < 6) raw = F::load(co + (size_t)o * P::COEFFW + t * W + comp * N);
             u32 *e = ring_reserve(o);
             if (l < 6) F::mul(raw, F::select(t == T_PLAIN, one, F::select(t == T_PY, py, px))).store(e + t * W + comp * N);
-            sync();
-            if (l >= 2 && l < 6) { // xi L_t, t = 1, 2
-                const F a = F::load(e + t * W + comp * N), b = F::load(e + t * W + (comp ^ 1) * N);
-                addsub(xi_real(a), b, comp == 0).store(e + (2 + t) * W + comp * N);
-            }
             ring_publish(o);
         }
     }
@@ -711,7 +740,6 @@ template <class K> struct PairingWave {
     //             lambda h, theta (g - h), e y, z e | x3, y3, z3        (-Q: the signs of the qy terms flip, no other change)
     enum { SX = 0, SY, SZ, XY, BB, CC, JJ, YZ, NE, FV, MM, GG, HH, CB3, CB9, ZERO, QX, QY, TH, LA, AC, AD, AE, AF, AG, AG2, AH, GH,
            CR0, CR1, CR2, // line coefficients before their scaling by px / py
-           SL1, SL2,      // L_1, L_2 once more, for the stage that makes xi L_t
            PXY,           // (px, py)
            QP,            // QP .. QP + 11 hold the (up to twenty-four) Fq products of a level
            PREP_SLOTS = QP + 12 };
@@ -720,7 +748,7 @@ template <class K> struct PairingWave {
     struct Lin {
         u32 ops, dst;
     };
-    static constexpr u32 NONE = 0xffffffffu, NEG = 0x80u, OUT = 0x80u, HALF = 0x100u, XI = 0x200u, DEFAULT_DST = 0xffu;
+    static constexpr u32 NONE = 0xffffffffu, NEG = 0x80u, OUT = 0x80u, HALF = 0x100u, DEFAULT_DST = 0xffu;
     static constexpr u32 fq(int slot, int comp) { return 2u * (u32)slot + (u32)comp; } // Fq slot: component comp of an Fq2 slot
     static constexpr u32 tq(int p, int k) { return fq(QP, 0) + 4u * (u32)p + (u32)k; } // product k of Fq2 product p
     static constexpr u32 ZQ = fq(ZERO, 0);
@@ -735,12 +763,9 @@ template <class K> struct PairingWave {
         constexpr void product(int sa, int sb) { // Fq2 slot sa x Fq2 slot sb on four lanes: a0 b0, a1 b1, a0 b1, a1 b0
             for (int k = 0; k < 4; ++k) put(fq(sa, k & 1), fq(sb, (k == 1 || k == 2) ? 1 : 0));
         }
-        // ring mode: coefficient t (raw in Fq2 slot raw) times px / py, to the ring entry and -- t = 1, 2 -- to SL_t
+        // ring mode: coefficient t (raw in Fq2 slot raw) times px / py, to the ring entry
         constexpr void scale(int t, int raw) {
-            for (int c = 0; c < 2; ++c) {
-                put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), OUT | fq(t, c));
-                if (t >= 1) put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), fq(t == 1 ? SL1 : SL2, c));
-            }
+            for (int c = 0; c < 2; ++c) put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), OUT | fq(t, c));
         }
     };
     struct LinTab { // a linear level: lane l adds up (at most four) signed Fq slots
@@ -755,16 +780,8 @@ template <class K> struct PairingWave {
         constexpr void coeff(bool ring, int t, int c, u32 o, u32 fl = 0) {
             if (!ring || t == T_PLAIN) {
                 put(o, OUT | fq(t, c), fl);
-                if (ring && t >= 1) put(o, fq(t == 1 ? SL1 : SL2, c), fl);
             } else {
                 put(o, fq(CR0 + t, c), fl);
-            }
-        }
-        constexpr void xi_multiples() { // ring mode: xi L_t = (U0 c0 - c1) + (U0 c1 + c0) u, t = 1, 2
-            for (int t = 1; t <= 2; ++t) {
-                const int sl = t == 1 ? SL1 : SL2;
-                put(ops(fq(sl, 0), fq(sl, 1) | NEG), OUT | XI | fq(2 + t, 0));
-                put(ops(fq(sl, 1), fq(sl, 0)), OUT | XI | fq(2 + t, 1));
             }
         }
     };
@@ -811,7 +828,6 @@ template <class K> struct PairingWave {
         t.rec(0, SX);
         for (int c = 0; c < 2; ++c) t.put(ops(re0(1, c), re1(1, c), re0(2, c), re1(2, c)), fq(SY, c)); // g^2 - 3 e^2
         t.rec(3, SZ);
-        if (RG) t.xi_multiples();
         return t;
     }
     // -- addition of (QX, +-QY)
@@ -853,7 +869,6 @@ template <class K> struct PairingWave {
         LinTab t;
         t.rec(0, AE), t.rec(1, AF), t.rec(2, AG);
         for (int c = 0; c < 2; ++c) t.put(ops(re0(2, c), re1(2, c), re0(2, c), re1(2, c)), fq(AG2, c));
-        if (RG) t.xi_multiples();
         return t;
     }
     static constexpr LinTab a_r3b() {
@@ -920,13 +935,12 @@ template <class K> struct PairingWave {
         }
         sync();
     }
-    template <int NOPS, bool MAY_HALVE = false, bool MAY_XI = false> static MG_DEV void lin_stage(const Lin e, u32 *out) {
+    template <int NOPS, bool MAY_HALVE = false> static MG_DEV void lin_stage(const Lin e, u32 *out) {
         if (e.dst != NONE) {
             F v[NOPS];
 #pragma unroll
             for (int k = 0; k < NOPS; ++k) v[k] = ldq((e.ops >> (8 * k)) & 127u);
             F r = v[0];
-            if constexpr (MAY_XI) r = F::select((e.dst & XI) != 0, xi_real(r), r);
 #pragma unroll
             for (int k = 1; k < NOPS; ++k) r = addsub(r, v[k], ((e.ops >> (8 * k + 7)) & 1u) != 0);
             if constexpr (MAY_HALVE) r = F::select((e.dst & HALF) != 0, half(r), r);
@@ -964,7 +978,7 @@ template <class K> struct PairingWave {
             prod_stage(ds2, c);
             lin_stage<3, true>(dr2, c);
             prod_stage(ds3, c);
-            lin_stage<4, false, RG>(dr3, c);
+            lin_stage<4>(dr3, c);
             done();
         };
         auto addition = [&](bool minus) {
@@ -974,7 +988,7 @@ template <class K> struct PairingWave {
             prod_stage(as2, c);
             lin_stage<4>(Lin{ar2.ops ^ (minus ? f2 : 0u), ar2.dst}, c);
             prod_stage(as3, c);
-            lin_stage<4, false, RG>(ar3a, c);
+            lin_stage<4>(ar3a, c);
             lin_stage<4>(ar3b, c);
             prod_stage(as4, c);
             lin_stage<4>(ar4, c);
