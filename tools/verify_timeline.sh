@@ -7,9 +7,10 @@ python - <<PY
 import sqlite3, glob
 db = sqlite3.connect(glob.glob("/tmp/vv/**/*.db", recursive=True)[0])
 rows = list(db.execute("select name, start, end, queue_id from kernels order by start"))
-# the last verification: its first kernel is the Miller kernel of the two early pairs, launched before the prepared-inputs MSM
+# the last verification: from its prepared-inputs MSM (digits kernel) or the Miller kernel of the two early pairs, whichever came first
 idx = [i for i, r in enumerate(rows) if "digits_kernel" in r[0]][-1]
-first = max(i for i in range(idx) if "miller_kernel" in rows[i][0])
+millers = [i for i, r in enumerate(rows) if "miller_kernel" in r[0]]
+first = min(idx, millers[-2])
 t0 = rows[first][1]
 for n, s, e, q in rows[first:]:
     print(f"{(s-t0)/1e3:9.1f} {(e-t0)/1e3:9.1f} {(e-s)/1e3:8.1f} us q{q} {n.replace('void mg::','')[:60]}")
