@@ -31,16 +31,27 @@ __global__ __launch_bounds__(64) void g2_prepare_kernel(const u32 *__restrict__ 
 // pairs). Q_i is either prepared already (coeffs[i] != null; wave 1 has nothing to do) or given as an affine point in
 // q[i]: then wave 1 runs G2Prepared::from(Q_i) and feeds the line coefficients to wave 0's Miller loop through LDS as they
 // appear -- the two chains overlap instead of running one after the other in two kernels.
+// (p = null: ONE pair whose G1 point rides in the kernel arguments -- a point the host has just computed, e.g. a
+// verification's prepared inputs, then needs no upload of its own in front of the kernel)
+template <class K> struct G1Arg {
+    u32 w[2 * Pairing<K>::N];
+};
 template <class K>
 __global__ __launch_bounds__(128) void miller_kernel(const u32 *__restrict__ p, const u32 *const *__restrict__ coeffs,
                                                      const u32 *__restrict__ q, const unsigned char *__restrict__ skip, size_t n,
-                                                     u32 *__restrict__ out) {
+                                                     u32 *__restrict__ out, const G1Arg<K> p_arg) {
     typedef Pairing<K> P;
     typedef PairingWave<K> PW;
     typedef PW w;
     const size_t i = blockIdx.x;
     const u32 *co = coeffs[i];
-    const typename P::F px = P::F::load(p + i * 2 * P::N), py = P::F::load(p + i * 2 * P::N + P::N);
+    typename P::F px, py;
+    if (p) {
+        px = P::F::load(p + i * 2 * P::N), py = P::F::load(p + i * 2 * P::N + P::N);
+    } else {
+#pragma unroll
+        for (int k = 0; k < P::N; ++k) px.v[k] = p_arg.w[k], py.v[k] = p_arg.w[P::N + k];
+    }
     const bool one = skip[i] || (px.is_zero() && py.is_zero());
     if (threadIdx.x == 0) w::counters()[0] = 0, w::counters()[1] = 0;
     __syncthreads(); // the only workgroup barrier: from here on the two wavefronts run different programs
@@ -154,7 +165,8 @@ template <class K> class PairingEngineT : public PairingEngine {
         if (e == hipSuccess)
             hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n_early), dim3(128), PW::miller_lds_bytes(), w->s, (const u32 *)d,
                                (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
-                               n_early, (u32 *)(d + o_f));
+                               n_early, (u32 *)(d + o_f), G1Arg<K>{});
+        if (e == hipSuccess && n_early < n) e = hipEventRecord(w->ev3, w->s); // the early Miller loops are done
         if (e != hipSuccess) {
             hipStreamSynchronize(w->s);
             ws_put(w);
@@ -175,17 +187,26 @@ template <class K> class PairingEngineT : public PairingEngine {
         if (n_late && (!p_late_affine_host || !out_f12_host)) e = hipErrorInvalidValue;
         if (e == hipSuccess && n_late) {
             const size_t off = w->n_early * 2 * P::N * 4, lb = n_late * 2 * P::N * 4;
-            std::memcpy((unsigned char *)w->h + w->h_late, p_late_affine_host, lb);
+            G1Arg<K> arg{};
             e = hipStreamWaitEvent(w->s2, w->ev, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(d + off, (unsigned char *)w->h + w->h_late, lb, hipMemcpyHostToDevice, w->s2);
+            if (n_late == 1) { // the usual case (a verification's prepared inputs): the point travels with the launch
+                std::memcpy(arg.w, p_late_affine_host, lb);
+            } else if (e == hipSuccess) {
+                std::memcpy((unsigned char *)w->h + w->h_late, p_late_affine_host, lb);
+                e = hipMemcpyAsync(d + off, (unsigned char *)w->h + w->h_late, lb, hipMemcpyHostToDevice, w->s2);
+            }
             if (e == hipSuccess) {
                 hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n_late), dim3(128), PW::miller_lds_bytes(), w->s2,
-                                   (const u32 *)(d + off), (const u32 *const *)(d + w->o_c) + w->n_early, (const u32 *)nullptr,
+                                   n_late == 1 ? (const u32 *)nullptr : (const u32 *)(d + off),
+                                   (const u32 *const *)(d + w->o_c) + w->n_early, (const u32 *)nullptr,
                                    (const unsigned char *)(d + w->o_s) + w->n_early, n_late,
-                                   (u32 *)(d + w->o_f) + w->n_early * P::F12W);
-                e = hipEventRecord(w->ev2, w->s2);
+                                   (u32 *)(d + w->o_f) + w->n_early * P::F12W, arg);
             }
-            if (e == hipSuccess) e = hipStreamWaitEvent(st, w->ev2, 0);
+            // the rest runs behind the late loops on THEIR stream: they end last, and by then the early ones' event has long been
+            // signalled -- waiting the other way round (the first stream for the late loops) left 30-70 us between the end of
+            // the late Miller kernel and the product
+            st = w->s2;
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, w->ev3, 0);
         }
         if (e == hipSuccess) {
             u32 *df = (u32 *)(d + w->o_f), *dg = (u32 *)(d + w->o_g);
@@ -207,7 +228,7 @@ template <class K> class PairingEngineT : public PairingEngine {
             e = hipMemcpyAsync(w->h, src, P::F12W * 4, hipMemcpyDeviceToHost, st);
         }
         const hipError_t e2 = hipStreamSynchronize(st); // (also on the error paths: nothing of this call stays in flight)
-        if (n_late) hipStreamSynchronize(w->s2);
+        if (n_late) hipStreamSynchronize(w->s);
         if (e == hipSuccess) e = e2;
         if (e == hipSuccess) std::memcpy(out_f12_host, w->h, P::F12W * 4);
         ws_put(w);
@@ -230,7 +251,7 @@ template <class K> class PairingEngineT : public PairingEngine {
         void *h = nullptr;
         size_t dcap = 0, hcap = 0;
         hipStream_t s = nullptr, s2 = nullptr; // s2: the Miller loops of pairs handed in late
-        hipEvent_t ev = nullptr, ev2 = nullptr;
+        hipEvent_t ev = nullptr, ev3 = nullptr; // upload done; early Miller loops done
         size_t n = 0, n_early = 0, o_q = 0, o_c = 0, o_s = 0, o_f = 0, o_g = 0, h_late = 0; // the product in flight
     };
     std::mutex ws_mu_;
@@ -249,7 +270,7 @@ template <class K> class PairingEngineT : public PairingEngine {
             if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&w->s2, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&w->ev2, hipEventDisableTiming) != hipSuccess) {
+                hipEventCreateWithFlags(&w->ev3, hipEventDisableTiming) != hipSuccess) {
                 delete w; // (creation failures at start-up only; the handles made so far are left to process exit)
                 return nullptr;
             }

@@ -305,9 +305,8 @@ template <class Curve, class K> class VerifierT : public Verifier {
         return MG_OK;
     }
 
-    // sum_j scalars_j * gamma_abc_g1[j] on the GPU (scalars Montgomery Fr, n <= P), in two steps so that a verification can
-    // start it first and put its Miller loops in flight before it waits for the result
-    int abc_msm_begin(const u64 *scalars_mont, size_t n, MsmWorkspace **out_ws) {
+    // sum_j scalars_j * gamma_abc_g1[j] on the GPU (scalars Montgomery Fr, n <= P)
+    int abc_msm(const u64 *scalars_mont, size_t n, HostPoint *out) {
         MsmWorkspace *ws = g1_->ws_acquire();
         if (!ws) return MG_ERR_HIP;
         // the scalars ride in the workspace's own grow-only buffer, on its stream: no hipMalloc / hipFree per verification
@@ -315,24 +314,10 @@ template <class Curve, class K> class VerifierT : public Verifier {
         int rc = ws->scratch.reserve(n * 32);
         if (!rc && hipMemcpyAsync(ws->scratch.p, scalars_mont, n * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
         if (!rc) rc = g1_->msm_launch(abc_bs_, ws->scratch.as<u32>(), n, SCALARS_MONT, 0, ws);
-        if (rc) {
-            hipStreamSynchronize(ws->stream), ws->pending = 0;
-            g1_->ws_release(ws);
-            return rc;
-        }
-        *out_ws = ws;
-        return MG_OK;
-    }
-    int abc_msm_end(MsmWorkspace *ws, HostPoint *out) {
-        const int rc = g1_->msm_finish(ws, out);
-        if (rc) hipStreamSynchronize(ws->stream), ws->pending = 0;
+        if (!rc) rc = g1_->msm_finish(ws, out);
+        else hipStreamSynchronize(ws->stream), ws->pending = 0;
         g1_->ws_release(ws);
         return rc;
-    }
-    int abc_msm(const u64 *scalars_mont, size_t n, HostPoint *out) {
-        MsmWorkspace *ws = nullptr;
-        const int rc = abc_msm_begin(scalars_mont, n, &ws);
-        return rc ? rc : abc_msm_end(ws, out);
     }
 
     int verify(const u64 *inputs, const u64 *proof, int *ok) override {
@@ -340,17 +325,8 @@ template <class Curve, class K> class VerifierT : public Verifier {
         DeviceScope on_device(dev_);
         *ok = 0;
         const u64 *A = proof, *B = proof + G1L, *Cc = proof + G1L + G2L;
-        // prepared_inputs = abc[0] + sum_j input_j abc[j+1]: a P-term MSM with the scalar 1 in front. It goes first: its point is
-        // the last thing the third Miller loop waits for, and that loop, not the two below, ends last
-        std::vector<u64> sc(P_ * 4);
-        HR one = HR::one();
-        std::memcpy(sc.data(), one.v, 32);
-        if (P_ > 1) std::memcpy(sc.data() + 4, inputs, (P_ - 1) * 32);
-        MsmWorkspace *mws = nullptr;
-        int rc = abc_msm_begin(sc.data(), P_, &mws);
-        if (rc) return rc;
-        // e(A, B) and e(C, -delta) do not depend on the public inputs: their Miller loops run next to the MSM. B is the one G2
-        // point that is new with every proof: its line coefficients are computed next to its Miller loop
+        // e(A, B) and e(C, -delta) do not depend on the public inputs: their Miller loops start first. B is the one G2 point that
+        // is new with every proof: its line coefficients are computed next to its Miller loop
         const u32 *cp[3] = {nullptr, d_delta_neg(), d_gamma_neg()};
         std::vector<u64> ps(2 * G1L);
         std::memcpy(ps.data(), A, G1L * 8);
@@ -359,13 +335,18 @@ template <class Curve, class K> class VerifierT : public Verifier {
         std::memcpy(qs.data(), B, G2L * 8);
         unsigned char skip[3] = {(unsigned char)is_zero_limbs(B, G2L), 0, 0};
         void *pp = nullptr;
-        rc = pe_->pairing_product_begin((const u32 *)ps.data(), cp, (const u32 *)qs.data(), skip, 3, 2, &pp);
-        HostPoint pi;
-        const int rc2 = abc_msm_end(mws, &pi); // (also when begin() failed: nothing of this call stays in flight)
+        int rc = pe_->pairing_product_begin((const u32 *)ps.data(), cp, (const u32 *)qs.data(), skip, 3, 2, &pp);
         if (rc) return rc;
-        if (rc2) {
+        // prepared_inputs = abc[0] + sum_j input_j abc[j+1]: a P-term MSM with the scalar 1 in front, next to those loops
+        std::vector<u64> sc(P_ * 4);
+        HR one = HR::one();
+        std::memcpy(sc.data(), one.v, 32);
+        if (P_ > 1) std::memcpy(sc.data() + 4, inputs, (P_ - 1) * 32);
+        HostPoint pi;
+        rc = abc_msm(sc.data(), P_, &pi);
+        if (rc) {
             pe_->pairing_product_abandon(pp);
-            return rc2;
+            return rc;
         }
         std::vector<u64> late(G1L);
         g1_->hp_to_affine(&pi, (u32 *)late.data());
