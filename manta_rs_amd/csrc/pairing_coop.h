@@ -445,51 +445,75 @@ template <class K> struct PairingWave {
         }
         sync();
     }
-    // 1/a in Fq by the binary extended Euclidean algorithm on the Montgomery representative y = a R (an integer below p):
-    // y^-1 = a^-1 R^-1, and one Montgomery product with R^3 turns it into a^-1 R. ~500 shift / subtract steps of 8-word
-    // integers instead of the ~380 dependent Montgomery products of Fermat's a^(p-2) (fp_dev.h Fp::inv: 0.5 ms on one lane).
-    // a != 0 (an Fq12 norm of a non-zero element).
+    // 1/a in Fq on one lane: Kaliski's almost-inverse on the Montgomery representative y = a R (an integer below p) -- u, v shrink
+    // by a bit per step while r, s only double and add (plain integers below 2p: no halving modulo p inside the loop, which was
+    // two thirds of the binary extended Euclid of round 2: 127 us) -- gives y^-1 2^k, N' <= k <= 2 N' (N' = bits of p); four
+    // Montgomery products then turn a^-1 R^-1 2^k into a^-1 R: two by R^2, two by the plain integers 2^(32N - j) that take
+    // j <= 32N bits of the 2^k off each. 94 us (the same loop on the scalar unit, its input read with readfirstlane: 114). a != 0 (an Fq12 norm of a non-zero element).
     static __device__ __noinline__ F inv_euclid(const F &a) {
-        F u = a, v, x1 = F::zero(), x2 = F::zero();
+        F u, v = a, r = F::zero(), sv = F::zero();
 #pragma unroll
-        for (int i = 0; i < N; ++i) v.v[i] = K::Fq::P[i];
-        x1.v[0] = 1; // plain integers from here on: u x1' = y ... invariants  u = x1 y, v = x2 y (mod p)
-        auto is_one = [](const F &t) {
-            u32 r = t.v[0] ^ 1u;
-#pragma unroll
-            for (int i = 1; i < N; ++i) r |= t.v[i];
-            return r == 0;
-        };
+        for (int i = 0; i < N; ++i) u.v[i] = K::Fq::P[i];
+        sv.v[0] = 1;
         auto shr1 = [](F &t) {
 #pragma unroll
             for (int i = 0; i < N; ++i) t.v[i] = (t.v[i] >> 1) | ((i + 1 < N ? t.v[i + 1] : 0u) << 31);
         };
-        auto geq = [](const F &s, const F &t) { // s >= t
-            bool ge = true;
+        auto shl1 = [](F &t) {
 #pragma unroll
-            for (int i = 0; i < N; ++i) ge = s.v[i] != t.v[i] ? s.v[i] > t.v[i] : ge;
-            return ge;
+            for (int i = N - 1; i >= 0; --i) t.v[i] = (t.v[i] << 1) | (i ? t.v[i - 1] >> 31 : 0u);
         };
-        auto isub = [](F &s, const F &t) { // plain s -= t (s >= t)
+        auto gt = [](const F &x, const F &y) { // x > y
+            bool g = false;
+#pragma unroll
+            for (int i = 0; i < N; ++i) g = x.v[i] != y.v[i] ? x.v[i] > y.v[i] : g;
+            return g;
+        };
+        auto isub = [](F &x, const F &y) { // plain x -= y (x >= y)
             u32 bw = 0;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
-                const u64 dd = (u64)s.v[i] - t.v[i] - bw;
-                s.v[i] = (u32)dd;
+                const u64 dd = (u64)x.v[i] - y.v[i] - bw;
+                x.v[i] = (u32)dd;
                 bw = (u32)(dd >> 63);
             }
         };
-        while (!is_one(u) && !is_one(v)) {
-            while (!(u.v[0] & 1u)) shr1(u), x1 = half(x1);
-            while (!(v.v[0] & 1u)) shr1(v), x2 = half(x2);
-            if (geq(u, v)) isub(u, v), x1 = F::sub(x1, x2);
-            else isub(v, u), x2 = F::sub(x2, x1);
+        auto iadd = [](F &x, const F &y) { // plain x += y (the sum stays below 2p < 2^(32 N))
+            u32 c = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const u64 ss = (u64)x.v[i] + y.v[i] + c;
+                x.v[i] = (u32)ss;
+                c = (u32)(ss >> 32);
+            }
+        };
+        int k = 0;
+        while (!v.is_zero()) { // invariants: y r = -u 2^k, y s = v 2^k (mod p); gcd(u, v) = 1
+            if (!(u.v[0] & 1u)) shr1(u), shl1(sv);
+            else if (!(v.v[0] & 1u)) shr1(v), shl1(r);
+            else if (gt(u, v)) isub(u, v), shr1(u), iadd(r, sv), shl1(sv);
+            else isub(v, u), shr1(v), iadd(sv, r), shl1(r);
+            ++k;
         }
-        const F yinv = is_one(u) ? x1 : x2;
+        F pp;
+#pragma unroll
+        for (int i = 0; i < N; ++i) pp.v[i] = K::Fq::P[i];
+        if (!gt(pp, r)) isub(r, pp); // r < 2p
+        isub(pp, r);                 // y^-1 2^k = p - r
         F r2;
 #pragma unroll
         for (int i = 0; i < N; ++i) r2.v[i] = K::Fq::R2[i];
-        return F::mul(yinv, F::mul(r2, r2)); // R^3 = mont(R^2, R^2)
+        F t = F::mul(F::mul(pp, r2), r2); // a^-1 2^k R
+        auto pow2 = [](int e) {            // the integer 2^e, e < 32 N
+            F z = F::zero();
+#pragma unroll
+            for (int i = 0; i < N; ++i) z.v[i] = (e >> 5) == i ? 1u << (e & 31) : 0u;
+            return z;
+        };
+        const int j1 = k < 32 * N ? k : 32 * N - 1, j2 = k - j1; // k <= 2 (32 N - 2): both below 32 N, j1 >= 1
+        t = F::mul(t, pow2(32 * N - j1));
+        if (j2) t = F::mul(t, pow2(32 * N - j2));
+        return t;
     }
     // d = 1 / a (registers; t1, t2 scratch; d, t1, t2 distinct from a): 1/a = conj(a) / (a conj(a)), and a conj(a) lies in
     // Fq6 (its odd coefficients cancel exactly), whose inverse is ark-ff's Fp6 formula with the Fq2 products of each level
