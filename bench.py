@@ -822,8 +822,10 @@ def verify_bench(ps, proofs, zs=None):
     bad = inputs.copy()
     bad[0] = ps.rs[0][0]
     assert not api.groth16_verify(vctx, bad, pts[0])
+    n1 = 100
+    for i in range(10):  # untimed: the device idled while the host decoded the proofs above, and a one-wavefront kernel runs at its clock
+        api.groth16_verify(vctx, inputs, pts[i % len(pts)])
     t0 = time.perf_counter()
-    n1 = 20
     for i in range(n1):
         api.groth16_verify(vctx, inputs, pts[i % len(pts)])
     t1 = (time.perf_counter() - t0) / n1
@@ -839,7 +841,7 @@ def verify_bench(ps, proofs, zs=None):
     vctx.close()
     return {"single_ms": round(t1 * 1e3, 3), "single_proofs_per_s": round(1 / t1, 1), "batch": k, "batch_ms": round(tb * 1e3, 3),
             "batch_proofs_per_s": round(k / tb, 1),
-            "how": "3 / k + 3 Miller loops (one wavefront each, the proof's G2 point prepared by a second wavefront alongside) + one wave-cooperative final exponentiation; accepted and a fuzzed input rejected before timing"}
+            "how": "3 / k + 3 Miller loops (two wavefronts each: one makes the lines -- G2Prepared::from of the proof's B as it runs, or the stored table scaled by P -- the other multiplies them in, one Fq product per lane) + one wave-cooperative final exponentiation (cyclotomic squarings, width-4 NAF); 10 untimed + 100 timed single calls; accepted and a fuzzed input rejected before timing"}
 
 
 def prove_cpu_baseline(ps, proofs, ncpu=8):
