@@ -16,6 +16,7 @@
 #include "host_ec.h"
 #include "params_gen.h"
 #include "prover.h"
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -210,7 +211,15 @@ template <class Curve, class K> class VerifierT : public Verifier {
         g2_ = get_engine(curve, 2);
         pe_ = get_pairing_engine(curve);
         if (!g1_ || !g2_ || !pe_) return MG_ERR_ARG;
-        int rc = g1_->bases_create((const u32 *)abc_.data(), P_, false, 0, &abc_bs_);
+        // gamma_abc_g1 with FULL tables (every multiple of every 6-bit window: 2.4 MB for 27 inputs): the prepared-inputs MSM is
+        // then digits + one accumulate + one merge kernel and its point is back on the host 140 us after the call instead of 205
+        // -- the third Miller loop, which waits for it, no longer ends after the other two (tools/abc_sweep_r4.sh;
+        // MANTA_VERIFY_ABC_C = 0: plain bases as in round 3, c > 0: window tables, c < 0: full tables of |c|-bit windows)
+        static const int abc_c = [] {
+            const char *e = getenv("MANTA_VERIFY_ABC_C");
+            return e ? atoi(e) : -6;
+        }();
+        int rc = g1_->bases_create((const u32 *)abc_.data(), P_, false, abc_c, &abc_bs_);
         if (rc) return rc;
         return pe_->prepare((const u32 *)beta_.data(), 1, &d_beta_);
     }
