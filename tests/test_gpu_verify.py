@@ -116,6 +116,39 @@ def test_gpu_pairing_is_bilinear_and_matches_the_oracle_up_to_the_fixed_exponent
     assert one == (1).to_bytes(nb, "little") + bytes(11 * nb)
 
 
+@pytest.mark.parametrize("curve", [0, 1])
+def test_gpu_pairing_at_the_edges_of_the_scalar_range(gpu, curve):
+    """The pairing's one-product-per-lane levels (table-driven signed sums, lazily reduced small-coefficient combinations,
+    cyclotomic squarings, the width-4 NAF of x, the almost-inverse) on the points with the smallest and largest multiples:
+    e(-G1, -G2) = e(G1, G2) = e(2 G1, (r+1)/2 G2), e(-G1, G2) = e(G1, -G2) = e(G1, G2)^-1 (the conjugate), and BN254's values
+    against the oracle's arkworks-exponent pairing."""
+    r = synth.FR_MODULUS[curve]
+    G1, G2 = O.generator(curve, 1), O.generator(curve, 2)
+    lim = lambda k: synth.ints_to_limbs([k % r], 4)[0]
+
+    def e(a, b):
+        k = _Key()
+        k.alpha_g1, k.beta_g2 = O.g_mul(curve, 1, G1, lim(a)), O.g_mul(curve, 2, G2, lim(b))
+        k.gamma_g2, k.delta_g2, k.gamma_abc_g1 = G2, G2, np.stack([G1])
+        return gpu.VerifyingContext(curve, k).alpha_g1_beta_g2(), k
+
+    base, kb = e(1, 1)
+    assert e(r - 1, r - 1)[0] == base and e(2, (r + 1) // 2)[0] == base and e((r + 1) // 2, 2)[0] == base
+    inv1, inv2 = e(r - 1, 1)[0], e(1, r - 1)[0]
+    assert inv1 == inv2 != base
+    nb = len(base) // 12
+    words = lambda bs: [int.from_bytes(bs[i * nb:(i + 1) * nb], "little") for i in range(12)]
+    q = synth.FQ_MODULUS[curve] if hasattr(synth, "FQ_MODULUS") else None
+    if q is not None:  # the inverse of a unitary element is its conjugate: the odd powers of w change sign
+        wb, wi = words(base), words(inv1)
+        # arkworks' memory order c0.(c0, c1, c2), c1.(c0, c1, c2), an Fq2 each: the second half is c1 (the odd powers of w)
+        assert wi[:6] == wb[:6] and all((x + y) % q == 0 for x, y in zip(wi[6:], wb[6:]))
+    if curve == 0:
+        assert base == O.pairing_bytes(0, kb.alpha_g1, kb.beta_g2, ark_exp=True)
+        k2 = e(r - 1, 1)[1]
+        assert inv1 == O.pairing_bytes(0, k2.alpha_g1, k2.beta_g2, ark_exp=True)
+
+
 @pytest.mark.parametrize("curve,k", [(0, 1), (0, 8), (0, 64), (1, 5)])
 def test_gpu_batch_verification(gpu, curve, k):
     """mg_groth16_verify_batch: k proofs with distinct assignments / inputs in one pass (k + 3 Miller loops, one final
