@@ -116,6 +116,39 @@ def test_gpu_pairing_is_bilinear_and_matches_the_oracle_up_to_the_fixed_exponent
     assert one == (1).to_bytes(nb, "little") + bytes(11 * nb)
 
 
+def test_gpu_verify_from_several_threads_at_once(gpu):
+    """Verifications from four host threads on one context: each call takes a pooled pairing workspace (two streams, the
+    third pair's point in the kernel arguments) and an MSM workspace of the shared engine; valid proofs stay valid, a
+    foreign proof and fuzzed inputs stay rejected, whatever is in flight next to them."""
+    from concurrent.futures import ThreadPoolExecutor
+    curve = 0
+    c = synth.make_circuit(curve, 700, 500, 9, seed=977)
+    pk = keygen.generate(c, synth.from_mont(H.toxic(curve, seed=33), synth.FR_MODULUS[curve]))
+    ctx = gpu.ProvingContext(curve, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    vctx = gpu.VerifyingContext(curve, pk)
+    R = synth.Reassigner(c)
+    cs = [R.assign(7000 + q) for q in range(6)]
+    rs = H.rand_fr_mont(curve, 12, seed=98)
+    proofs = [gpu.Groth16.prove_with_randomness(ctx, x.z, rs[2 * q], rs[2 * q + 1]) for q, x in enumerate(cs)]
+
+    def job(t):
+        good = bad = 0
+        for it in range(12):
+            q = (t + it) % len(cs)
+            good += gpu.groth16_verify(vctx, cs[q].z[1:c.P], proofs[q]) is True
+            wrong = proofs[(q + 1) % len(cs)] if it % 2 else proofs[q]
+            inputs = cs[q].z[1:c.P].copy()
+            if not it % 2:
+                inputs[it % (c.P - 1)] = rs[0]
+            bad += gpu.groth16_verify(vctx, inputs, wrong) is False
+        return good, bad
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        res = list(ex.map(job, range(4)))
+    assert res == [(12, 12)] * 4
+
+
 @pytest.mark.parametrize("curve", [0, 1])
 def test_gpu_pairing_at_the_edges_of_the_scalar_range(gpu, curve):
     """The pairing's one-product-per-lane levels (table-driven signed sums, lazily reduced small-coefficient combinations,
