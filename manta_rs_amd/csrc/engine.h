@@ -239,6 +239,14 @@ class GroupEngine {
     // element-wise group operations on host arrays of affine points (the primitive menu of
     // manta-benchmark/src/ecc.rs; op codes in mantagpu.h), run with the MSM kernels' device functions
     virtual int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) = 0;
+    // the same, results left as XYZZ points (xyzz_words() words each; no inversion on the device), and the host conversion of
+    // such an array to affine points with one inversion for all of them
+    virtual int ec_elementwise_xyzz(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_xyzz_host) = 0;
+    virtual void xyzz_batch_to_affine(const u32 *xyzz_host, size_t n, u32 *out_affine_host) const = 0;
+    // k_i P_i around other work: begin() uploads into ws's scratch buffer and launches on ws's stream, finish() waits and fetches
+    // the n XYZZ results (nothing else may use ws in between)
+    virtual int ec_mul_xyzz_begin(const u32 *a_affine_host, const u32 *k_canonical_host, size_t n, MsmWorkspace *ws) = 0;
+    virtual int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host) = 0;
     // radix-2 (I)NTT over a vector of 2^lg group elements (host affine in/out, natural order); d_twiddles_mont = the Fr
     // domain's omega^k table on the device, n_inv_canonical != nullptr scales by n^-1 (inverse transform)
     virtual int group_ntt(const u32 *in_affine_host, unsigned lg, const u32 *d_twiddles_mont, const u32 *n_inv_canonical,

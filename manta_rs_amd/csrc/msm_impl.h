@@ -1970,26 +1970,106 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
 
     int ec_elementwise(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_affine_host) override {
-        if (op < 0 || op > 5 || !a_host || !out_affine_host || n == 0 || (op != 2 && !b_host)) return MG_ERR_ARG;
+        return ec_elementwise_impl(op, a_host, b_host, n, out_affine_host, false);
+    }
+    // the same results as XYZZ points (XW_IO words each): no inversion on the device -- xyzz_batch_to_affine() turns them
+    // into affine points on the host with one inversion for all of them
+    int ec_elementwise_xyzz(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_xyzz_host) override {
+        return ec_elementwise_impl(op, a_host, b_host, n, out_xyzz_host, true);
+    }
+    // the multiplication k_i P_i (op MG_EC_MUL) as two calls around other work: begin() uploads into the workspace's grow-only
+    // scratch buffer and launches on the workspace's stream (no hipMalloc / hipFree / stream 0: nothing else on the device
+    // waits for it and it waits for nothing), finish() waits and fetches the XYZZ results
+    int ec_mul_xyzz_begin(const u32 *a_host, const u32 *k_host, size_t n, MsmWorkspace *ws) override {
+        if (!a_host || !k_host || !n || !ws) return MG_ERR_ARG;
+        const size_t ab = n * AW_IO * 4, bb = n * 32, tb = n * XW_IO * 4;
+        int rc = ws->scratch.reserve(ab + bb + tb);
+        if (rc) return rc;
+        unsigned char *d = (unsigned char *)ws->scratch.p;
+        hipError_t e = hipMemcpyAsync(d, a_host, ab, hipMemcpyHostToDevice, ws->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + ab, k_host, bb, hipMemcpyHostToDevice, ws->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, ws->stream, 3, (const u32 *)d,
+                               (const u32 *)(d + ab), n, (u32 *)(d + ab + bb));
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            hipStreamSynchronize(ws->stream);
+            set_last_hip_error(e, "ec_mul_xyzz", __FILE__, __LINE__);
+            return MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+    int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host) override {
+        if (!ws || !n || !out_xyzz_host) return MG_ERR_ARG;
+        const size_t ab = n * AW_IO * 4, bb = n * 32, tb = n * XW_IO * 4;
+        hipError_t e = hipMemcpyAsync(out_xyzz_host, (unsigned char *)ws->scratch.p + ab + bb, tb, hipMemcpyDeviceToHost, ws->stream);
+        const hipError_t e2 = hipStreamSynchronize(ws->stream);
+        if (e == hipSuccess) e = e2;
+        if (e != hipSuccess) {
+            set_last_hip_error(e, "ec_mul_xyzz", __FILE__, __LINE__);
+            return MG_ERR_HIP;
+        }
+        return MG_OK;
+    }
+    void xyzz_batch_to_affine(const u32 *xyzz_host, size_t n, u32 *out_affine_host) const override {
+        typedef decltype(HP{}.x) HF;
+        std::vector<HF> den(n), pre(n);
+        HF acc = HF::one();
+        for (size_t i = 0; i < n; ++i) { // Montgomery's trick: prefix products of the denominators ZZ ZZZ (1 for infinity)
+            const HP q = HP::from_xyzz_words(xyzz_host + i * XW_IO);
+            den[i] = q.is_inf() ? HF::one() : HF::mul(q.zz, q.zzz);
+            pre[i] = acc;
+            acc = HF::mul(acc, den[i]);
+        }
+        HF inv = HF::inv(acc);
+        for (size_t i = n; i-- > 0;) {
+            const HP q = HP::from_xyzz_words(xyzz_host + i * XW_IO);
+            const HF t = HF::mul(inv, pre[i]); // 1 / (ZZ ZZZ) of point i
+            inv = HF::mul(inv, den[i]);
+            u32 *o = out_affine_host + i * AW_IO;
+            if (q.is_inf()) {
+                std::memset(o, 0, AW_IO * 4);
+                continue;
+            }
+            HF::mul(q.x, HF::mul(t, q.zzz)).store_words(o);
+            HF::mul(q.y, HF::mul(t, q.zz)).store_words(o + HF::WORDS);
+        }
+    }
+    int ec_elementwise_impl(int op, const u32 *a_host, const u32 *b_host, size_t n, u32 *out_host, bool xyzz) {
+        if (op < 0 || op > 5 || !a_host || !out_host || n == 0 || (op != 2 && !b_host)) return MG_ERR_ARG;
         const size_t ab = n * AW_IO * 4, bb = op == 3 ? n * 32 : (op == 5 ? 32 : ab);
         u32 *da = nullptr, *db = nullptr, *tmp = nullptr, *dout = nullptr;
-        hipError_t e = hipMalloc((void **)&da, ab);
+        // a stream of its own (not stream 0: a synchronous copy anywhere else in the process -- another thread creating a base
+        // set, say -- would wait for this kernel, a millisecond of one-lane latency for 128-bit multipliers)
+        hipStream_t st = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&da, ab);
         if (e == hipSuccess) e = hipMalloc((void **)&db, bb);
         if (e == hipSuccess) e = hipMalloc((void **)&tmp, n * XW_IO * 4);
-        if (e == hipSuccess) e = hipMalloc((void **)&dout, ab);
-        if (e == hipSuccess) e = hipMemcpy(da, a_host, ab, hipMemcpyHostToDevice);
-        if (e == hipSuccess && op != 2) e = hipMemcpy(db, b_host, bb, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !xyzz) e = hipMalloc((void **)&dout, ab);
+        if (e == hipSuccess) e = hipMemcpyAsync(da, a_host, ab, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && op != 2) e = hipMemcpyAsync(db, b_host, bb, hipMemcpyHostToDevice, st);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, op, da, db, n, tmp);
-            constexpr int KB = 16;
-            hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, 0, tmp, n, dout,
-                               (u32)AW_IO);
-            e = hipMemcpy(out_affine_host, dout, ab, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, st, op, da, db, n, tmp);
+            if (xyzz) {
+                e = hipMemcpyAsync(out_host, tmp, n * XW_IO * 4, hipMemcpyDeviceToHost, st);
+            } else {
+                constexpr int KB = 16;
+                hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, st, tmp, n, dout,
+                                   (u32)AW_IO);
+                e = hipMemcpyAsync(out_host, dout, ab, hipMemcpyDeviceToHost, st);
+            }
+        }
+        if (st) {
+            const hipError_t e2 = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = e2;
+            hipStreamDestroy(st);
         }
         hipFree(da);
         hipFree(db);
         hipFree(tmp);
-        hipFree(dout);
+        if (dout) hipFree(dout);
         if (e != hipSuccess) {
             set_last_hip_error(e, "ec_elementwise", __FILE__, __LINE__);
             return e == hipErrorOutOfMemory ? MG_ERR_OOM : MG_ERR_HIP;

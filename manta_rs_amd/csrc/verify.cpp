@@ -383,27 +383,42 @@ template <class Curve, class K> class VerifierT : public Verifier {
             r_can[4 * i] = c.v[0], r_can[4 * i + 1] = c.v[1];
             r[i] = HR::to_mont(c);
             s = HR::add(s, r[i]);
-            for (u64 j = 1; j < P_; ++j) {
-                HR x;
-                std::memcpy(x.v, inputs + (i * (P_ - 1) + (j - 1)) * 4, 32);
-                comb[j] = HR::add(comb[j], HR::mul(r[i], x));
-            }
         }
-        comb[0] = s;
-        HostPoint pi;
-        int rc = abc_msm((const u64 *)comb.data(), P_, &pi);
-        if (rc) return rc;
-        // sum_i r_i C_i: a k-term MSM over the proofs' C points
         std::vector<u64> cs(k * G1L), as(k * G1L), bs(k * G2L);
         for (u64 i = 0; i < k; ++i) {
             std::memcpy(as.data() + i * G1L, proofs + i * PL, G1L * 8);
             std::memcpy(bs.data() + i * G2L, proofs + i * PL + G1L, G2L * 8);
             std::memcpy(cs.data() + i * G1L, proofs + i * PL + G1L + G2L, G1L * 8);
         }
+        // r_i A_i, element-wise on the GPU -- k independent 128-bit multiplications, one per lane: a millisecond of pure latency
+        // on a handful of wavefronts. It is launched first, on a workspace stream of its own, and the two MSMs below (which fill
+        // the rest of the machine for 0.4 ms) run next to it; the results come back as XYZZ points and the host turns them into
+        // affine ones with ONE inversion (Montgomery's trick, ~0.1 ms), where the device spent 0.56 ms on Fermat inversions at
+        // one-lane latency. (The base set of the C points is made before the launch: its allocation and synchronous upload would
+        // otherwise wait for that kernel.)
+        std::vector<u64> ra(k * G1L);
+        BaseSet *cb = nullptr;
+        int rc = g1_->bases_create((const u32 *)cs.data(), k, false, 0, &cb);
+        if (rc) return rc;
+        MsmWorkspace *wse = g1_->ws_acquire();
+        int rc_a = wse ? g1_->ec_mul_xyzz_begin((const u32 *)as.data(), (const u32 *)r_can.data(), k, wse) : MG_ERR_HIP;
+        if (rc_a) {
+            if (wse) g1_->ws_release(wse);
+            g1_->bases_destroy(cb);
+            return rc_a;
+        }
+        for (u64 i = 0; i < k; ++i) // (k (P - 1) host products: next to the kernel just launched)
+            for (u64 j = 1; j < P_; ++j) {
+                HR x;
+                std::memcpy(x.v, inputs + (i * (P_ - 1) + (j - 1)) * 4, 32);
+                comb[j] = HR::add(comb[j], HR::mul(r[i], x));
+            }
+        comb[0] = s;
+        HostPoint pi;
+        rc = abc_msm((const u64 *)comb.data(), P_, &pi);
+        // sum_i r_i C_i: a k-term MSM over the proofs' C points
         HostPoint csum;
-        {
-            BaseSet *cb = nullptr;
-            if ((rc = g1_->bases_create((const u32 *)cs.data(), k, false, 0, &cb))) return rc;
+        if (!rc) {
             MsmWorkspace *ws = g1_->ws_acquire();
             rc = ws ? ws->scratch.reserve(k * 32) : MG_ERR_HIP;
             if (!rc && hipMemcpyAsync(ws->scratch.p, r_can.data(), k * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
@@ -411,18 +426,22 @@ template <class Curve, class K> class VerifierT : public Verifier {
             if (!rc) rc = g1_->msm_finish(ws, &csum);
             else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
             if (ws) g1_->ws_release(ws);
-            g1_->bases_destroy(cb);
-            if (rc) return rc;
         }
-        // r_i A_i, element-wise on the GPU
-        std::vector<u64> ra(k * G1L);
-        if ((rc = g1_->ec_elementwise(MG_EC_MUL, (const u32 *)as.data(), (const u32 *)r_can.data(), k, (u32 *)ra.data()))) return rc;
-        // -(sum r_i) alpha on the host
+        // -(sum r_i) alpha on the host (still next to that kernel)
         HostPoint al;
         g1_->hp_from_affine(&al, (const u32 *)alpha_.data());
         HR sc = HR::from_mont(s);
         g1_->hp_mul(&al, sc.v);
         g1_->hp_neg(&al);
+        {
+            std::vector<u32> xy((size_t)k * g1_->xyzz_words());
+            rc_a = g1_->ec_mul_xyzz_finish(wse, k, xy.data()); // (also when an MSM failed: nothing of this call stays in flight)
+            g1_->ws_release(wse);
+            if (!rc && !rc_a) g1_->xyzz_batch_to_affine(xy.data(), k, (u32 *)ra.data());
+        }
+        g1_->bases_destroy(cb);
+        if (rc) return rc;
+        if (rc_a) return rc_a;
         // pairs: (r_i A_i, B_i) ..., (PI, -gamma), (C, -delta), (-s alpha, beta)
         const size_t n = k + 3;
         std::vector<u64> ps(n * G1L);
