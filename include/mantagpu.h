@@ -384,10 +384,12 @@ void mg_vk_destroy(mg_vk *vk);
  * affine Montgomery (the in-memory ark_groth16::Proof<E>; mg_proof_decode gives it from the 128 / 192 proof bytes).
  * *ok = 1 iff the proof verifies; the return value reports only operational failures. */
 int mg_groth16_verify(const mg_vk *vk, const uint64_t *inputs_mont, const uint64_t *proof_points, int *ok);
-/* k proofs against one key by random linear combination: rand128 = k x 2 u64 non-zero 128-bit coefficients from the
- * caller's RNG. k + 3 Miller loops (one wavefront each), two small MSMs and one final exponentiation. *ok = 1 iff ALL
- * k proofs verify (up to the 2^-128 soundness error of the combination); on 0 fall back to mg_groth16_verify to find
- * the offender. */
+/* k proofs against one key by random linear combination: rand128 = k x 2 u64 -- 128 random bits per proof from the
+ * caller's RNG, not both words zero. Proof i enters with the coefficient k1 + lambda k2, (k1, k2) its two words and
+ * lambda the eigenvalue of G1's endomorphism (x, y) -> (beta x, y): 2^128 - 1 distinct non-zero values, and k_i A_i
+ * then costs 64 doublings instead of 128. k + 3 Miller loops (two wavefronts each), k scalar multiplications, two small
+ * MSMs and one final exponentiation. *ok = 1 iff ALL k proofs verify (up to the 2^-128 soundness error of the
+ * combination); on 0 fall back to mg_groth16_verify to find the offender. */
 int mg_groth16_verify_batch(const mg_vk *vk, uint64_t k, const uint64_t *inputs_mont, const uint64_t *proof_points,
                             const uint64_t *rand128, int *ok);
 /* prod_i e(P_i, Q_i) == 1 ? -- the pairing-product test behind `PairingEngineExt::has_same` / `same_ratio`

@@ -245,8 +245,11 @@ class GroupEngine {
     virtual void xyzz_batch_to_affine(const u32 *xyzz_host, size_t n, u32 *out_affine_host) const = 0;
     // k_i P_i around other work: begin() uploads into ws's scratch buffer and launches on ws's stream, finish() waits and fetches
     // the n XYZZ results (nothing else may use ws in between)
-    virtual int ec_mul_xyzz_begin(const u32 *a_affine_host, const u32 *k_canonical_host, size_t n, MsmWorkspace *ws) = 0;
-    virtual int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host) = 0;
+    // glv_beta_std (G1 only; the field element beta of phi(x, y) = (beta x, y) = lambda (x, y), arkworks-format words): the
+    // multipliers are then k1 + lambda k2 with k1, k2 the low two u64 of each 4 x u64 scalar -- one chain of 64 doublings
+    virtual int ec_mul_xyzz_begin(const u32 *a_affine_host, const u32 *k_canonical_host, size_t n, MsmWorkspace *ws,
+                                  const u32 *glv_beta_std = nullptr) = 0;
+    virtual int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host, bool glv = false) = 0;
     // radix-2 (I)NTT over a vector of 2^lg group elements (host affine in/out, natural order); d_twiddles_mont = the Fr
     // domain's omega^k table on the device, n_inv_canonical != nullptr scales by n^-1 (inverse transform)
     virtual int group_ntt(const u32 *in_affine_host, unsigned lg, const u32 *d_twiddles_mont, const u32 *n_inv_canonical,

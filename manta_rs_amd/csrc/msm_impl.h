@@ -1049,6 +1049,7 @@ __global__ __launch_bounds__(256) void group_scale_store_kernel(const u32 *__res
 //   op 2: 2P                                          op 3: [k]P, k = 4 x u64 canonical (double-and-add over madd)
 //   op 4: P - Q via madd with the negate flag            op 5: [k]P with ONE scalar k for all points (`batch_mul_fixed_scalar`,
 //                                                              manta-trusted-setup/src/util.rs:440-445): uniform control flow
+//   op 6 (internal, ec_mul_xyzz_begin): [k1 + lambda k2]P, 64-bit k1 and k2, through the endomorphism (G1 only)
 template <class F>
 __global__ __launch_bounds__(256) void ec_elementwise_kernel(int op, const u32 *__restrict__ a, const u32 *__restrict__ b,
                                                              size_t n, u32 *__restrict__ out_xyzz_std) {
@@ -1075,6 +1076,31 @@ __global__ __launch_bounds__(256) void ec_elementwise_kernel(int op, const u32 *
         acc.add(XYZZ<F>::from_affine(load_affine(b + i * Affine<S>::WORDS)));
     } else if (op == 2) {
         acc = XYZZ<F>::dbl(acc);
+    } else if (op == 6) {
+        // [k1 + lambda k2] P with 64-bit k1, k2 (the low two u64 of the lane's scalar) through the curve's endomorphism
+        // phi(x, y) = (beta x, y) = lambda (x, y): ONE chain of 64 doublings with additions of P, phi(P) or P + phi(P) --
+        // the general addition on a table entry picked by selects, so that every lane runs the same instruction stream
+        // (128 doublings + 64 mixed additions for a 128-bit multiplier otherwise). beta: arkworks-format words behind the
+        // n scalars in b. The batch verifier's random coefficients (verify.cpp).
+        const S beta_std = S::load(b + n * 8);
+        const F beta = F::from_std(beta_std);
+        const XYZZ<F> t1 = acc;
+        XYZZ<F> t2 = acc;
+        if (!t1.is_inf()) t2.x = (bv<F::BM>(pa.x) * bv<F::BM>(beta)).v;
+        XYZZ<F> t3 = t1;
+        t3.add(t2);
+        const u64 k1 = (u64)b[i * 8] | ((u64)b[i * 8 + 1] << 32), k2 = (u64)b[i * 8 + 2] | ((u64)b[i * 8 + 3] << 32);
+        acc = XYZZ<F>::inf();
+        for (int bit = 63; bit >= 0; --bit) {
+            acc = XYZZ<F>::dbl(acc);
+            const int sel = (int)((k1 >> bit) & 1) | ((int)((k2 >> bit) & 1) << 1);
+            XYZZ<F> o;
+            o.x = F::select(sel == 3, t3.x, F::select(sel == 2, t2.x, t1.x));
+            o.y = F::select(sel == 3, t3.y, t1.y); // (phi keeps y)
+            o.zz = F::select(sel == 3, t3.zz, t1.zz);
+            o.zzz = F::select(sel == 3, t3.zzz, t1.zzz);
+            if (sel) acc.add(o);
+        }
     } else {
         acc = XYZZ<F>::inf();
         const size_t si = op == 5 ? 0 : i; // op 5: every lane reads the same scalar
@@ -1980,16 +2006,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // the multiplication k_i P_i (op MG_EC_MUL) as two calls around other work: begin() uploads into the workspace's grow-only
     // scratch buffer and launches on the workspace's stream (no hipMalloc / hipFree / stream 0: nothing else on the device
     // waits for it and it waits for nothing), finish() waits and fetches the XYZZ results
-    int ec_mul_xyzz_begin(const u32 *a_host, const u32 *k_host, size_t n, MsmWorkspace *ws) override {
+    int ec_mul_xyzz_begin(const u32 *a_host, const u32 *k_host, size_t n, MsmWorkspace *ws, const u32 *glv_beta_std) override {
         if (!a_host || !k_host || !n || !ws) return MG_ERR_ARG;
-        const size_t ab = n * AW_IO * 4, bb = n * 32, tb = n * XW_IO * 4;
+        const size_t ab = n * AW_IO * 4, bb = n * 32 + (glv_beta_std ? (size_t)AW_IO / 2 * 4 : 0), tb = n * XW_IO * 4;
         int rc = ws->scratch.reserve(ab + bb + tb);
         if (rc) return rc;
         unsigned char *d = (unsigned char *)ws->scratch.p;
         hipError_t e = hipMemcpyAsync(d, a_host, ab, hipMemcpyHostToDevice, ws->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d + ab, k_host, bb, hipMemcpyHostToDevice, ws->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + ab, k_host, n * 32, hipMemcpyHostToDevice, ws->stream);
+        if (e == hipSuccess && glv_beta_std)
+            e = hipMemcpyAsync(d + ab + n * 32, glv_beta_std, (size_t)AW_IO / 2 * 4, hipMemcpyHostToDevice, ws->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, ws->stream, 3, (const u32 *)d,
+            hipLaunchKernelGGL((ec_elementwise_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, ws->stream, glv_beta_std ? 6 : 3, (const u32 *)d,
                                (const u32 *)(d + ab), n, (u32 *)(d + ab + bb));
             e = hipGetLastError();
         }
@@ -2000,9 +2028,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         return MG_OK;
     }
-    int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host) override {
+    int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host, bool glv) override {
         if (!ws || !n || !out_xyzz_host) return MG_ERR_ARG;
-        const size_t ab = n * AW_IO * 4, bb = n * 32, tb = n * XW_IO * 4;
+        const size_t ab = n * AW_IO * 4, bb = n * 32 + (glv ? (size_t)AW_IO / 2 * 4 : 0), tb = n * XW_IO * 4;
         hipError_t e = hipMemcpyAsync(out_xyzz_host, (unsigned char *)ws->scratch.p + ab + bb, tb, hipMemcpyDeviceToHost, ws->stream);
         const hipError_t e2 = hipStreamSynchronize(ws->stream);
         if (e == hipSuccess) e = e2;

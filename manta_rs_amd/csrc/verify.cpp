@@ -122,6 +122,51 @@ template <class Curve, class K> class VerifierT : public Verifier {
     u32 *d_gneg_ = nullptr, *d_dneg_ = nullptr, *d_beta_ = nullptr; // prepared -gamma, -delta, beta on the device
     BaseSet *abc_bs_ = nullptr;                                     // gamma_abc_g1[0..P) as MSM bases
     std::mutex mu_;
+    // G1's endomorphism phi(x, y) = (beta x, y) = lambda (x, y) (beta^3 = 1 in Fq, lambda^3 = 1 in Fr): the batch check draws
+    // its coefficients as k1 + lambda k2 with 64-bit k1, k2 -- as many distinct values as 128-bit integers (the lattice of
+    // pairs with k1 + lambda k2 = 0 mod r has no vector shorter than ~2^127), and k_i A_i is then one chain of 64 doublings
+    // instead of 128. The pair (lambda, beta) is checked against alpha_g1 when the context is made.
+    bool glv_ok_ = false;
+    HR glv_lambda_;                  // Montgomery
+    std::vector<u32> glv_beta_std_;  // arkworks-format words
+    static void glv_constants(u64 lambda[4], u64 *beta) {
+        if constexpr (N64 == 4) { // BN254
+            const u64 l[4] = {0x8b17ea66b99c90ddull, 0x5bfc41088d8daaa7ull, 0xb3c4d79d41a91758ull, 0};
+            const u64 b[4] = {0x5763473177fffffeull, 0xd4f263f1acdb5c4full, 0x59e26bcea0d48bacull, 0};
+            std::memcpy(lambda, l, 32), std::memcpy(beta, b, 32);
+        } else { // BLS12-381
+            static_assert(N64 == 4 || N64 == 6, "BN254 or BLS12-381");
+            const u64 l[4] = {0x00000000ffffffffull, 0xac45a4010001a402ull, 0, 0};
+            const u64 b[6] = {0x8bfd00000000aaacull, 0x409427eb4f49fffdull, 0x897d29650fb85f9bull,
+                              0xaa0d857d89759ad4ull, 0xec02408663d4de85ull, 0x1a0111ea397fe699ull};
+            std::memcpy(lambda, l, 32), std::memcpy(beta, b, 48);
+        }
+    }
+    void glv_init() {
+        glv_ok_ = false;
+        if (alpha_.size() != (size_t)G1L || is_zero_limbs(alpha_.data(), G1L)) return;
+        u64 lam[4], bet[N64];
+        glv_constants(lam, bet);
+        HF b;
+        std::memcpy(b.v, bet, sizeof(bet));
+        b = HF::to_mont(b);
+        HostPoint p, q;
+        g1_->hp_from_affine(&p, (const u32 *)alpha_.data());
+        g1_->hp_mul(&p, lam);
+        std::vector<u64> lp(G1L), want(alpha_);
+        g1_->hp_to_affine(&p, (u32 *)lp.data());
+        HF ax;
+        std::memcpy(ax.v, alpha_.data(), N64 * 8);
+        ax = HF::mul(ax, b);
+        std::memcpy(want.data(), ax.v, N64 * 8);
+        if (lp != want) return; // (never with the constants above; the batch check then multiplies by plain 128-bit coefficients)
+        HR l;
+        std::memcpy(l.v, lam, 32);
+        glv_lambda_ = HR::to_mont(l);
+        glv_beta_std_.resize(2 * N64);
+        b.store_words(glv_beta_std_.data());
+        glv_ok_ = true;
+    }
 
     ~VerifierT() override {
         int prev = 0;
@@ -221,6 +266,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         }();
         int rc = g1_->bases_create((const u32 *)abc_.data(), P_, false, abc_c, &abc_bs_);
         if (rc) return rc;
+        glv_init();
         return pe_->prepare((const u32 *)beta_.data(), 1, &d_beta_);
     }
 
@@ -375,13 +421,22 @@ template <class Curve, class K> class VerifierT : public Verifier {
         std::vector<HR> r(k);
         HR s = HR::zero();
         std::vector<HR> comb(P_, HR::zero());
-        std::vector<u64> r_can(k * 4, 0);
+        std::vector<u64> r_can(k * 4, 0), r_full(k * 4, 0); // (k1, k2, 0, 0) per proof for the multiplication; the coefficient itself
         for (u64 i = 0; i < k; ++i) {
             HR c = HR::zero();
             c.v[0] = rand128[2 * i], c.v[1] = rand128[2 * i + 1];
             if ((c.v[0] | c.v[1]) == 0) return MG_ERR_ARG; // a zero coefficient would drop proof i from the check
             r_can[4 * i] = c.v[0], r_can[4 * i + 1] = c.v[1];
-            r[i] = HR::to_mont(c);
+            if (glv_ok_) { // the coefficient of proof i is k1 + lambda k2 (k1, k2 = the two halves of its 128 random bits)
+                HR k1 = HR::zero(), k2 = HR::zero();
+                k1.v[0] = c.v[0], k2.v[0] = c.v[1];
+                r[i] = HR::add(HR::to_mont(k1), HR::mul(glv_lambda_, HR::to_mont(k2)));
+                const HR full = HR::from_mont(r[i]);
+                std::memcpy(&r_full[4 * i], full.v, 32);
+            } else {
+                r[i] = HR::to_mont(c);
+                std::memcpy(&r_full[4 * i], c.v, 32);
+            }
             s = HR::add(s, r[i]);
         }
         std::vector<u64> cs(k * G1L), as(k * G1L), bs(k * G2L);
@@ -401,7 +456,8 @@ template <class Curve, class K> class VerifierT : public Verifier {
         int rc = g1_->bases_create((const u32 *)cs.data(), k, false, 0, &cb);
         if (rc) return rc;
         MsmWorkspace *wse = g1_->ws_acquire();
-        int rc_a = wse ? g1_->ec_mul_xyzz_begin((const u32 *)as.data(), (const u32 *)r_can.data(), k, wse) : MG_ERR_HIP;
+        int rc_a = wse ? g1_->ec_mul_xyzz_begin((const u32 *)as.data(), (const u32 *)r_can.data(), k, wse, glv_ok_ ? glv_beta_std_.data() : nullptr)
+                       : MG_ERR_HIP;
         if (rc_a) {
             if (wse) g1_->ws_release(wse);
             g1_->bases_destroy(cb);
@@ -421,7 +477,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         if (!rc) {
             MsmWorkspace *ws = g1_->ws_acquire();
             rc = ws ? ws->scratch.reserve(k * 32) : MG_ERR_HIP;
-            if (!rc && hipMemcpyAsync(ws->scratch.p, r_can.data(), k * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
+            if (!rc && hipMemcpyAsync(ws->scratch.p, r_full.data(), k * 32, hipMemcpyHostToDevice, ws->stream) != hipSuccess) rc = MG_ERR_HIP;
             if (!rc) rc = g1_->msm_launch(cb, ws->scratch.as<u32>(), k, SCALARS_CANONICAL, 0, ws);
             if (!rc) rc = g1_->msm_finish(ws, &csum);
             else if (ws) hipStreamSynchronize(ws->stream), ws->pending = 0;
@@ -435,7 +491,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         g1_->hp_neg(&al);
         {
             std::vector<u32> xy((size_t)k * g1_->xyzz_words());
-            rc_a = g1_->ec_mul_xyzz_finish(wse, k, xy.data()); // (also when an MSM failed: nothing of this call stays in flight)
+            rc_a = g1_->ec_mul_xyzz_finish(wse, k, xy.data(), glv_ok_); // (also when an MSM failed: nothing of this call stays in flight)
             g1_->ws_release(wse);
             if (!rc && !rc_a) g1_->xyzz_batch_to_affine(xy.data(), k, (u32 *)ra.data());
         }
