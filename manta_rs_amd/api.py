@@ -824,7 +824,7 @@ def groth16_verify(context: VerifyingContext, inputs, proof) -> bool:
 
 def groth16_verify_batch(context: VerifyingContext, inputs, proofs, rand128) -> bool:
     """k proofs of one key in one pass (`mg_groth16_verify_batch`): inputs [k, P - 1, 4], proofs = k proof byte strings
-    (or [k, limbs] points), rand128 [k, 2] uint64 non-zero coefficients."""
+    (or [k, limbs] points), rand128 [k, 2] uint64: 128 random bits per proof (not both words zero; proof i enters with k1 + lambda k2, see mantagpu.h)."""
     k = len(proofs)
     inp = _u64(inputs).reshape(k, -1, 4)
     if inp.shape[1] != context.num_inputs - 1:
