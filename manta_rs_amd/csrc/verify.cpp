@@ -150,7 +150,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         HF b;
         std::memcpy(b.v, bet, sizeof(bet));
         b = HF::to_mont(b);
-        HostPoint p, q;
+        HostPoint p;
         g1_->hp_from_affine(&p, (const u32 *)alpha_.data());
         g1_->hp_mul(&p, lam);
         std::vector<u64> lp(G1L), want(alpha_);
