@@ -136,6 +136,9 @@ template <class K> class PairingEngineT : public PairingEngine {
     // the remaining ones (their G2 sides -- prepared coefficients -- were given to begin()), runs their Miller loops on a second
     // stream next to the ones still in flight, then the product tree and the final exponentiation. A verification computes
     // its prepared-inputs point (an MSM) between the two calls instead of in front of all three Miller loops.
+    // factors per wavefront and level of the product tree: a level is chunk - 1 dependent Fq12 products (5.6 us each), so a batch
+    // of 259 Miller values costs 18 of them in chunks of 8 (three levels) and 11 in chunks of 3 (six levels)
+    static constexpr size_t PRODUCT_CHUNK = 3;
     int pairing_product_begin(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                               const unsigned char *skip, size_t n, size_t n_early, void **handle) override {
         if (!p_affine_host || !d_coeffs || !n || !handle || n_early > n || !n_early) return MG_ERR_ARG;
@@ -145,7 +148,7 @@ template <class K> class PairingEngineT : public PairingEngine {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         const size_t pb = n * 2 * P::N * 4, qb = q_affine_host ? n * 2 * P::F2W * 4 : 0, cb = n * sizeof(u32 *);
         const size_t o_q = up(pb), o_c = o_q + up(qb), o_s = o_c + up(cb), in_bytes = o_s + up(n);
-        const size_t o_f = in_bytes, o_g = o_f + up(n * P::F12W * 4), total = o_g + up((n / 8 + 2) * P::F12W * 4);
+        const size_t o_f = in_bytes, o_g = o_f + up(n * P::F12W * 4), total = o_g + up((n / PRODUCT_CHUNK + 2) * P::F12W * 4);
         // pooled workspace (device block + pinned staging + non-blocking streams of its own): no hipMalloc / hipFree per call --
         // hipFree synchronises the whole device and would stall every proof in flight on this GPU -- and nothing on stream 0
         const size_t late_bytes = up((n - n_early) * 2 * P::N * 4);
@@ -210,11 +213,11 @@ template <class K> class PairingEngineT : public PairingEngine {
         }
         if (e == hipSuccess) {
             u32 *df = (u32 *)(d + w->o_f), *dg = (u32 *)(d + w->o_g);
-            // product tree: chunks of 8 per wavefront until one element is left
+            // product tree: chunks of PRODUCT_CHUNK per wavefront until one element is left
             u32 *src = df, *dst = dg;
             size_t m = n;
             while (m > 1) {
-                const size_t chunk = 8, outn = (m + chunk - 1) / chunk;
+                const size_t chunk = PRODUCT_CHUNK, outn = (m + chunk - 1) / chunk;
                 hipLaunchKernelGGL((f12_product_kernel<K>), dim3((unsigned)outn), dim3(64), PW::lds_bytes(2), st, src, m, chunk, dst);
                 u32 *t = src;
                 src = dst;
