@@ -451,7 +451,6 @@ template <class Curve, class K> class VerifierT : public Verifier {
         // affine ones with ONE inversion (Montgomery's trick, ~0.1 ms), where the device spent 0.56 ms on Fermat inversions at
         // one-lane latency. (The base set of the C points is made before the launch: its allocation and synchronous upload would
         // otherwise wait for that kernel.)
-        std::vector<u64> ra(k * G1L);
         BaseSet *cb = nullptr;
         int rc = g1_->bases_create((const u32 *)cs.data(), k, false, 0, &cb);
         if (rc) return rc;
@@ -489,22 +488,24 @@ template <class Curve, class K> class VerifierT : public Verifier {
         HR sc = HR::from_mont(s);
         g1_->hp_mul(&al, sc.v);
         g1_->hp_neg(&al);
+        // pairs: (r_i A_i, B_i) ..., (PI, -gamma), (C, -delta), (-s alpha, beta); the three fixed ones are made affine (an inversion
+        // each) while the multiplications still run
+        const size_t n = k + 3;
+        std::vector<u64> ps(n * G1L);
+        if (!rc) {
+            g1_->hp_to_affine(&pi, (u32 *)(ps.data() + k * G1L));
+            g1_->hp_to_affine(&csum, (u32 *)(ps.data() + (k + 1) * G1L));
+            g1_->hp_to_affine(&al, (u32 *)(ps.data() + (k + 2) * G1L));
+        }
         {
             std::vector<u32> xy((size_t)k * g1_->xyzz_words());
             rc_a = g1_->ec_mul_xyzz_finish(wse, k, xy.data(), glv_ok_); // (also when an MSM failed: nothing of this call stays in flight)
             g1_->ws_release(wse);
-            if (!rc && !rc_a) g1_->xyzz_batch_to_affine(xy.data(), k, (u32 *)ra.data());
+            if (!rc && !rc_a) g1_->xyzz_batch_to_affine(xy.data(), k, (u32 *)ps.data());
         }
         g1_->bases_destroy(cb);
         if (rc) return rc;
         if (rc_a) return rc_a;
-        // pairs: (r_i A_i, B_i) ..., (PI, -gamma), (C, -delta), (-s alpha, beta)
-        const size_t n = k + 3;
-        std::vector<u64> ps(n * G1L);
-        std::memcpy(ps.data(), ra.data(), k * G1L * 8);
-        g1_->hp_to_affine(&pi, (u32 *)(ps.data() + k * G1L));
-        g1_->hp_to_affine(&csum, (u32 *)(ps.data() + (k + 1) * G1L));
-        g1_->hp_to_affine(&al, (u32 *)(ps.data() + (k + 2) * G1L));
         std::vector<const u32 *> cp(n, nullptr); // the k proof points B_i are prepared on the fly
         std::vector<unsigned char> skip(n, 0);
         std::vector<u64> qs(n * G2L, 0);
