@@ -250,6 +250,7 @@ class GroupEngine {
     virtual int ec_mul_xyzz_begin(const u32 *a_affine_host, const u32 *k_canonical_host, size_t n, MsmWorkspace *ws,
                                   const u32 *glv_beta_std = nullptr) = 0;
     virtual int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host, bool glv = false) = 0;
+    virtual const u32 *ec_mul_xyzz_device(MsmWorkspace *ws, size_t n, bool glv = false) const = 0; // the results in device memory (valid on ws's stream after begin())
     // radix-2 (I)NTT over a vector of 2^lg group elements (host affine in/out, natural order); d_twiddles_mont = the Fr
     // domain's omega^k table on the device, n_inv_canonical != nullptr scales by n^-1 (inverse transform)
     virtual int group_ntt(const u32 *in_affine_host, unsigned lg, const u32 *d_twiddles_mont, const u32 *n_inv_canonical,

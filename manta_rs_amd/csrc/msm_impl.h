@@ -2028,6 +2028,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         return MG_OK;
     }
+    const u32 *ec_mul_xyzz_device(MsmWorkspace *ws, size_t n, bool glv) const override { // where begin()'s kernel leaves the n results
+        const size_t ab = n * AW_IO * 4, bb = n * 32 + (glv ? (size_t)AW_IO / 2 * 4 : 0);
+        return ws && ws->scratch.p ? (const u32 *)((unsigned char *)ws->scratch.p + ab + bb) : nullptr;
+    }
     int ec_mul_xyzz_finish(MsmWorkspace *ws, size_t n, u32 *out_xyzz_host, bool glv) override {
         if (!ws || !n || !out_xyzz_host) return MG_ERR_ARG;
         const size_t ab = n * AW_IO * 4, bb = n * 32 + (glv ? (size_t)AW_IO / 2 * 4 : 0), tb = n * XW_IO * 4;

@@ -683,7 +683,7 @@ template <class K> struct PairingWave {
     // ---- the ring through which wave 1 of the Miller kernel hands lines to wave 0. An entry is what `ell` multiplies with
     // (RINGW words: the coefficients scaled by px / py); wave 1 makes it either from G2Prepared::from(Q) as that
     // runs (prepare<true>, below) or from a stored coefficient table (scale_stored)
-    static constexpr int PREP_WORDS_ = 44 * W; // = PREP_SLOTS * W (the enum is declared further down)
+    static constexpr int PREP_WORDS_ = 45 * W; // = PREP_SLOTS * W (the enum is declared further down)
     static constexpr int RING_OFF = MILLER_WORDS + PREP_WORDS_, CNT_OFF = RING_OFF + RING * RINGW;
     static constexpr size_t miller_lds_bytes() { return (size_t)(CNT_OFF + 2) * 4; }
     static MG_DEV volatile u32 *counters() { return (volatile u32 *)(mg_pairing_lds + CNT_OFF); } // [0] produced, [1] consumed
@@ -732,18 +732,19 @@ template <class K> struct PairingWave {
     }
     // wave 1, Q prepared in advance (the verifying key's -gamma, -delta; arkworks' table of NCOEFF triples in global memory):
     // scale each triple by P's coordinates and hand it on -- well ahead of wave 0, which so never waits
-    // for a global load
+    // for a global load. (px, py, pz) = (x, y, 1) for an affine P; for P = (X, Y, ZZ, ZZZ) the line is taken times ZZ ZZZ --
+    // (X ZZZ, Y ZZ, ZZ ZZZ) -- a factor in Fq, which the final exponentiation sends to 1: no inversion for a point that comes
+    // out of a scalar multiplication
     static constexpr int T_PLAIN = K::TWIST_D ? 2 : 0, T_PY = K::TWIST_D ? 0 : 2; // t = 1 is scaled by px on both twists
-    static __device__ void scale_stored(const u32 *co, const F &px, const F &py) {
+    static __device__ void scale_stored(const u32 *co, const F &px, const F &py, const F &pz) {
         const int l = lane_id();
-        const F one = F::one();
 #pragma unroll 1
         for (int o = 0; o < P::NCOEFF; ++o) {
             F raw = F::zero();
             const int t = l >> 1, comp = l & 1;
             if (l < 6) raw = F::load(co + (size_t)o * P::COEFFW + t * W + comp * N);
             u32 *e = ring_reserve(o);
-            if (l < 6) F::mul(raw, F::select(t == T_PLAIN, one, F::select(t == T_PY, py, px))).store(e + t * W + comp * N);
+            if (l < 6) F::mul(raw, F::select(t == T_PLAIN, pz, F::select(t == T_PY, py, px))).store(e + t * W + comp * N);
             ring_publish(o);
         }
     }
@@ -765,6 +766,7 @@ template <class K> struct PairingWave {
     enum { SX = 0, SY, SZ, XY, BB, CC, JJ, YZ, NE, FV, MM, GG, HH, CB3, CB9, ZERO, QX, QY, TH, LA, AC, AD, AE, AF, AG, AG2, AH, GH,
            CR0, CR1, CR2, // line coefficients before their scaling by px / py
            PXY,           // (px, py)
+           PZ,            // (pz, 0): the factor of the coefficient that px / py do not touch (1 for an affine P)
            QP,            // QP .. QP + 11 hold the (up to twenty-four) Fq products of a level
            PREP_SLOTS = QP + 12 };
     static constexpr size_t prep_lds_bytes() { return (size_t)PREP_SLOTS * W * 4; }
@@ -787,9 +789,9 @@ template <class K> struct PairingWave {
         constexpr void product(int sa, int sb) { // Fq2 slot sa x Fq2 slot sb on four lanes: a0 b0, a1 b1, a0 b1, a1 b0
             for (int k = 0; k < 4; ++k) put(fq(sa, k & 1), fq(sb, (k == 1 || k == 2) ? 1 : 0));
         }
-        // ring mode: coefficient t (raw in Fq2 slot raw) times px / py, to the ring entry
+        // ring mode: coefficient t (raw in Fq2 slot raw) times px / py / pz, to the ring entry
         constexpr void scale(int t, int raw) {
-            for (int c = 0; c < 2; ++c) put(fq(raw, c), fq(PXY, t == T_PY ? 1 : 0), OUT | fq(t, c));
+            for (int c = 0; c < 2; ++c) put(fq(raw, c), t == T_PLAIN ? fq(PZ, 0) : fq(PXY, t == T_PY ? 1 : 0), OUT | fq(t, c));
         }
     };
     struct LinTab { // a linear level: lane l adds up (at most four) signed Fq slots
@@ -802,11 +804,8 @@ template <class K> struct PairingWave {
         }
         // component c of line coefficient t: arkworks' table (raw mode) / the ring entry or the slot its scaling reads (ring mode)
         constexpr void coeff(bool ring, int t, int c, u32 o, u32 fl = 0) {
-            if (!ring || t == T_PLAIN) {
-                put(o, OUT | fq(t, c), fl);
-            } else {
-                put(o, fq(CR0 + t, c), fl);
-            }
+            if (!ring) put(o, OUT | fq(t, c), fl);
+            else put(o, fq(CR0 + t, c), fl);
         }
     };
     static constexpr int T_DBL_NH = K::TWIST_D ? 0 : 2, T_DBL_I = K::TWIST_D ? 2 : 0; // (-h, 3j, i) or (i, 3j, -h)
@@ -844,7 +843,7 @@ template <class K> struct PairingWave {
     template <bool RG> static constexpr ProdTab d_s3() {
         ProdTab t;
         t.product(XY, MM), t.product(GG, GG), t.product(NE, FV), t.product(BB, HH);
-        if (RG) t.scale(T_PY, CR0 + T_PY), t.scale(1, CR1);
+        if (RG) t.scale(T_PY, CR0 + T_PY), t.scale(1, CR1), t.scale(T_PLAIN, CR0 + T_PLAIN);
         return t;
     }
     template <bool RG> static constexpr LinTab d_r3() {
@@ -886,7 +885,7 @@ template <class K> struct PairingWave {
     template <bool RG> static constexpr ProdTab a_s3() {
         ProdTab t;
         t.product(LA, AD), t.product(SZ, AC), t.product(SX, AD);
-        if (RG) t.scale(T_PY, LA), t.scale(1, CR1); // (lambda is the coefficient that py scales on either twist)
+        if (RG) t.scale(T_PY, LA), t.scale(1, CR1), t.scale(T_PLAIN, CR0 + T_PLAIN); // (lambda is the coefficient that py scales on either twist)
         return t;
     }
     template <bool RG> static constexpr LinTab a_r3a() {
@@ -974,7 +973,7 @@ template <class K> struct PairingWave {
     }
     // The NCOEFF line-coefficient triples of Q (affine, not infinity) in the order the Miller loop consumes them: as arkworks'
     // table in global memory (RG = false: g2_prepare_kernel), or as ring entries for wave 0's Miller loop with P = (px, py)
-    template <bool RG> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out, const F &px, const F &py) {
+    template <bool RG> static __device__ void prepare(const F2 &qx, const F2 &qy, u32 *out, const F &px, const F &py, const F &pz) {
         static_assert(PREP_SLOTS * W == PREP_WORDS_, "layout");
         static_assert(fq(PREP_SLOTS, 0) <= 128, "seven bits per operand");
         const u32 ds1 = lane_prod(d_s1()), ds2 = lane_prod(d_s2()), ds3 = lane_prod(d_s3<RG>());
@@ -986,7 +985,7 @@ template <class K> struct PairingWave {
         if (lane_id() == 0) {
             const F2 b3 = triple(P::f2const(K::B2));
             st(SX, qx), st(SY, qy), st(SZ, F2::one()), st(QX, qx), st(QY, qy), st(ZERO, F2::zero()), st(CB3, b3), st(CB9, triple(b3));
-            st(PXY, F2{px, py});
+            st(PXY, F2{px, py}), st(PZ, F2{pz, F::zero()});
         }
         sync();
         int o = 0;

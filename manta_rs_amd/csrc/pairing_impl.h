@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void g2_prepare_kernel(const u32 *__restrict__ 
         for (int k = threadIdx.x; k < P::NCOEFF * P::COEFFW; k += 64) o[k] = 0;
         return;
     }
-    w::template prepare<false>(qx, qy, o, P::F::zero(), P::F::zero());
+    w::template prepare<false>(qx, qy, o, P::F::zero(), P::F::zero(), P::F::zero());
 }
 
 // workgroup i (two wavefronts): f_i = Miller(P_i, Q_i); a pair with an infinity member contributes 1 (ark-ec filters such
@@ -39,26 +39,36 @@ template <class K> struct G1Arg {
 template <class K>
 __global__ __launch_bounds__(128) void miller_kernel(const u32 *__restrict__ p, const u32 *const *__restrict__ coeffs,
                                                      const u32 *__restrict__ q, const unsigned char *__restrict__ skip, size_t n,
-                                                     u32 *__restrict__ out, const G1Arg<K> p_arg) {
+                                                     u32 *__restrict__ out, const G1Arg<K> p_arg, const u32 *__restrict__ p_xyzz,
+                                                     u32 n_xyzz) {
     typedef Pairing<K> P;
     typedef PairingWave<K> PW;
     typedef PW w;
     const size_t i = blockIdx.x;
     const u32 *co = coeffs[i];
-    typename P::F px, py;
-    if (p) {
-        px = P::F::load(p + i * 2 * P::N), py = P::F::load(p + i * 2 * P::N + P::N);
+    typename P::F px, py, pz = P::F::one();
+    bool p_inf;
+    if (i < n_xyzz) { // (X, Y, ZZ, ZZZ) in device memory (the result of a scalar multiplication): the lines times ZZ ZZZ, no inversion
+        const u32 *g = p_xyzz + i * 4 * P::N;
+        const typename P::F X = P::F::load(g), Y = P::F::load(g + P::N), ZZ = P::F::load(g + 2 * P::N), ZZZ = P::F::load(g + 3 * P::N);
+        p_inf = ZZ.is_zero();
+        px = P::F::mul(X, ZZZ), py = P::F::mul(Y, ZZ), pz = P::F::mul(ZZ, ZZZ);
     } else {
+        if (p) {
+            px = P::F::load(p + i * 2 * P::N), py = P::F::load(p + i * 2 * P::N + P::N);
+        } else {
 #pragma unroll
-        for (int k = 0; k < P::N; ++k) px.v[k] = p_arg.w[k], py.v[k] = p_arg.w[P::N + k];
+            for (int k = 0; k < P::N; ++k) px.v[k] = p_arg.w[k], py.v[k] = p_arg.w[P::N + k];
+        }
+        p_inf = px.is_zero() && py.is_zero();
     }
-    const bool one = skip[i] || (px.is_zero() && py.is_zero());
+    const bool one = skip[i] || p_inf;
     if (threadIdx.x == 0) w::counters()[0] = 0, w::counters()[1] = 0;
     __syncthreads(); // the only workgroup barrier: from here on the two wavefronts run different programs
     if (w::wave_id() == 1) { // the lines, as ring entries: from the stored table of Q, or from G2Prepared::from(Q) as it runs
         if (one) return;
-        if (co) w::scale_stored(co, px, py);
-        else w::template prepare<true>(P::F2::load(q + i * 2 * P::F2W), P::F2::load(q + i * 2 * P::F2W + P::F2W), nullptr, px, py);
+        if (co) w::scale_stored(co, px, py, pz);
+        else w::template prepare<true>(P::F2::load(q + i * 2 * P::F2W), P::F2::load(q + i * 2 * P::F2W + P::F2W), nullptr, px, py, pz);
         return;
     }
     if (one) w::set_one(PW::R(0));
@@ -131,6 +141,16 @@ template <class K> class PairingEngineT : public PairingEngine {
         const int rc = pairing_product_begin(p_affine_host, d_coeffs, q_affine_host, skip, n, n, &h);
         return rc ? rc : pairing_product_end(h, nullptr, do_final_exp, out_f12_host);
     }
+    // the same with the G1 points of the first n_xyzz pairs taken from DEVICE memory as (X, Y, ZZ, ZZZ) -- what `producer`, the
+    // stream of the kernel that makes them, leaves there (p_affine_host's first n_xyzz entries are ignored)
+    int pairing_product_xyzz(const u32 *p_affine_host, const u32 *d_p_xyzz, size_t n_xyzz, void *producer, const u32 *const *d_coeffs,
+                             const u32 *q_affine_host, const unsigned char *skip, size_t n, bool do_final_exp,
+                             u32 *out_f12_host) override {
+        if (n_xyzz > n || (n_xyzz && (!d_p_xyzz || !producer))) return MG_ERR_ARG;
+        void *h = nullptr;
+        const int rc = begin_impl(p_affine_host, d_coeffs, q_affine_host, skip, n, n, &h, d_p_xyzz, n_xyzz, (hipStream_t)producer);
+        return rc ? rc : pairing_product_end(h, nullptr, do_final_exp, out_f12_host);
+    }
 
     // The same product in two steps: begin() starts the Miller loops of the first n_early pairs; end() takes the G1 points of
     // the remaining ones (their G2 sides -- prepared coefficients -- were given to begin()), runs their Miller loops on a second
@@ -141,6 +161,10 @@ template <class K> class PairingEngineT : public PairingEngine {
     static constexpr size_t PRODUCT_CHUNK = 3;
     int pairing_product_begin(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                               const unsigned char *skip, size_t n, size_t n_early, void **handle) override {
+        return begin_impl(p_affine_host, d_coeffs, q_affine_host, skip, n, n_early, handle, nullptr, 0, nullptr);
+    }
+    int begin_impl(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host, const unsigned char *skip, size_t n,
+                   size_t n_early, void **handle, const u32 *d_p_xyzz, size_t n_xyzz, hipStream_t producer) {
         if (!p_affine_host || !d_coeffs || !n || !handle || n_early > n || !n_early) return MG_ERR_ARG;
         for (size_t i = 0; i < n; ++i)
             if (!d_coeffs[i] && (!q_affine_host || i >= n_early)) return MG_ERR_ARG;
@@ -165,10 +189,14 @@ template <class K> class PairingEngineT : public PairingEngine {
         unsigned char *d = w->d;
         hipError_t e = hipMemcpyAsync(d, stage, in_bytes, hipMemcpyHostToDevice, w->s);
         if (e == hipSuccess && n_early < n) e = hipEventRecord(w->ev, w->s); // the late pairs' coefficient pointers and flags sit in the block this upload fills
+        if (e == hipSuccess && n_xyzz) { // the points another stream's kernel is still making
+            e = hipEventRecord(w->evx, producer);
+            if (e == hipSuccess) e = hipStreamWaitEvent(w->s, w->evx, 0);
+        }
         if (e == hipSuccess)
             hipLaunchKernelGGL((miller_kernel<K>), dim3((unsigned)n_early), dim3(128), PW::miller_lds_bytes(), w->s, (const u32 *)d,
                                (const u32 *const *)(d + o_c), qb ? (const u32 *)(d + o_q) : nullptr, (const unsigned char *)(d + o_s),
-                               n_early, (u32 *)(d + o_f), G1Arg<K>{});
+                               n_early, (u32 *)(d + o_f), G1Arg<K>{}, d_p_xyzz, (u32)(n_xyzz < n_early ? n_xyzz : n_early));
         if (e == hipSuccess && n_early < n) e = hipEventRecord(w->ev3, w->s); // the early Miller loops are done
         if (e != hipSuccess) {
             hipStreamSynchronize(w->s);
@@ -203,7 +231,7 @@ template <class K> class PairingEngineT : public PairingEngine {
                                    n_late == 1 ? (const u32 *)nullptr : (const u32 *)(d + off),
                                    (const u32 *const *)(d + w->o_c) + w->n_early, (const u32 *)nullptr,
                                    (const unsigned char *)(d + w->o_s) + w->n_early, n_late,
-                                   (u32 *)(d + w->o_f) + w->n_early * P::F12W, arg);
+                                   (u32 *)(d + w->o_f) + w->n_early * P::F12W, arg, (const u32 *)nullptr, 0u);
             }
             // the rest runs behind the late loops on THEIR stream: they end last, and by then the early ones' event has long been
             // signalled -- waiting the other way round (the first stream for the late loops) left 30-70 us between the end of
@@ -254,7 +282,7 @@ template <class K> class PairingEngineT : public PairingEngine {
         void *h = nullptr;
         size_t dcap = 0, hcap = 0;
         hipStream_t s = nullptr, s2 = nullptr; // s2: the Miller loops of pairs handed in late
-        hipEvent_t ev = nullptr, ev3 = nullptr; // upload done; early Miller loops done
+        hipEvent_t ev = nullptr, ev3 = nullptr, evx = nullptr; // upload done; early Miller loops done; a producer stream's points are there
         size_t n = 0, n_early = 0, o_q = 0, o_c = 0, o_s = 0, o_f = 0, o_g = 0, h_late = 0; // the product in flight
     };
     std::mutex ws_mu_;
@@ -273,7 +301,8 @@ template <class K> class PairingEngineT : public PairingEngine {
             if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess ||
                 hipStreamCreateWithFlags(&w->s2, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&w->ev3, hipEventDisableTiming) != hipSuccess) {
+                hipEventCreateWithFlags(&w->ev3, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&w->evx, hipEventDisableTiming) != hipSuccess) {
                 delete w; // (creation failures at start-up only; the handles made so far are left to process exit)
                 return nullptr;
             }

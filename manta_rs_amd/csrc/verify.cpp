@@ -489,32 +489,30 @@ template <class Curve, class K> class VerifierT : public Verifier {
         g1_->hp_mul(&al, sc.v);
         g1_->hp_neg(&al);
         // pairs: (r_i A_i, B_i) ..., (PI, -gamma), (C, -delta), (-s alpha, beta); the three fixed ones are made affine (an inversion
-        // each) while the multiplications still run
+        // each) while the multiplications still run. The k products r_i A_i never leave the device: the Miller kernel waits for
+        // their kernel and reads them as (X, Y, ZZ, ZZZ) -- no download, inversion, upload between the two
         const size_t n = k + 3;
-        std::vector<u64> ps(n * G1L);
+        std::vector<u64> ps(n * G1L, 0);
         if (!rc) {
             g1_->hp_to_affine(&pi, (u32 *)(ps.data() + k * G1L));
             g1_->hp_to_affine(&csum, (u32 *)(ps.data() + (k + 1) * G1L));
             g1_->hp_to_affine(&al, (u32 *)(ps.data() + (k + 2) * G1L));
         }
-        {
-            std::vector<u32> xy((size_t)k * g1_->xyzz_words());
-            rc_a = g1_->ec_mul_xyzz_finish(wse, k, xy.data(), glv_ok_); // (also when an MSM failed: nothing of this call stays in flight)
-            g1_->ws_release(wse);
-            if (!rc && !rc_a) g1_->xyzz_batch_to_affine(xy.data(), k, (u32 *)ps.data());
-        }
-        g1_->bases_destroy(cb);
-        if (rc) return rc;
-        if (rc_a) return rc_a;
-        std::vector<const u32 *> cp(n, nullptr); // the k proof points B_i are prepared on the fly
-        std::vector<unsigned char> skip(n, 0);
-        std::vector<u64> qs(n * G2L, 0);
-        std::memcpy(qs.data(), bs.data(), k * G2L * 8);
-        for (u64 i = 0; i < k; ++i) skip[i] = (unsigned char)is_zero_limbs(bs.data() + i * G2L, G2L);
-        cp[k] = d_gamma_neg(), cp[k + 1] = d_delta_neg(), cp[k + 2] = d_beta_;
-        skip[k + 2] = (unsigned char)is_zero_limbs(beta_.data(), G2L);
         std::vector<u32> out(pe_->f12_words());
-        rc = pe_->pairing_product((const u32 *)ps.data(), cp.data(), (const u32 *)qs.data(), skip.data(), n, true, out.data());
+        if (!rc) {
+            std::vector<const u32 *> cp(n, nullptr); // the k proof points B_i are prepared on the fly
+            std::vector<unsigned char> skip(n, 0);
+            std::vector<u64> qs(n * G2L, 0);
+            std::memcpy(qs.data(), bs.data(), k * G2L * 8);
+            for (u64 i = 0; i < k; ++i) skip[i] = (unsigned char)is_zero_limbs(bs.data() + i * G2L, G2L);
+            cp[k] = d_gamma_neg(), cp[k + 1] = d_delta_neg(), cp[k + 2] = d_beta_;
+            skip[k + 2] = (unsigned char)is_zero_limbs(beta_.data(), G2L);
+            rc = pe_->pairing_product_xyzz((const u32 *)ps.data(), g1_->ec_mul_xyzz_device(wse, k, glv_ok_), k, (void *)wse->stream, cp.data(),
+                                           (const u32 *)qs.data(), skip.data(), n, true, out.data());
+        }
+        hipStreamSynchronize(wse->stream); // (also on the error paths: nothing of this call stays in flight)
+        g1_->ws_release(wse);
+        g1_->bases_destroy(cb);
         if (rc) return rc;
         std::vector<u32> one(out.size(), 0u);
         HF::one().store_words(one.data());

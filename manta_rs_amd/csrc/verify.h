@@ -20,6 +20,12 @@ class PairingEngine {
     // skip[i] != 0 leaves pair i out (its G2 point was infinity)
     virtual int pairing_product(const u32 *p_affine_host, const u32 *const *d_coeffs, const u32 *q_affine_host,
                                 const unsigned char *skip, size_t n, bool do_final_exp, u32 *out_f12_host) = 0;
+    // the same with the G1 points of the first n_xyzz pairs in DEVICE memory as (X, Y, ZZ, ZZZ), 4 fq_words() each -- left there
+    // by a kernel on the HIP stream `producer` (the lines of such a pair are taken times ZZ ZZZ, which the final
+    // exponentiation removes: no inversion between a scalar multiplication and its pairing)
+    virtual int pairing_product_xyzz(const u32 *p_affine_host, const u32 *d_p_xyzz, size_t n_xyzz, void *producer,
+                                     const u32 *const *d_coeffs, const u32 *q_affine_host, const unsigned char *skip, size_t n,
+                                     bool do_final_exp, u32 *out_f12_host) = 0;
     // the same in two steps: the Miller loops of the first n_early pairs start at once (P points of those only; coefficients /
     // Q / skip of all n); end() takes the G1 points of the other pairs -- which must have prepared coefficients -- and finishes.
     // A handle is consumed by exactly one end() or abandon().

@@ -30,7 +30,7 @@ template <int MODE> __global__ __launch_bounds__(64) void bench(u32 *buf, int it
         if (MODE == 3) PW::inv12(PW::R(1), PW::R(0), PW::R(2), PW::R(3));
         if (MODE == 4) PW::sqr12(PW::R(0), PW::R(0), st);
         if (MODE == 5) PW::cyc_sqr12(PW::R(0), PW::R(0), ct);
-        if (MODE == 6) PW::template prepare<false>(qx, qy, buf + 8192, px, py);
+        if (MODE == 6) PW::template prepare<false>(qx, qy, buf + 8192, px, py, px);
         if (MODE == 7) PW::conj12(PW::R(0));
         if (MODE == 8) qacc = PW::mul2(qacc, qx);
         if (MODE == 9) qacc = PW::mul2_xi(qacc);
