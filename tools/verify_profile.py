@@ -1,11 +1,12 @@
-"""dev tool: single verifications of a PrivateTransfer-shape proof (for rocprofv3 --kernel-trace; prints ms per verification)."""
+"""dev tool: single verifications of a PrivateTransfer-shape proof (for rocprofv3 --kernel-trace; prints ms per verification).
+CURVE=1: BLS12-381, a small circuit with the same number of public inputs (the verifier's work depends on nothing else)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from manta_rs_amd import api, synth, keygen
 api.init(0)
-curve = 0
+curve = int(os.environ.get("CURVE", "0"))
 p = synth.FR_MODULUS[curve]
-c = synth.make_shape(curve, "private_transfer")
+c = synth.make_shape(curve, "private_transfer") if curve == 0 else synth.make_circuit(curve, 4096, 3000, 27, seed=5)
 rng = synth.XorShift(5)
 pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
 ctx = api.ProvingContext(curve, pk)
