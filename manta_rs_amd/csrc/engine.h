@@ -128,6 +128,10 @@ struct BaseSet {
     // merge levels -- leaves n_sets results. n_sets = 1: an ordinary set.
     u32 n_sets = 1;
     size_t set_len = 0;
+    // stored points of query q = [set_first[q], set_first[q + 1]) (infinity entries dropped, order kept): with full tables the
+    // digit kernel runs once per query, in stream order, and the pairs come out grouped by query -- no sort (msm_launch)
+    static constexpr u32 MAX_SETS = 4;
+    u32 set_first[MAX_SETS + 1] = {};
     size_t bytes = 0;
 };
 
@@ -157,6 +161,11 @@ struct MsmWorkspace {
     bool timed = false;
     bool in_graph_slot = false; // owned by a proof slot whose launches are captured into hipGraphs (prover.cpp)
     bool capturing = false; // msm_launch is being stream-captured: enqueue kernels and copies only, no event records
+    // notify: after the staged result a 4-byte token is copied to *h_flag (pinned), so that a host that zeroed it before the
+    // launch can see THIS chain end without a stream or event wait (a chain inside a captured multi-branch graph has neither)
+    bool notify = false;
+    u32 *h_flag = nullptr; // pinned, owned
+    u32 *d_token = nullptr; // device word holding 1, owned
     float accumulate_ms = 0.f;
     // host-side description of what was staged (filled by msm_launch, consumed by msm_finish)
     MsmPlan plan;

@@ -26,6 +26,7 @@
 #include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -70,9 +71,9 @@ __global__ __launch_bounds__(1024) void digits_kernel(const u32 *__restrict__ sc
                                                      u32 *__restrict__ keys, u32 *__restrict__ vals,
                                                      const u32 *__restrict__ map, u32 n_scalars,
                                                      size_t scalar_stride, u32 seg_keys, u32 *__restrict__ count,
-                                                     u32 n_sets = 1, u32 set_len = 0) {
+                                                     u32 n_sets = 1, u32 set_len = 0, u32 i_first = 0) {
     MG_PRIO_HIGH();
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 i = i_first + blockIdx.x * blockDim.x + threadIdx.x; // (i_first: one launch per query, lanes [i_first, n))
     // blockIdx.y = scalar vector of a batch: its own scalars, its own range of bucket keys; the bases (and so
     // the values) are shared
     scalars += (size_t)blockIdx.y * scalar_stride;
@@ -1245,6 +1246,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         bs->n_orig = n_in;
         bs->n_sets = n_sets;
         bs->set_len = n_in / n_sets;
+        if (n_sets > 1 && n_sets <= BaseSet::MAX_SETS) { // where every query starts among the stored points
+            for (u32 q = 0; q <= n_sets; ++q) {
+                const size_t first = (size_t)q * bs->set_len; // original index
+                bs->set_first[q] = map.empty() ? (u32)(first < n ? first : n)
+                                               : (u32)(std::lower_bound(map.begin(), map.end(), (u32)first) - map.begin());
+            }
+            bs->set_first[n_sets] = (u32)n;
+        }
         if (!map.empty()) {
             if (hipMalloc((void **)&bs->d_map, map.size() * 4) != hipSuccess ||
                 hipMemcpy(bs->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -1596,13 +1605,33 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); // measured: 256 beats 512 and 1024 on the same box
         }();
         const u32 dthreads = d_count ? dthreads_sparse : 256u; // compacting path: fewer, larger workgroups = fewer atomics on the counter
+        // Concatenated queries on full tables, ONE scalar vector (the a | b_g1 | l MSM of a single proof): every pair's key is its
+        // query. One digit launch per query, in stream order, appends query 0's pairs, then query 1's, ... -- the pairs ARE sorted
+        // and the radix pass over them (histogram, two scans, scatter: 135-150 us on the chain that ends a W or dense proof) is
+        // not run. MANTA_Z3_SORT=1 restores the single launch + sort (A/B).
+        static const bool z3_sort = [] {
+            const char *e = getenv("MANTA_Z3_SORT");
+            return e && atoi(e) != 0;
+        }();
+        const bool per_query = pl.full && nsets > 1 && nsets <= BaseSet::MAX_SETS && batch == 1 && d_count && !z3_sort &&
+                               bs->set_first[nsets] == (u32)bs->n;
+        if (per_query) {
+            for (u32 q = 0; q < nsets; ++q) {
+                const u32 lo = bs->set_first[q], hi = bs->set_first[q + 1];
+                if (hi <= lo) continue;
+                hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(hi - lo, dthreads), 1), dim3(dthreads), 0, s, d_scalars, hi, pl.c, pl.W,
+                                   pl.B, 2, (u32)bs->n, scalar_mode, invalid, ws->keys_in.as<u32>(), ws->vals_in.as<u32>(),
+                                   (const u32 *)bs->d_map, (u32)n_scalars, scalar_stride_words, seg_keys, d_count, nsets,
+                                   (u32)bs->set_len, lo);
+            }
+        } else
         hipLaunchKernelGGL((digits_kernel<FrC>), dim3(cdiv(n, dthreads), batch), dim3(dthreads), 0, s, d_scalars, (u32)n, pl.c, pl.W,
                            pl.B, pl.full ? 2 : (pl.precomp ? 1 : 0), (u32)bs->n, scalar_mode, invalid,
                            ws->keys_in.as<u32>(), ws->vals_in.as<u32>(), (const u32 *)bs->d_map, (u32)n_scalars,
                            scalar_stride_words, seg_keys, d_count, nsets, (u32)bs->set_len);
         batch *= nsets; // from here on every (vector, query) pair is a vector of its own: its keys, its window sums, its result
-        // one key in all (a single MSM on full tables, pairs compacted): any order is sorted
-        const bool no_sort = nb == 1 && d_count;
+        // one key in all (a single MSM on full tables, pairs compacted): any order is sorted; one digit launch per query: sorted
+        const bool no_sort = (nb == 1 || per_query) && d_count;
         const u32 *skeys = no_sort ? ws->keys_in.as<u32>() : ws->keys_out.as<u32>();
         const u32 *svals = no_sort ? ws->vals_in.as<u32>() : ws->vals_out.as<u32>();
         if (!no_sort && (rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
@@ -1846,6 +1875,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         ws->n_extra = n_extra;
         for (u32 e = 0; e < n_extra; ++e) ws->extra_shift[e] = extra_shift[e];
         ws->extra_off_pts = stage_pts;
+        if (ws->notify) { // (the staged copies above are earlier commands of the same stream)
+            if (!ws->h_flag) {
+                MG_HIP(hipHostMalloc((void **)&ws->h_flag, 64, hipHostMallocDefault));
+                *ws->h_flag = 0;
+            }
+            if (!ws->d_token) {
+                const u32 one = 1;
+                MG_HIP(hipMalloc((void **)&ws->d_token, 64));
+                MG_HIP(hipMemcpy(ws->d_token, &one, 4, hipMemcpyHostToDevice));
+            }
+            MG_HIP(hipMemcpyAsync(ws->h_flag, ws->d_token, 4, hipMemcpyDeviceToHost, s));
+        }
         if (!ws->capturing) MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());
         ws->plan = pl;

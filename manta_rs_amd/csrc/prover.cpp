@@ -141,6 +141,7 @@ struct ProveWs {
             if (mw[i]) {
                 mw[i]->run_on = nullptr;
                 mw[i]->in_graph_slot = false;
+                mw[i]->notify = false;
                 me[i]->ws_release(mw[i]);
             }
         z.release();
@@ -681,6 +682,14 @@ class ProverImpl : public Prover {
             }
             w->mw[i]->in_graph_slot = graphs_enabled();
         }
+        // z3 slots: the combined a | b_g1 | l MSM announces its end through a pinned flag (MsmWorkspace::notify), so that the host
+        // can fold its three results into s A + r B1 -- the one long piece of host work of a proof, ~0.1 ms -- while the h chain is
+        // still running (finish_pass_body). MANTA_Z3_EARLY=0: wait for all of part A first, as before (A/B).
+        static const bool z3_early = [] {
+            const char *e = std::getenv("MANTA_Z3_EARLY");
+            return !(e && std::atoi(e) == 0);
+        }();
+        w->mw[0]->notify = z3 && z3_early;
         // Three streams per proof, not six: the G2 MSM is the critical path (~3x a G1 MSM), so the three
         // z-MSMs over G1 run back to back beside it and the h MSM follows the witness map on the main stream.
         // Fewer streams = fewer hardware queues per proof in flight (the runtime multiplexes streams onto
@@ -1214,6 +1223,7 @@ class ProverImpl : public Prover {
         const uint64_t *r = nullptr, *s = nullptr;
         uint8_t *out = nullptr;
         float enqueue_ms = 0.f;
+        bool z3_folded = false; // the combined MSM's results were taken before the rest of part A (finish_pass_body)
     };
 
     static bool is_page_locked(const void *p) {
@@ -1287,6 +1297,10 @@ class ProverImpl : public Prover {
             w->timed = ok;
         }
         if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2 && !w->timed) build_graphs(w);
+        if (w->mw[0]->notify && w->mw[0]->h_flag) { // the combined MSM's end-of-chain token of THIS pass (z3 slots)
+            *(volatile u32 *)w->mw[0]->h_flag = 0;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+        }
         if (w->timed) {
             rc = enqueue_proof(w, z_src, false);
         } else if (w->graphs_ready) {
@@ -1319,6 +1333,7 @@ class ProverImpl : public Prover {
         for (int i = 0; i < 5; ++i) {
             if (in_part_a(i) != part_a) continue;
             if (w->z3 && (i == 1 || i == 3)) continue; // part of the combined MSM on mw[0]
+            if (w->z3 && i == 0 && p.z3_folded) continue; // finish_pass_body took its results when its chain ended
             if (w->z3 && i == 0 && w->mw[0]->pending) { // three results per proof: a, b_g1, l
                 std::vector<HostPoint> t3((size_t)3 * p.k);
                 int rc2 = w->me[0]->msm_finish(w->mw[0], t3.data(), true);
@@ -1413,6 +1428,33 @@ class ProverImpl : public Prover {
         });
     }
     // res[i * k + q] = MSM i (a, b_g1, b_g2, l, h) of proof q; writes A and C of every proof
+    // `pre` (single proofs on a z3 slot): g_a and s g_a + r g1_b - rs delta were computed by assemble_g1_early while the h chain ran
+    struct EarlyG1 {
+        HostPoint g_a, g_c;
+    };
+    void assemble_g1_early(const HostPoint *res /* k = 1 */, Blind &b, const uint64_t *rq, EarlyG1 *e) const {
+        const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0;
+        e->g_a = res[0];
+        g1_->hp_add(&e->g_a, &a0_alpha_);
+        g1_->hp_add(&e->g_a, &b.t_rd);
+        HostPoint g1_b;
+        g1_->hp_set_inf(&g1_b);
+        if (!r_zero) {
+            g1_b = res[1];
+            g1_->hp_add(&g1_b, &b10_beta_);
+            g1_->hp_add(&g1_b, &b.t_sd);
+        }
+        g1_->hp_mul2(&e->g_a, b.sc4, &g1_b, b.rc4, &e->g_c);
+        g1_->hp_neg(&b.t_rsd);
+        g1_->hp_add(&e->g_c, &b.t_rsd);
+        g1_->hp_add(&e->g_c, &res[3]);
+    }
+    void assemble_g1_late(const HostPoint *res /* k = 1 */, EarlyG1 *e, uint8_t *out) const {
+        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
+        g1_->hp_add(&e->g_c, &res[4]);
+        g1_->hp_serialize(&e->g_a, out, true);
+        g1_->hp_serialize(&e->g_c, out + b1 + b2, true);
+    }
     void assemble_g1(u32 k, const HostPoint *res, Blind *bl, const uint64_t *r, uint8_t *proofs_out) const {
         const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
         for_each_proof(k, [&](u32 q) {
@@ -1727,6 +1769,7 @@ class ProverImpl : public Prover {
             throw;
         }
     }
+    bool peer_passes_active(const std::vector<Pass> *peer_passes) const { return peer_passes && !peers_.empty(); }
     int finish_pass_body(Pass &p, std::vector<Pass> *peer_passes) {
         ProveWs *w = p.w;
         int rc = MG_OK;
@@ -1755,8 +1798,42 @@ class ProverImpl : public Prover {
         };
         // ---- part A is back: the G1 side of the assembly runs while the G2 MSM finishes
         const auto t_wait0 = std::chrono::steady_clock::now();
+        // A single proof on a z3 slot: the combined a | b_g1 | l MSM ends before the h chain does (witness map, then the one dense MSM
+        // of a proof). Its end-of-chain token lands in pinned memory; the host folds the three results and runs s A + r B1 (0.1 ms, the
+        // long piece of host work) while the GPU finishes h. The order of additions into C differs from assemble_g1's; the point is
+        // the same and so are its bytes.
+        EarlyG1 early;
+        bool have_early = false;
+        if (!rc && k == 1 && w->z3 && w->mw[0]->notify && w->mw[0]->h_flag && w->mw[0]->pending && !peer_passes_active(peer_passes)) {
+            volatile u32 *flag = w->mw[0]->h_flag;
+            bool seen = false;
+            for (u32 spin = 0;; ++spin) {
+                if (*flag) {
+                    seen = true;
+                    break;
+                }
+                // (a failed launch or a device fault never writes the token: every few microseconds ask the stream itself)
+                if ((spin & 1023u) == 1023u && hipStreamQuery(w->stream) != hipErrorNotReady) break;
+                __builtin_ia32_pause();
+            }
+            if (!seen && *flag) seen = true; // (the stream reported complete: the token was written before that)
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            if (seen) {
+                HostPoint t3[3];
+                const int rc2 = w->me[0]->msm_finish(w->mw[0], t3, true);
+                if (!rc2) {
+                    res[0] = t3[0], res[1] = t3[1], res[3] = t3[2];
+                    p.z3_folded = true;
+                    assemble_g1_early(res.data(), bl[0], r, &early);
+                    have_early = true;
+                } else {
+                    rc = rc2;
+                }
+            }
+        }
         collect(w->stream, true); // every G1 MSM stream has been joined into it
-        if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
+        if (!rc && have_early) assemble_g1_late(res.data(), &early, p.out);
+        else if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
         // ---- part B: the G2 element
         collect(msm_stream(w, 2), false);
         float phases[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};

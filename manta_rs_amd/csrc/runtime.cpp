@@ -113,6 +113,8 @@ MsmWorkspace::~MsmWorkspace() {
                      &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch, &clk};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
+    if (h_flag) hipHostFree(h_flag);
+    if (d_token) hipFree(d_token);
     if (done) hipEventDestroy(done);
     if (t0) hipEventDestroy(t0);
     if (t1) hipEventDestroy(t1);
