@@ -1432,7 +1432,7 @@ class ProverImpl : public Prover {
     struct EarlyG1 {
         HostPoint g_a, g_c;
     };
-    void assemble_g1_early(const HostPoint *res /* k = 1 */, Blind &b, const uint64_t *rq, EarlyG1 *e) const {
+    void assemble_g1_early(const HostPoint *res /* k = 1 */, Blind &b, const uint64_t *rq, EarlyG1 *e, uint8_t *out) const {
         const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0;
         e->g_a = res[0];
         g1_->hp_add(&e->g_a, &a0_alpha_);
@@ -1448,11 +1448,11 @@ class ProverImpl : public Prover {
         g1_->hp_neg(&b.t_rsd);
         g1_->hp_add(&e->g_c, &b.t_rsd);
         g1_->hp_add(&e->g_c, &res[3]);
+        g1_->hp_serialize(&e->g_a, out, true); // A is final (its inversion too runs beside the h chain)
     }
     void assemble_g1_late(const HostPoint *res /* k = 1 */, EarlyG1 *e, uint8_t *out) const {
         const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
         g1_->hp_add(&e->g_c, &res[4]);
-        g1_->hp_serialize(&e->g_a, out, true);
         g1_->hp_serialize(&e->g_c, out + b1 + b2, true);
     }
     void assemble_g1(u32 k, const HostPoint *res, Blind *bl, const uint64_t *r, uint8_t *proofs_out) const {
@@ -1803,7 +1803,7 @@ class ProverImpl : public Prover {
         // long piece of host work) while the GPU finishes h. The order of additions into C differs from assemble_g1's; the point is
         // the same and so are its bytes.
         EarlyG1 early;
-        bool have_early = false;
+        bool have_early = false, g2_early = false;
         if (!rc && k == 1 && w->z3 && w->mw[0]->notify && w->mw[0]->h_flag && w->mw[0]->pending && !peer_passes_active(peer_passes)) {
             volatile u32 *flag = w->mw[0]->h_flag;
             bool seen = false;
@@ -1824,8 +1824,17 @@ class ProverImpl : public Prover {
                 if (!rc2) {
                     res[0] = t3[0], res[1] = t3[1], res[3] = t3[2];
                     p.z3_folded = true;
-                    assemble_g1_early(res.data(), bl[0], r, &early);
+                    assemble_g1_early(res.data(), bl[0], r, &early, p.out);
                     have_early = true;
+                    // the G2 chain (a linear graph on a stream of its own) has usually ended by now: its element too is
+                    // finished before the h chain is waited for
+                    if (hipStreamQuery(msm_stream(w, 2)) == hipSuccess) {
+                        collect(msm_stream(w, 2), false);
+                        if (!rc) assemble_g2(k, res.data(), bl.data(), p.out);
+                        g2_early = true;
+                    } else {
+                        (void)hipGetLastError(); // (hipErrorNotReady is not an error here)
+                    }
                 } else {
                     rc = rc2;
                 }
@@ -1835,7 +1844,7 @@ class ProverImpl : public Prover {
         if (!rc && have_early) assemble_g1_late(res.data(), &early, p.out);
         else if (!rc) assemble_g1(k, res.data(), bl.data(), r, p.out);
         // ---- part B: the G2 element
-        collect(msm_stream(w, 2), false);
+        if (!g2_early) collect(msm_stream(w, 2), false);
         float phases[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         const bool timed = w->timed && !rc;
         if (timed) { // every event has completed: both parts were synchronised above
@@ -1857,7 +1866,7 @@ class ProverImpl : public Prover {
                 pg.w = nullptr;
             }
         if (rc) return rc;
-        assemble_g2(k, res.data(), bl.data(), p.out);
+        if (!g2_early) assemble_g2(k, res.data(), bl.data(), p.out);
         {
             const float hv[3] = {p.enqueue_ms, wait_ms, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_host).count()};
             set_last_pass_host_ms(hv);
