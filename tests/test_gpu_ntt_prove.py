@@ -130,6 +130,49 @@ def test_single_proofs_on_full_and_on_bucket_tables(gpu):
     assert sizes[""][0] == sizes["0"][0]
 
 
+_Z3_SCRIPT = '''
+import os, sys
+sys.path.insert(0, r"{root}"); sys.path.insert(0, os.path.join(r"{root}", "tests"))
+import helpers as H
+from manta_rs_amd import api as gpu, synth, keygen
+gpu.init(0)
+c = synth.make_shape(0, "to_public", profile="W")
+pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+ctx = gpu.ProvingContext(0, pk)
+ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+rs = H.rand_fr_mont(0, 4, seed=98)
+rs[2][:] = 0  # r = 0: b_g1 is not used
+for i in range(5):  # eager, eager, capture, replay, replay
+    print("PROOF", gpu.Groth16.prove_with_randomness(ctx, c.z, rs[2 * (i & 1)], rs[2 * (i & 1) + 1]).hex())
+'''
+
+
+def test_single_proof_host_fold_variants(gpu):
+    """Single proofs run the a | b_g1 | l queries as ONE MSM over a concatenated full table. Round 4: one digit launch per
+    query leaves the pairs grouped by query (no sort), and the MSM's end-of-chain token lets the host compute s A + r B1 and
+    finish A and the G2 element while the h chain is still running. MANTA_Z3_SORT=1 / MANTA_Z3_EARLY=0 restore the single
+    launch + radix pass / the wait for all of part A; MANTA_Z3=0 the three separate MSMs. Knobs are read once per process,
+    hence the children: every variant must give the oracle's bytes, eager and replayed, with r != 0 and r = 0."""
+    import os
+    import subprocess
+    import sys
+    from manta_rs_amd import keygen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = synth.make_shape(0, "to_public", profile="W")
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+    rs = H.rand_fr_mont(0, 4, seed=98)
+    rs[2][:] = 0
+    O.set_threads(O.usable_cpus())
+    two = [O.groth16_prove(c, pk, rs[0], rs[1]).hex(), O.groth16_prove(c, pk, rs[2], rs[3]).hex()]
+    want = [two[i & 1] for i in range(5)]
+    for knobs in ({}, {"MANTA_Z3_EARLY": "0"}, {"MANTA_Z3_SORT": "1"}, {"MANTA_Z3_EARLY": "0", "MANTA_Z3_SORT": "1"}, {"MANTA_Z3": "0"}):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_Z3")}
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", _Z3_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        assert [ln.split()[1] for ln in out.stdout.split("\n") if ln.startswith("PROOF")] == want, knobs
+
+
 def test_prove_real_shape_private_transfer(gpu):
     """Shape-exact PrivateTransfer circuit (D=2^16, V=35175, P=27): bit-exact vs the oracle, pairing-verified,
     and -- like manta-pay/src/test/transfer.rs:346-417 -- a fuzzed public input must invalidate the proof."""
