@@ -173,6 +173,51 @@ def test_single_proof_host_fold_variants(gpu):
         assert [ln.split()[1] for ln in out.stdout.split("\n") if ln.startswith("PROOF")] == want, knobs
 
 
+def test_captured_graphs_survive_other_contexts(gpu):
+    """A context's captured graphs (part A forked, the G2 chain linear; passes of 1, 2, 3 and 8 proofs) must keep giving the
+    oracle's bytes while OTHER contexts of the process are created, load a circuit (window tables built on the default stream,
+    GBs allocated), prove eagerly and capture graphs of their own. Round 4 found that a part-A graph captured as ONE linear
+    chain (MANTA_PROVE_STREAMS=1, a measurement knob) gives a wrong C element exactly there -- profiles/r04_z3_helper_thread.txt;
+    the default topology must not. Every element of every proof is compared (A | B | C)."""
+    c = synth.make_circuit(0, 700, 500, 9, seed=11)
+    pk = O.groth16_setup(c, H.toxic(0))
+    ctx = gpu.ProvingContext(0, pk)
+    r1cs = gpu.R1CS.from_circuit(c)
+    ctx.set_r1cs(r1cs)
+    K = 8
+    rs = H.rand_fr_mont(0, 2 * K, seed=5)
+    rs[1][:] = 0  # one member with r = 0
+    truth = [O.groth16_prove(c, pk, rs[q], rs[K + q]) for q in range(K)]
+    zs = np.stack([c.z] * K)
+
+    def check(tag):
+        assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[K]) == truth[0], tag
+        assert gpu.Groth16.prove_with_randomness(ctx, c.z, rs[1], rs[K + 1]) == truth[1], tag
+        for k in (2, 3, K):
+            got = gpu.Groth16.prove_batch(ctx, zs[:k], rs[0:k], rs[K:K + k])
+            for q in range(k):
+                assert got[q] == truth[q], (tag, k, q, [got[q][a:b] == truth[q][a:b] for a, b in ((0, 32), (32, 96), (96, 128))])
+
+    for i in range(4):  # eager, eager, capture + replay, replay -- for every pass size
+        check("run %d" % i)
+    c2 = gpu.ProvingContext(0, pk)
+    check("after a second context was created")
+    c2.set_r1cs(r1cs)
+    check("after its set_r1cs")
+    for i in range(3):
+        assert gpu.Groth16.prove_with_randomness(c2, c.z, rs[0], rs[K]) == truth[0]
+        check("after its proof %d" % (i + 1))
+    c3 = gpu.ProvingContext(0, pk, full_table_bytes=0)
+    c3.set_r1cs(r1cs)
+    check("after a third context without full tables")
+    got = gpu.Groth16.prove_batch(c3, zs[:3], rs[0:3], rs[K:K + 3])
+    assert [got[q] for q in range(3)] == truth[:3]
+    check("after its batched pass")
+    c2.close()
+    check("after the second context was closed")
+    c3.close()
+
+
 def test_prove_real_shape_private_transfer(gpu):
     """Shape-exact PrivateTransfer circuit (D=2^16, V=35175, P=27): bit-exact vs the oracle, pairing-verified,
     and -- like manta-pay/src/test/transfer.rs:346-417 -- a fuzzed public input must invalidate the proof."""
