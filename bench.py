@@ -1035,6 +1035,135 @@ def prove_leg_in_child(args, env):
     return res
 
 
+# ---------------------------------------------------------------------------------------------------- the printed line
+LINE_HARD_CAP = 8192   # the driver keeps ~8 KB of stdout: round 4's 22 KB line came back `parsed: null`
+LINE_TARGET = 4096
+
+
+def _g(o, *path, default=None):
+    """nested lookup that never raises: legs that did not run (quick, N > 1, an error object) give `default`"""
+    for k in path:
+        if not isinstance(o, dict) or k not in o or o[k] is None:
+            return default
+        o = o[k]
+    return o
+
+
+def _drop_none(o):
+    if isinstance(o, dict):
+        out = {k: _drop_none(v) for k, v in o.items() if v is not None}
+        return {k: v for k, v in out.items() if v != {}}
+    return o
+
+
+def _three(leg):
+    """the three numbers of a witness profile: sequential ms, six threads proofs/s, batched proofs/s"""
+    return {"sequential_ms": _g(leg, "sequential", "ms_per_proof"), "six_threads": _g(leg, "six_threads", "proofs_per_s"),
+            "batched": _g(leg, "batched", "proofs_per_s"), "cpu_1_thread": _g(leg, "cpu_baseline", "value"),
+            "cpu_all_cores": _g(leg, "cpu_baseline", "all_cores", "value"),
+            "batched_frac_of_int_mad_bound": _g(leg, "int_mad", "batched_frac_of_bound", default=_g(leg, "roofline", "int_mad", "batched_frac_of_bound"))}
+
+
+def compact_line(full):
+    """The ONE line the driver parses: numbers only, a few short strings, no notes. Everything else (how-strings, histograms,
+    per-phase tables, min / max of the repetitions, the host probe) stays in the detail object, which main() writes to
+    gpurun_out/bench_detail.json and, with --detail, to stderr -- never to stdout."""
+    rl, cb, pr = full.get("roofline") or {}, full.get("cpu_baseline") or {}, full.get("proofs") or {}
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg[k] for k in ("workload", "curve", "log_n", "window_bits", "msms_in_flight", "sharding") if k in cfg}
+    if "latency_mode" in cfg:
+        out["config"]["one_at_a_time_Mscalar_s"] = _g(cfg, "latency_mode", "Mscalar_s")
+    if cfg.get("plain_bases"):
+        out["config"]["plain_bases_Mscalar_s"] = _g(cfg, "plain_bases", "pipelined_Mscalar_s")
+    out["roofline"] = None if not rl else {
+        "bound": rl.get("bound"), "kernel": rl.get("kernel"), "achieved": rl.get("achieved"), "peak": rl.get("peak"), "unit": rl.get("unit"),
+        "frac": rl.get("frac"), "traffic": rl.get("traffic"), "kernel_ms": rl.get("kernel_ms"),
+        "algorithmic_bytes_per_launch": rl.get("algorithmic_bytes_per_launch"),
+        "int_mad": None if not rl.get("int_mad") else {
+            "frac": _g(rl, "int_mad", "frac"), "peak_Tmad_s": _g(rl, "int_mad", "peak_Tmad_s"), "achieved_Tmad_s": _g(rl, "int_mad", "achieved_Tmad_s"),
+            "frac_at_kernel_clock": _g(rl, "int_mad", "frac_at_the_kernels_own_clock")},
+        "kernel_MHz": _g(rl, "clock", "accumulate_kernel_MHz_latency_mode")}
+    out["cpu_baseline"] = None if not cb else {
+        "value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+        "sample": "the same 2^%s bases/scalars, one whole MSM, arkworks-0.3 Pippenger restatement (oracle/)" % _g(cfg, "log_n", default="?"),
+        "all_cores": {"value": _g(cb, "all_cores", "value"), "cores": _g(cb, "all_cores", "cores")}, "cpu_model": cb.get("cpu_model")}
+    if pr:
+        p = {"metric": pr.get("metric"), "value": pr.get("value"), "unit": "proofs/s", "profile": pr.get("witness_profile"),
+             "sequential_ms": _g(pr, "sequential", "ms_per_proof"), "two_threads": _g(pr, "two_threads", "proofs_per_s"),
+             "six_threads": _g(pr, "six_threads", "proofs_per_s"), "batched": _g(pr, "batched", "proofs_per_s"),
+             "per_gpu": pr.get("per_gpu_proofs_per_s"),
+             "int_mad": {"bound_proofs_per_s": _g(pr, "roofline", "int_mad", "bound_proofs_per_s"),
+                         "batched_frac_of_bound": _g(pr, "roofline", "int_mad", "batched_frac_of_bound")},
+             "cpu_baseline": None if not pr.get("cpu_baseline") else {
+                 "value": _g(pr, "cpu_baseline", "value"), "unit": "proofs/s", "cores": 1, "kind": _g(pr, "cpu_baseline", "kind"),
+                 "all_cores": {"value": _g(pr, "cpu_baseline", "all_cores", "value"), "cores": _g(pr, "cpu_baseline", "all_cores", "cores")}},
+             "key_tables_hbm_bytes": (_g(pr, "key_tables_hbm_bytes", "bucket_tables", default=0) + _g(pr, "key_tables_hbm_bytes", "full_tables", default=0)) or None}
+        wp = pr.get("witness_profiles")
+        if wp:
+            p["witness_profiles"] = {k: (_three(v) if "error" not in v else {"error": str(v["error"])[-120:]}) for k, v in wp.items() if isinstance(v, dict)}
+        if pr.get("shapes"):
+            p["shapes_batched"] = {k: _g(v, "batched", "proofs_per_s", default="error") for k, v in pr["shapes"].items()}
+        out["proofs"] = p
+        if pr.get("verify"):
+            out["verify"] = {"single_ms": _g(pr, "verify", "single_ms"), "batch": _g(pr, "verify", "batch"),
+                             "batch_per_s": _g(pr, "verify", "batch_proofs_per_s")}
+    if full.get("ntt"):
+        out["ntt"] = {"log_n": _g(full, "ntt", "log_n"), "ms": _g(full, "ntt", "fft", "device_ms"), "frac": _g(full, "ntt", "fft", "frac_of_hbm_peak"),
+                      "ifft_ms": _g(full, "ntt", "ifft", "device_ms"), "coset_fft_ms": _g(full, "ntt", "coset_fft", "device_ms"),
+                      "coset_ifft_ms": _g(full, "ntt", "coset_ifft", "device_ms")}
+    if full.get("config2"):
+        out["config2"] = {"ms": _g(full, "config2", "prove_ms"), "profile": _g(full, "config2", "witness_profile"),
+                          "cpu_all_cores_s": _g(full, "config2", "cpu_all_cores_s"), "error": _g(full, "config2", "error")}
+    if full.get("hbm_reference"):
+        out["hbm_copy_TBps"] = _g(full, "hbm_reference", "d2d_copy_TBps")
+    ss = full.get("strong_scaling")
+    if ss:
+        out["strong_scaling"] = {k: {"ms_per_msm": _g(v, "ms_per_msm_pipelined"), "Mscalar_s": _g(v, "Mscalar_s_pipelined")} for k, v in ss.items()
+                                 if isinstance(v, dict)}
+    sp = full.get("sharded_proof")
+    if sp:
+        out["sharded_proof"] = {"sequential_ms": _g(sp, "sequential", "ms_per_proof"), "batched": _g(sp, "batched", "proofs_per_s"),
+                                "task_parallel_ms": _g(sp, "task_parallel", "sequential", "ms_per_proof"), "error": _g(sp, "error")}
+    if full.get("errors"):
+        out["errors"] = {k: str(v)[-160:] for k, v in full["errors"].items()}
+    out = _drop_none(out)
+    for k in ("vs_baseline",):  # keys of the contract stay even when null
+        out.setdefault(k, None)
+    out["detail"] = full.get("_detail_path")
+    s = json.dumps(out, separators=(",", ":"))
+    if len(s) >= LINE_HARD_CAP:  # cannot happen with the fields above; if it ever does, shed the optional blocks rather than the headline
+        for k in ("strong_scaling", "sharded_proof", "hbm_copy_TBps", "verify", "ntt", "config2", "errors", "proofs"):
+            out.pop(k, None)
+            s = json.dumps(out, separators=(",", ":"))
+            if len(s) < LINE_HARD_CAP:
+                break
+    return s
+
+
+def emit(full, args):
+    """rank 0: detail object -> file (and stderr on --detail), compact line -> the LAST line of stdout"""
+    full = dict(full)
+    path = None
+    blob = json.dumps(full, indent=1, default=str)
+    for d in (os.path.join(ROOT, "gpurun_out"), "/tmp"):
+        try:
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, "bench_detail_n%d.json" % full.get("n_gpus", 1))
+            with open(path, "w") as f:
+                f.write(blob)
+            break
+        except OSError:
+            path = None
+    full["_detail_path"] = os.path.relpath(path, ROOT) if path and path.startswith(ROOT) else path
+    if getattr(args, "detail", False):
+        sys.stderr.write("#detail " + json.dumps(full, default=str) + "\n")
+        sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1048,6 +1177,7 @@ def main():
     ap.add_argument("--shape", default="private_transfer", choices=["to_private", "to_public", "private_transfer"])
     ap.add_argument("--profile", default="W", choices=["sparse", "W", "dense"],
                     help="witness profile of the proofs legs (manta_rs_amd/synth.py); the headline is W")
+    ap.add_argument("--detail", action="store_true", help="also write the full detail object to stderr (it always goes to gpurun_out/bench_detail_n<N>.json)")
     ap.add_argument("--lite", action="store_true", help=argparse.SUPPRESS)          # internal: sequential / six threads / batched only
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)         # internal: print the proofs object only
     ap.add_argument("--batched-only", action="store_true", help=argparse.SUPPRESS)  # internal: skip the single-proof legs
@@ -1068,29 +1198,42 @@ def main():
                     "warmup": args.warmup, "ms_per_step": res["batched"]["ms_per_proof"], "higher_is_better": True, "scaling": "weak",
                     "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": res["workload"]},
                     "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"), "proofs": res}
-            print(json.dumps(line), flush=True)
+            emit(line, args)
         env.close()
         return
     # The proofs half runs in a CHILD PROCESS of its own (one per rank, same GPU, before this process touches the device):
     # both legs depend on how the HIP runtime maps their streams onto its 4 hardware queues, and whichever leg creates
     # its streams second in a shared process loses -- measured on MI355X: sequential proof 1.38 ms instead of 1.05 ms after
     # the MSM leg, pipelined MSM 320 instead of 345 Mscalar/s after the proofs leg. A deployment runs one or the other.
-    proofs = None
+    proofs, errors = None, {}
+
+    def leg(name, f, *a):
+        """an optional leg must never cost the run its headline: its failure is recorded under `errors` (all ranks take the same
+        branch only for failures that are deterministic; a rank-local failure in a collective leg still ends the run)"""
+        try:
+            return f(*a)
+        except Exception as e:  # noqa: BLE001
+            if env.world > 1:
+                raise
+            errors[name] = "%s: %s" % (type(e).__name__, e)
+            return None
     if args.workload == "both" and not args.quick:
-        proofs = prove_leg_in_child(args, env)
+        proofs = leg("proofs", prove_leg_in_child, args, env)
     line, inst = msm_bench(args, env)
     if args.workload == "both" and not args.quick and env.world == 1:
         inst.bases.close()  # the 2 GiB window tables: the legs below allocate their own
-        line["ntt"] = ntt_bench(env)
-        line["config2"] = config2_bench(env)
+        line["ntt"] = leg("ntt", ntt_bench, env)
+        line["config2"] = leg("config2", config2_bench, env)
     if args.workload == "both" and not args.quick:
         if env.world > 1:
             line["strong_scaling"] = strong_scaling(args, env)
             line["sharded_proof"] = sharded_proof_bench(args, env)
         line["proofs"] = proofs
     finish_cpu_baselines(line)
+    if errors:
+        line["errors"] = errors
     if env.rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line, args)
     env.close()
 
 

@@ -259,3 +259,67 @@ def test_rust_sys_crate_declares_exactly_the_header():
         cnames = re.findall(r"\*?(\w+)\s*[;,]", re.sub(r"/\*.*?\*/", "", cbody, flags=re.S))
         rnames = re.findall(r"pub (\w+):", body)
         assert rnames == cnames, (struct, rnames, cnames)
+
+
+def _canned_bench_result(n_gpus=1):
+    """a full detail object of a real run (round 4's 22 KB line, kept as a fixture) -- with N > 1 the legs of that path bolted on"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    if n_gpus > 1:
+        d["n_gpus"] = n_gpus
+        d["strong_scaling"] = {"n_2^20": {"n_total": 1 << 20, "n_per_gpu": (1 << 20) // n_gpus, "window_bits": 17, "ms_per_msm_latency_mode": 1.9,
+                                          "ms_per_msm_pipelined": 1.5, "Mscalar_s_pipelined": 700.0},
+                               "n_35174": {"n_total": 35174, "n_per_gpu": 35174 // n_gpus, "window_bits": 8, "ms_per_msm_latency_mode": 0.4,
+                                           "ms_per_msm_pipelined": 0.2, "Mscalar_s_pipelined": 170.0}}
+        d["sharded_proof"] = {"workload": "x" * 300, "exchange": "y" * 300, "sequential": {"ms_per_proof": 1.2, "proofs_per_s": 830.0},
+                              "batched": {"proofs_per_pass": 32, "passes_in_flight": 3, "proofs_per_s": 2900.0, "ms_per_proof": 0.34},
+                              "task_parallel": {"placement": "z" * 200, "sequential": {"ms_per_proof": 1.3, "proofs_per_s": 770.0}}}
+        d["proofs"]["per_gpu_proofs_per_s"] = [3300.0] * n_gpus
+        for k in ("ntt", "config2", "hbm_reference"):
+            d.pop(k)
+    return d
+
+
+@pytest.mark.parametrize("n_gpus", [1, 2, 8])
+def test_bench_line_is_small_enough_for_the_driver(n_gpus):
+    """the driver keeps ~8 KB of stdout; round 4's 22 KB line came back `parsed: null`. The printed line is
+    built by bench.compact_line from the detail object: < 8 KB (target 4 KB), valid JSON, with the contract's keys, `roofline`
+    and `cpu_baseline` inside."""
+    import json
+    import bench
+    full = _canned_bench_result(n_gpus)
+    assert len(json.dumps(full)) > 20000  # the object that broke the driver
+    s = bench.compact_line(full)
+    assert "\n" not in s and len(s) < bench.LINE_TARGET < bench.LINE_HARD_CAP == 8192
+    d = json.loads(s)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == full["value"] and d["ms_per_step"] == full["ms_per_step"] and d["n_gpus"] == n_gpus
+    assert d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["traffic"] > r["algorithmic_bytes_per_launch"] and 0 < r["int_mad"]["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["all_cores"]["cores"] >= 1 and c["sample"]
+    p = d["proofs"]
+    assert p["value"] == p["batched"] and set(p["witness_profiles"]) == {"sparse", "W", "dense"}
+    assert all(v["batched"] > 0 for v in p["witness_profiles"].values())
+    if n_gpus > 1:
+        assert d["sharded_proof"]["batched"] and d["strong_scaling"]["n_2^20"]["Mscalar_s"]
+    else:
+        assert d["ntt"]["ms"] and d["config2"]["ms"] and d["verify"]["batch_per_s"]
+
+
+def test_bench_line_survives_missing_legs():
+    """--quick / a failed optional leg: the headline still prints, errors are named, nothing raises"""
+    import json
+    import bench
+    full = _canned_bench_result(1)
+    for k in ("proofs", "ntt", "config2", "hbm_reference"):
+        full[k] = None
+    full["errors"] = {"proofs": "RuntimeError: " + "x" * 5000}
+    full["roofline"]["int_mad"] = None
+    full["cpu_baseline"] = None
+    d = json.loads(bench.compact_line(full))
+    assert d["value"] == full["value"] and "proofs" not in d and len(d["errors"]["proofs"]) <= 160 and d["roofline"]["frac"]
