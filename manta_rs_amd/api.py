@@ -565,6 +565,9 @@ class ProvingContext:
         h = _vp()
         if task_mask is not None and int(task_mask) == 0:  # a rank beyond the fifth owns no MSM: the struct reads 0 as "all five"
             _chk(LIB.mg_ctx_create_task(curve, ctypes.byref(v), ctypes.c_uint(0), ctypes.byref(h)), "mg_ctx_create_task")
+        elif shard is not None and int(shard[1]) == 1 and devices is None and task_mask is None and full_table_bytes is None:
+            # a world of one driven through the partials interface: the entry point that says so (no combined a | b_g1 | l table)
+            _chk(LIB.mg_ctx_create_shard(curve, ctypes.byref(v), 0, 1, ctypes.byref(h)), "mg_ctx_create_shard")
         else:
             o, keep = _ctx_opts(devices, shard, task_mask, full_table_bytes, exchange)
             _chk(LIB.mg_ctx_create_ex(curve, ctypes.byref(v), ctypes.byref(o), ctypes.byref(h)), "mg_ctx_create_ex")

@@ -13,7 +13,20 @@
 // An unsatisfied witness is not an error (ark-groth16 only debug_asserts it): a non-verifying proof
 // comes back, exactly like the reference in release builds.
 #include "prover.h"
-#include <rccl/rccl.h> // types and prototypes only: librccl.so is loaded on demand (Rccl::get), never linked
+// The six RCCL entry points this file calls, declared here from NCCL's stable C ABI (ncclResult_t 0 = success, ncclUint64 = 5):
+// librccl.so is loaded on demand (Rccl::get) and never linked, and its header is not a build dependency of a single-GPU host
+// (advisor r4). Only decltype() of the prototypes is used: nothing below references the symbols themselves.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint64 = 5 } ncclDataType_t;
+ncclResult_t ncclCommInitAll(ncclComm_t *comms, int ndev, const int *devlist);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+const char *ncclGetErrorString(ncclResult_t result);
+}
 #include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
@@ -43,6 +56,12 @@ FrEngine *get_ntt_engine(int curve) { // one per (device, curve): twiddle and sc
 }
 
 namespace {
+
+#ifdef MG_DIAG
+__global__ void diag_zero_words(u32 *p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+#endif
 
 // RCCL behind the C ABI (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL): the library is dlopen'ed the first time a context asks for
 // it -- a process that already holds one (PyTorch ships its own librccl.so.1) gets THAT copy, two RCCL runtimes in one
@@ -159,11 +178,22 @@ struct ProveWs {
     }
 };
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#endif
+}
+
 static int prove_streams() {
     static const int n = [] {
         const char *e = std::getenv("MANTA_PROVE_STREAMS");
         const int v = e ? std::atoi(e) : 6;
-        return v == 1 || v == 3 || v == 4 || v == 5 ? v : 6;
+#ifdef MG_DIAG
+        if (v == 1) return 1; // part A as ONE linear chain: the topology of the round-4 wrong-C defect, diagnosis builds only
+#endif
+        return v == 3 || v == 4 || v == 5 ? v : 6; // (1 is ignored by the shipped library: DESIGN section 8)
     }();
     return n;
 }
@@ -377,8 +407,11 @@ class ProverImpl : public Prover {
     size_t shard_lo(size_t n) const { return n * shard_ / n_shards_; }
     size_t shard_hi(size_t n) const { return n * (shard_ + 1) / n_shards_; }
 
+    // allow_z3 = false: the context is driven through the partials interface (mg_ctx_create_shard, an RCCL exchange) -- its passes
+    // fold every MSM by its own index, wants_z3() is false for them, and a combined table would only take the separate tables'
+    // HBM and leave a / b_g1 / l on the slower bucket tables (advisor r4)
     int init(int curve, const mg_pk_view *pk, int device, u32 shard = 0, u32 n_shards = 1, int64_t full_table_bytes = -1,
-             int shards_on_this_device = 1) {
+             int shards_on_this_device = 1, bool allow_z3 = true) {
         curve_ = curve;
         dev_ = device;
         shard_ = shard;
@@ -426,7 +459,7 @@ class ProverImpl : public Prover {
             while (D < h_len_) D <<= 1;
             const u64 nq[5] = {zn, zn, zn, ln, (u64)(D * (shard_ + 1) / n_shards_ - D * shard_ / n_shards_)};
             const char *z3e = std::getenv("MANTA_Z3");
-            plan_full_tables(nq, full_budget_, full_c_plan_, n_shards_ == 1 && task_mask_ == 0x1f && !(z3e && std::atoi(z3e) == 0));
+            plan_full_tables(nq, full_budget_, full_c_plan_, allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && !(z3e && std::atoi(z3e) == 0));
         }
         const int f_z1a = -full_c_plan_[0], f_z1b = -full_c_plan_[1], f_z2 = -full_c_plan_[2], f_l = -full_c_plan_[3];
         if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
@@ -460,7 +493,7 @@ class ProverImpl : public Prover {
             return !(e && std::atoi(e) == 0);
         }();
         const int c_z3 = std::min(full_c_plan_[0], std::min(full_c_plan_[1], full_c_plan_[3]));
-        if (z3_on && n_shards_ == 1 && task_mask_ == 0x1f && c_z3 >= 2 && 3 * (u64)zn * ((u64)((g1_->scalar_bits() + c_z3 - 1) / c_z3) << (c_z3 - 1)) < ((u64)1 << 31)) {
+        if (z3_on && allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && c_z3 >= 2 && 3 * (u64)zn * ((u64)((g1_->scalar_bits() + c_z3 - 1) / c_z3) << (c_z3 - 1)) < ((u64)1 << 31)) {
             // a | b_g1 | l as one table over the scalars z[1 .. V): l_query[i] belongs to z[P + i] = scalar P - 1 + i of that range
             std::vector<u32> cat((size_t)3 * zn * w1, 0u);
             std::memcpy(&cat[0], aq, zn * w1 * 4);
@@ -604,7 +637,7 @@ class ProverImpl : public Prover {
             int f_h = 0;
             if (lg <= 17 && !std::getenv("MANTA_PROVE_CH") && full_budget_ > 0) {
                 int64_t left = full_budget_;
-                for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_})
+                for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, z3_bs_full_}) // (z3 replaces a / b_g1 / l: advisor r4)
                     if (b) left -= (int64_t)b->bytes;
                 for (int cc = full_c_plan_[4] ? std::max(full_c_plan_[4], 4) : 0; cc >= 4 && !f_h; --cc)
                     if (full_fits_index(g1_, hi - lo, cc) && (int64_t)full_cost(g1_, hi - lo, cc) <= left) f_h = -cc;
@@ -758,11 +791,24 @@ class ProverImpl : public Prover {
         const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words(); // u32 per work element
         int rc;
         hipStream_t s = w->stream;
+#ifdef MG_DIAG
+        static const int diag_zero = std::getenv("MG_DIAG_ZERO") ? std::atoi(std::getenv("MG_DIAG_ZERO")) : 0;
+        static const int diag_stop = std::getenv("MG_DIAG_WM_STOP") ? std::atoi(std::getenv("MG_DIAG_WM_STOP")) : 0;
+        if (diag_zero) {
+            hipLaunchKernelGGL(diag_zero_words, dim3(1024), dim3(256), 0, s, w->a.as<u32>(), 3 * k * D * ww);
+        } else
+#endif
         MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s)); // rows past m + P are zero (the all-zero words are 0 in the work form too)
         u32 *a = w->a.as<u32>(), *b = a + k * D * ww, *c = b + k * D * ww, *zz = w->z.as<u32>();
         const size_t zs = (size_t)V_ * 8, ds = D * ww;
+#ifdef MG_DIAG
+        if (diag_stop == 1) return MG_OK;
+#endif
         // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j
         if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds))) return rc;
+#ifdef MG_DIAG
+        if (diag_stop == 2) return MG_OK;
+#endif
         // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
         if ((rc = fr_->qap_quotient(a, b, c, log_d_, s, (u32)k))) return rc;
         return MG_OK;
@@ -1752,6 +1798,55 @@ class ProverImpl : public Prover {
         return rc;
     }
 
+#ifdef MG_DIAG
+    // diagnosis builds: word sums of every device buffer of the most recently used one-proof slot (it sits in ws_free_), so that a
+    // pass replayed from graphs can be compared buffer by buffer with the same pass in a good state / launched eagerly
+    int diag_slot_sums(u64 *out, int cap, int eager_next) {
+        hipSetDevice(dev_);
+        hipDeviceSynchronize();
+        ProveWs *w = nullptr;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (auto &kv : ws_free_)
+                for (ProveWs *q : kv.second)
+                    if (q->k == 1 && (!w || q->last_use > w->last_use)) w = q;
+        }
+        if (!w) return -1;
+        if (eager_next == 1) w->drop_graphs(), w->no_graph = true;  // from now on this slot launches eagerly
+        if (eager_next == 2) w->drop_graphs(), w->no_graph = false, w->eager_runs = 2; // re-capture on the next pass
+        int n = 0;
+        auto sum = [&](const void *p, size_t bytes) {
+            u64 acc = 0;
+            if (p && bytes) {
+                std::vector<u32> h(bytes / 4);
+                hipMemcpy(h.data(), p, bytes / 4 * 4, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < h.size(); ++i) acc = acc * 1000003ull + h[i];
+            }
+            if (n < cap) out[n] = acc;
+            ++n;
+        };
+        const size_t D = (size_t)1 << log_d_, ww = (size_t)fr_->work_words() * 4;
+        sum(w->z.p, V_ * 32);                       // 0 z
+        sum(w->a.p, D * ww);                        // 1 h (a)
+        sum((char *)w->a.p + D * ww, D * ww);       // 2 b
+        sum((char *)w->a.p + 2 * D * ww, D * ww);   // 3 c
+        for (int i : {0, 2, 4}) {                   // 4.. : 10 per MSM (a / z3, b_g2, h)
+            MsmWorkspace *m = w->mw[i];
+            sum(m->count.p, m->count.p ? 4 : 0);
+            sum(m->keys_in.p, m->keys_in.cap);
+            sum(m->vals_in.p, m->vals_in.cap);
+            sum(m->keys_out.p, m->keys_out.cap);
+            sum(m->vals_out.p, m->vals_out.cap);
+            sum(m->pkeys[0].p, m->pkeys[0].cap);
+            sum(m->ppts[0].p, m->ppts[0].cap);
+            sum(m->ppts[1].p, m->ppts[1].cap);
+            sum(m->buckets.p, m->buckets.cap);
+            sum(m->redS.p, m->redS.cap);
+        }
+        return n;
+    }
+#endif
+
     int finish_pass(Pass &p, int rc, std::vector<Pass> *peer_passes = nullptr) {
         ProveWs *w = p.w;
         if (!w || rc) {
@@ -1807,6 +1902,9 @@ class ProverImpl : public Prover {
         if (!rc && k == 1 && w->z3 && w->mw[0]->notify && w->mw[0]->h_flag && w->mw[0]->pending && !peer_passes_active(peer_passes)) {
             volatile u32 *flag = w->mw[0]->h_flag;
             bool seen = false;
+            // a short spin (the chain usually ends within tens of microseconds of the host getting here on dense witnesses), then the
+            // core is offered to other runnable threads between polls: six signer threads on one context must not pin six cores for
+            // the length of their GPU chains (advisor r4); a lone caller's sched_yield returns at once
             for (u32 spin = 0;; ++spin) {
                 if (*flag) {
                     seen = true;
@@ -1814,7 +1912,8 @@ class ProverImpl : public Prover {
                 }
                 // (a failed launch or a device fault never writes the token: every few microseconds ask the stream itself)
                 if ((spin & 1023u) == 1023u && hipStreamQuery(w->stream) != hipErrorNotReady) break;
-                __builtin_ia32_pause();
+                cpu_relax();
+                if (spin >= 2048u && (spin & 15u) == 15u) std::this_thread::yield();
             }
             if (!seen && *flag) seen = true; // (the stream reported complete: the token was written before that)
             std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -1906,7 +2005,7 @@ int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Pr
         if (o.exchange != 0) return MG_ERR_ARG; // a collective needs a device list
         ProverImpl *p = new ProverImpl();
         p->task_mask_ = o.task_mask;
-        const int rc = p->init(curve, pk, prev, o.shard, o.n_shards, o.full_table_bytes, 1);
+        const int rc = p->init(curve, pk, prev, o.shard, o.n_shards, o.full_table_bytes, 1, !o.partials_interface);
         if (rc) {
             delete p;
             return rc;
@@ -1923,7 +2022,7 @@ int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Pr
         if (g) p0->peers_.insert(p0->peers_.begin(), p), p->shard_owner_ = p0;
         int same = 0;
         for (int t = 0; t < o.n_devices; ++t) same += o.devices[t] == o.devices[g];
-        rc = p->init(curve, pk, o.devices[g], (u32)g, (u32)o.n_devices, o.full_table_bytes, same);
+        rc = p->init(curve, pk, o.devices[g], (u32)g, (u32)o.n_devices, o.full_table_bytes, same, o.exchange == 0);
     }
     if (!rc && o.exchange == 1) rc = p0->exchange_init();
     hipSetDevice(prev);
@@ -1935,10 +2034,18 @@ int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Pr
     return MG_OK;
 }
 
+#ifdef MG_DIAG
+extern "C" __attribute__((visibility("default"))) int mg_diag_slot_sums(void *ctx, uint64_t *out, int cap, int eager_next) {
+    Prover *p = *(Prover **)ctx; // struct mg_ctx { Prover *p; }
+    return static_cast<ProverImpl *>(p)->diag_slot_sums(out, cap, eager_next);
+}
+#endif
+
 int prover_create(int curve, const mg_pk_view *pk, Prover **out) { return prover_create_ex(curve, pk, ProverOptions(), out); }
 int prover_create_shard(int curve, const mg_pk_view *pk, u32 shard, u32 n_shards, Prover **out) {
     ProverOptions o;
     o.shard = shard, o.n_shards = n_shards;
+    o.partials_interface = true; // one process per GPU: partials_launch / assemble (a world of one included)
     return prover_create_ex(curve, pk, o, out);
 }
 int prover_create_task(int curve, const mg_pk_view *pk, u32 task_mask, Prover **out) {

@@ -79,6 +79,7 @@ struct ProverOptions {
     u32 task_mask = 0x1f;         // task placement: the MSMs (bit 0 a, 1 b_g1, 2 b_g2, 3 l, 4 h) this context computes
     int64_t full_table_bytes = -1; // HBM budget of the full tables; < 0: the default (a tenth of the device's HBM)
     int exchange = 0;             // in-process sharding: 0 = partial points summed through pinned host memory, 1 = RCCL all_gather
+    bool partials_interface = false; // the context will be driven through partials_launch / assemble (mg_ctx_create_shard)
 };
 int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Prover **out);
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);

@@ -19,5 +19,5 @@ for o in ../lib/obj/*.o; do
   done
   objs="$objs $use"
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libmantagpu_$tag.so $objs -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libmantagpu_$tag.so $objs -ldl -Wl,-rpath,/opt/rocm/lib
 echo built manta_rs_amd/lib/libmantagpu_$tag.so
