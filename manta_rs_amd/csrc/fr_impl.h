@@ -425,14 +425,24 @@ struct Csr3 {
     u32 *out[3];
 };
 template <class FrC>
-__global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, u32 P, size_t z_stride, size_t out_stride) {
+__global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, u32 P, size_t z_stride, size_t out_stride,
+                                                    u32 rows_total) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.z;
-    if (i >= m + (t == 0 ? P : 0)) return;
     z += (size_t)blockIdx.y * z_stride; // batch member
     u32 *__restrict__ out = M.out[t] + (size_t)blockIdx.y * out_stride;
     typedef Fp<FrC> F;
     typedef FpR<FrC> R;
+    if (i >= m + (t == 0 ? P : 0)) {
+        // rows past the constraints (and, in A, past the input-consistency rows) up to the domain size are zero -- written here, by the
+        // kernel that owns the vector, not by a memset node in front of it (round 5: a hipMemsetAsync node of a LINEAR captured graph
+        // replays with a wrong fill pattern once other work has gone through the runtime: profiles/r05_linear_graph_defect.txt)
+        if (i < rows_total) {
+#pragma unroll
+            for (int k = 0; k < R::K; ++k) out[(size_t)i * R::K + k] = 0u;
+        }
+        return;
+    }
     F acc = F::zero();
     if (i >= m) {
         acc = F::load(z + (size_t)(i - m) * 8);
@@ -749,11 +759,12 @@ template <class FrC> class FrEngineT : public FrEngine {
     }
     int work_words() const override { return RK; }
     int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m, u64 P,
-              hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0) override {
+              hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0, u64 rows_total = 0) override {
         if (m == 0) return MG_OK;
+        if (rows_total < m + P) rows_total = m + P; // (0: the caller has zeroed the vectors itself)
         Csr3 M{{A.row_ptr, B.row_ptr, C.row_ptr}, {A.col, B.col, C.col}, {A.val, B.val, C.val}, {d_a, d_b, d_c}};
-        hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((m + P + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m, (u32)P,
-                           z_stride, out_stride);
+        hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((rows_total + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m, (u32)P,
+                           z_stride, out_stride, (u32)rows_total);
         MG_HIP(hipGetLastError());
         return MG_OK;
     }

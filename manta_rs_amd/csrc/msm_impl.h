@@ -1156,6 +1156,22 @@ template <class Curve> struct GT<Curve, 2> {
 
 static inline u32 cdiv(size_t a, size_t b) { return (u32)((a + b - 1) / b); }
 
+// The zero-fills of an MSM launch (pair counter, bucket array or direct result, timing words) as ONE kernel of ours instead of
+// hipMemsetAsync calls: inside a stream capture those become memset nodes, and a memset node of a LINEAR captured graph was found
+// to replay with a wrong fill pattern once other work had gone through the runtime (round 5: profiles/r05_linear_graph_defect.txt;
+// the runtime pre-builds the AQL packets of such graphs, its own fill kernel included). No node of the library's graphs is a
+// runtime-generated fill any more; one launch instead of two or three also shortens the chain.
+struct ZeroRanges {
+    u32 *p[3];
+    u32 n[3]; // words
+};
+template <class F> __global__ __launch_bounds__(256) void zero_ranges(ZeroRanges r) {
+    const u32 stride = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        for (u32 i = i0; i < r.n[t]; i += stride) r.p[t][i] = 0u;
+}
+
 template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public GroupEngine {
   public:
     typedef typename GT<Curve, GROUP>::F F;
@@ -1579,7 +1595,27 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (sparse && sort_pairs_takes_device_count(end_bit)) {
             if ((rc = ws->count.reserve(256))) return rc;
             d_count = ws->count.as<u32>();
-            MG_HIP(hipMemsetAsync(d_count, 0, 4, s));
+        }
+        // one key in all (full tables, one scalar vector): the run the last merge level closes IS the result -- it is stored in the
+        // host's format straight away (no bucket array, no reduce launch: one node fewer on the latency chain of a proof's MSM)
+#ifdef MG_NO_DIRECT // A/B builds (tools/build_variant.sh)
+        const bool direct = false;
+#else
+        const bool direct = nb == 1;
+#endif
+        constexpr int XWM0 = XW > XW_IO ? XW : XW_IO;
+        if (direct && ((rc = ws->redA.reserve((size_t)XWM0 * 4)) || (rc = ws->redS.reserve((size_t)XWM0 * 4)))) return rc;
+        ws->timed = kernel_timing() && !ws->capturing;
+        if (ws->timed && (rc = ws->clk.reserve(64))) return rc;
+        { // every zero-fill of this launch, up front (none of the targets is touched by the digit kernel or the sort)
+            ZeroRanges zr{};
+            zr.p[0] = d_count, zr.n[0] = d_count ? 1u : 0u;
+            // direct: no pair at all means the sum is the point at infinity; else the buckets (+ the slot of the invalid key)
+            zr.p[1] = direct ? ws->redS.as<u32>() : ws->buckets.as<u32>();
+            zr.n[1] = direct ? (u32)XWM0 : (u32)((size_t)(nb + 1) * XW);
+            zr.p[2] = ws->timed ? ws->clk.as<u32>() : nullptr, zr.n[2] = ws->timed ? 4u : 0u;
+            const u32 most = zr.n[1] > 4u ? zr.n[1] : 4u;
+            hipLaunchKernelGGL((zero_ranges<F>), dim3(most > 256u * 1024u ? 1024u : cdiv(most, 256)), dim3(256), 0, s, zr);
         }
         // Compacted pairs (witness MSMs: two thirds of the digits are zero): the host sized T for all n W digits, so the pairs
         // that remain fill an arbitrary part of it -- 1.35 rounds of wavefronts for the G2 MSM of a PrivateTransfer proof, i.e. two
@@ -1637,27 +1673,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (!no_sort && (rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
                                          ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
             return rc;
-        // one key in all (full tables, one scalar vector): the run the last merge level closes IS the result -- it is stored in the
-        // host's format straight away (no bucket array, no reduce launch: one node fewer on the latency chain of a proof's MSM)
-#ifdef MG_NO_DIRECT // A/B builds (tools/build_variant.sh)
-        const bool direct = false;
-#else
-        const bool direct = nb == 1;
-#endif
-        constexpr int XWM0 = XW > XW_IO ? XW : XW_IO;
-        if (direct) {
-            if ((rc = ws->redA.reserve((size_t)XWM0 * 4)) || (rc = ws->redS.reserve((size_t)XWM0 * 4))) return rc;
-            MG_HIP(hipMemsetAsync(ws->redS.p, 0, (size_t)XWM0 * 4, s)); // no pair at all: the sum is the point at infinity
-        } else {
-            MG_HIP(hipMemsetAsync(ws->buckets.p, 0, (size_t)(nb + 1) * XW * 4, s));
-        }
         u32 *const std_final = direct ? ws->redS.as<u32>() : (u32 *)nullptr;
-        ws->timed = kernel_timing() && !ws->capturing;
-        if (ws->timed) {
-            if ((rc = ws->clk.reserve(64))) return rc;
-            MG_HIP(hipMemsetAsync(ws->clk.p, 0, 16, s));
-            MG_HIP(hipEventRecord(ws->t0, s));
-        }
+        if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
 #ifdef MG_CALIBRATION
         static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration build only (wrong results)
         if (gather_only)

@@ -57,12 +57,6 @@ FrEngine *get_ntt_engine(int curve) { // one per (device, curve): twiddle and sc
 
 namespace {
 
-#ifdef MG_DIAG
-__global__ void diag_zero_words(u32 *p, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
-}
-#endif
-
 // RCCL behind the C ABI (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL): the library is dlopen'ed the first time a context asks for
 // it -- a process that already holds one (PyTorch ships its own librccl.so.1) gets THAT copy, two RCCL runtimes in one
 // process would each claim the devices -- and only the six entry points below are used. MANTA_RCCL_LIB names another file.
@@ -791,21 +785,19 @@ class ProverImpl : public Prover {
         const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words(); // u32 per work element
         int rc;
         hipStream_t s = w->stream;
-#ifdef MG_DIAG
-        static const int diag_zero = std::getenv("MG_DIAG_ZERO") ? std::atoi(std::getenv("MG_DIAG_ZERO")) : 0;
-        static const int diag_stop = std::getenv("MG_DIAG_WM_STOP") ? std::atoi(std::getenv("MG_DIAG_WM_STOP")) : 0;
-        if (diag_zero) {
-            hipLaunchKernelGGL(diag_zero_words, dim3(1024), dim3(256), 0, s, w->a.as<u32>(), 3 * k * D * ww);
-        } else
-#endif
-        MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s)); // rows past m + P are zero (the all-zero words are 0 in the work form too)
         u32 *a = w->a.as<u32>(), *b = a + k * D * ww, *c = b + k * D * ww, *zz = w->z.as<u32>();
         const size_t zs = (size_t)V_ * 8, ds = D * ww;
 #ifdef MG_DIAG
+        // diagnosis builds: MG_DIAG_MEMSET=1 puts the round-4 memset node back in front of the SpMV (the negative control of
+        // test_captured_graphs_survive_other_contexts: with it a LINEAR part A must go wrong); MG_DIAG_WM_STOP cuts the witness map
+        static const int diag_memset = std::getenv("MG_DIAG_MEMSET") ? std::atoi(std::getenv("MG_DIAG_MEMSET")) : 0;
+        static const int diag_stop = std::getenv("MG_DIAG_WM_STOP") ? std::atoi(std::getenv("MG_DIAG_WM_STOP")) : 0;
+        if (diag_memset) MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s));
         if (diag_stop == 1) return MG_OK;
 #endif
-        // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j
-        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds))) return rc;
+        // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j, and every
+        // vector its zero rows up to the domain size (the all-zero words are 0 in the work form too): no memset node in front of it
+        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds, D))) return rc;
 #ifdef MG_DIAG
         if (diag_stop == 2) return MG_OK;
 #endif
@@ -1830,7 +1822,21 @@ class ProverImpl : public Prover {
         sum(w->a.p, D * ww);                        // 1 h (a)
         sum((char *)w->a.p + D * ww, D * ww);       // 2 b
         sum((char *)w->a.p + 2 * D * ww, D * ww);   // 3 c
-        for (int i : {0, 2, 4}) {                   // 4.. : 10 per MSM (a / z3, b_g2, h)
+        {                                           // 4: non-zero words of a | b | c, 5: index of the first one
+            std::vector<u32> h(3 * D * ww / 4);
+            hipMemcpy(h.data(), w->a.p, h.size() * 4, hipMemcpyDeviceToHost);
+            u64 nz = 0, first = ~0ull;
+            for (size_t i = 0; i < h.size(); ++i)
+                if (h[i]) {
+                    if (!nz) first = i;
+                    ++nz;
+                }
+            if (n < cap) out[n] = nz;
+            ++n;
+            if (n < cap) out[n] = first;
+            ++n;
+        }
+        for (int i : {0, 2, 4}) {                   // 6.. : 10 per MSM (a / z3, b_g2, h)
             MsmWorkspace *m = w->mw[i];
             sum(m->count.p, m->count.p ? 4 : 0);
             sum(m->keys_in.p, m->keys_in.cap);

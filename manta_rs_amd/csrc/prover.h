@@ -25,7 +25,7 @@ class FrEngine {
     // (batch members: z vectors z_stride u32 apart, outputs out_stride u32 apart)
     virtual int work_words() const = 0;
     virtual int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m, u64 P,
-                      hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0) = 0;
+                      hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0, u64 rows_total = 0) = 0;
     // a, b, c = constraint evaluations over the domain (work form) -> a = coefficients of h = (AB - C)/Z in
     // bit-reversed order, work form, < 2p (ifft, coset fft x3, pointwise, coset ifft; fused, permutation-free)
     // batch > 1: a, b, c each hold `batch` vectors back to back

@@ -218,6 +218,45 @@ def test_captured_graphs_survive_other_contexts(gpu):
     c3.close()
 
 
+def _linear_child(env_extra):
+    """tools/diag_linear.py --child in a process of its own (the topology knobs are read once per process): the first context proves
+    after every step of a second context's life, each proof split A | B | C against the oracle. -> (number of wrong proofs, output)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("MANTA_", "MG_DIAG", "DIAG_"))}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "diag_linear.py"), "--child"], env=env, capture_output=True, text=True,
+                         timeout=900)
+    res = [ln for ln in out.stdout.split("\n") if ln.startswith("RESULT nbad=")]
+    assert out.returncode == 0 and res, out.stdout[-3000:] + out.stderr[-2000:]
+    return int(res[-1].split("=")[1]), out.stdout
+
+
+def test_linear_graphs_are_right_and_the_guard_is_sensitive(gpu):
+    """Round 5 root cause of round 4's wrong-C mode (profiles/r05_linear_graph_defect.txt): a hipMemsetAsync NODE inside a LINEAR
+    captured graph (one stream: the runtime pre-builds the graph's AQL packets, its own fill kernel included --
+    DEBUG_CLR_GRAPH_PACKET_CAPTURE) replays with a wrong fill pattern after other work has gone through the runtime; the a | b | c
+    vectors of the witness map then start from garbage instead of zeros and C is wrong. The library no longer has a memset node in
+    any captured graph (spmv3 writes its zero rows, zero_ranges the MSM's counters and buckets).
+    NEGATIVE CONTROL first: the diagnosis twin of the library with the memset node put back (MG_DIAG_MEMSET=1) and part A linear must
+    FAIL this very sequence at this very circuit size -- otherwise the sequence pins nothing. Then the same
+    topologies without the node must be right: linear part A (diagnosis twin), six linear graphs (MANTA_GRAPH=split, shipped
+    library), and the shipped default with MANTA_PROVE_STREAMS=1 in the environment (ignored outside -DMG_DIAG builds)."""
+    import os
+    from manta_rs_amd import api
+    diag = os.path.join(os.path.dirname(api.LIB_PATH), "libmantagpu_diag.so")
+    assert os.path.exists(diag), "manta_rs_amd/csrc/Makefile builds the diagnosis twin next to the library"
+    nbad, out = _linear_child({"MANTA_LIB": diag, "MANTA_PROVE_STREAMS": "1", "MG_DIAG_MEMSET": "1"})
+    assert nbad > 0, "the negative control passed: the guard sequence is not sensitive to the defect any more\n" + out
+    assert "ok ok BAD" in out and "BAD ok" not in out and "BAD BAD" not in out, out  # C alone goes wrong: the h term
+    for env in ({"MANTA_LIB": diag, "MANTA_PROVE_STREAMS": "1"}, {"MANTA_LIB": diag, "MANTA_GRAPH": "split"}, {"MANTA_GRAPH": "split"},
+                {"MANTA_PROVE_STREAMS": "1"}, {"MANTA_GRAPH": "split", "DIAG_FULL_TABLE_BYTES": "0"}):
+        nbad, out = _linear_child(env)
+        assert nbad == 0, (env, out)
+
+
 def test_prove_real_shape_private_transfer(gpu):
     """Shape-exact PrivateTransfer circuit (D=2^16, V=35175, P=27): bit-exact vs the oracle, pairing-verified,
     and -- like manta-pay/src/test/transfer.rs:346-417 -- a fuzzed public input must invalidate the proof."""

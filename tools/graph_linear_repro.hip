@@ -38,7 +38,21 @@ struct Test {
         CK(hipMalloc(&out, n * 4));
         CK(hipMemset(out, 0, n * 4));
         CK(hipMemset(buf, 0xff, n * 4));
-        CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (getenv("REPRO_PRIO")) {
+            int lo, hi;
+            CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi));
+        } else
+            CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        if (getenv("REPRO_EAGER")) // the library runs a slot twice with plain launches before it captures
+            for (int r = 0; r < 2; ++r) {
+                CK(hipMemsetAsync(buf, 0, n * 4, s));
+                Big b0{};
+                b0.p[3] = buf;
+                hipLaunchKernelGGL(fill, dim3((rows + 255) / 256), dim3(256), 0, s, b0, rows);
+                hipLaunchKernelGGL(acc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, buf, out, (unsigned)n);
+                CK(hipStreamSynchronize(s));
+            }
         hipStream_t s2 = nullptr;
         hipEvent_t e1, e2;
         CK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -141,6 +155,40 @@ int main(int argc, char **argv) {
     std::vector<unsigned> host(1 << 20, 3u);
     CK(hipMemcpy(other, host.data(), 4 << 20, hipMemcpyHostToDevice));
     round("after a pageable H2D hipMemcpy");
+    // the same kinds of operation MANY times: a ring of blit constants / kernel arguments would wrap
+    for (int i = 0; i < 200; ++i) CK(hipMemcpy(host.data(), other + i, 4 * (1 + i % 7), hipMemcpyDeviceToHost));
+    round("after 200 small pageable D2H hipMemcpy");
+    for (int i = 0; i < 200; ++i) CK(hipMemcpy(other + i, host.data(), 4 * (1 + i % 7), hipMemcpyHostToDevice));
+    round("after 200 small pageable H2D hipMemcpy");
+    for (int i = 0; i < 200; ++i) CK(hipMemset(other + 64 * i, 0x30 + i % 64, 4 * (1 + i % 50)));
+    CK(hipDeviceSynchronize());
+    round("after 200 small hipMemset (non-zero patterns), null stream");
+    for (int i = 0; i < 200; ++i) CK(hipMemsetAsync(other + 64 * i, 0x30 + i % 64, 4 * (1 + i % 50), tests[2].s));
+    CK(hipStreamSynchronize(tests[2].s));
+    round("after 200 small hipMemsetAsync (non-zero) on test 2's stream");
+    for (int i = 0; i < 200; ++i) CK(hipMemsetAsync(other + 64 * i, 0, 4 * (1 + i % 50), tests[2].s));
+    CK(hipStreamSynchronize(tests[2].s));
+    round("after 200 small hipMemsetAsync (zero) on test 2's stream");
+    for (int i = 0; i < 200; ++i) CK(hipMemset(other + 64 * i, 0x30 + i % 64, (1 << 20) + 4 * i));
+    CK(hipDeviceSynchronize());
+    round("after 200 x 1 MB hipMemset (non-zero), null stream");
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(scribble, dim3(4), dim3(256), 0, 0, other, 1000u, (unsigned)i);
+    CK(hipDeviceSynchronize());
+    round("after 200 kernels on the null stream");
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(scribble, dim3(4), dim3(256), 0, tests[2].s, other, 1000u, (unsigned)i);
+    CK(hipStreamSynchronize(tests[2].s));
+    round("after 200 kernels on test 2's stream");
+    {
+        unsigned *pin = nullptr;
+        CK(hipHostMalloc((void **)&pin, 1 << 20, hipHostMallocDefault));
+        for (int i = 0; i < 200; ++i) CK(hipMemcpyAsync(other + 64 * i, pin, 4096, hipMemcpyHostToDevice, tests[2].s));
+        CK(hipStreamSynchronize(tests[2].s));
+        round("after 200 pinned H2D hipMemcpyAsync on test 2's stream");
+        for (int i = 0; i < 200; ++i) CK(hipMemcpyAsync(pin, other + 64 * i, 4096, hipMemcpyDeviceToHost, tests[2].s));
+        CK(hipStreamSynchronize(tests[2].s));
+        round("after 200 pinned D2H hipMemcpyAsync on test 2's stream");
+        CK(hipHostFree(pin));
+    }
     {   // another graph is instantiated: does that "heal" the first ones?
         Test t;
         t.n = 4096;
