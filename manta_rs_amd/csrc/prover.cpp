@@ -797,6 +797,11 @@ class ProverImpl : public Prover {
 #endif
         // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j, and every
         // vector its zero rows up to the domain size (the all-zero words are 0 in the work form too): no memset node in front of it
+#ifdef MG_DIAG
+        if (diag_memset) { // round 4 exactly: the memset node zeroes, the SpMV writes its m + P rows only
+            if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds, 0))) return rc;
+        } else
+#endif
         if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds, D))) return rc;
 #ifdef MG_DIAG
         if (diag_stop == 2) return MG_OK;

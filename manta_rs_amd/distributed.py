@@ -123,10 +123,16 @@ class PartialPointExchange:
         """a free buffer set; the producer writes `words` u64 to slot.send (device memory) and makes stream_handle() wait"""
         return self._acquire()
 
-    def gather_async(self, sl: _Slot):
-        """all_gather_into_tensor from device memory on the current stream + asynchronous copy to pinned memory"""
-        self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)  # RCCL over xGMI
-        sl.h_recv.copy_(sl.recv, non_blocking=True)
+    def gather_async(self, sl: _Slot, words=None):
+        """all_gather_into_tensor from device memory on the current stream + asynchronous copy to pinned memory. `words` (<= the
+        buffer's) = u64 per rank the producer wrote: only those travel -- a pass of k proofs moves k * 5 points per rank over xGMI,
+        not the max_batch-sized buffer -- and land packed as [world, words] at the front of recv / h_recv."""
+        w = self.words if words is None else int(words)
+        if w <= 0 or w > self.words:
+            raise ValueError("PartialPointExchange.gather_async: words out of range")
+        sl.sent = w
+        self.dist.all_gather_into_tensor(sl.recv[:self.world * w], sl.send[:w], group=self.pg)  # RCCL over xGMI
+        sl.h_recv[:self.world * w].copy_(sl.recv[:self.world * w], non_blocking=True)
         sl.done.record()
 
     def wait(self, sl: _Slot, words=None) -> np.ndarray:
@@ -134,11 +140,12 @@ class PartialPointExchange:
         (<= the buffer's) = how many u64 per rank the producer actually wrote: the tail of a send buffer holds whatever an
         earlier, larger pass left there and must never reach the consumer."""
         sl.done.synchronize()
-        w = self.words if words is None else int(words)
-        if w < 0 or w > self.words:
+        sent = getattr(sl, "sent", self.words)  # per-rank length of the gather that filled this slot
+        w = sent if words is None else int(words)
+        if w < 0 or w > sent:
             sl.busy = False
             raise ValueError("PartialPointExchange.wait: words out of range")
-        out = sl.h_recv.numpy().view(np.uint64).reshape(self.world, self.words)[:, :w].copy()
+        out = sl.h_recv.numpy().view(np.uint64)[:self.world * sent].reshape(self.world, sent)[:, :w].copy()
         sl.busy = False
         return out
 
@@ -252,7 +259,7 @@ class ShardedProver:
         if ex.on_gpu:  # device path: partial points -> send buffer -> RCCL, no host sync in between
             sl = ex.begin()
             job = self.ctx.partials_launch(zs, k, sl.send.data_ptr(), ex.stream_handle())
-            ex.gather_async(sl)
+            ex.gather_async(sl, k * 5 * self.slot)  # what this pass wrote, not the max_batch-sized buffer
             return ShardedProofJob(self, k, rs, ss, slot=sl, job=job)
         # host path (gloo, or a single rank): the partial points come back through a device buffer of our own
         words = k * 5 * self.slot
