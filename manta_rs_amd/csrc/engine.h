@@ -288,6 +288,7 @@ size_t sort_pairs_temp_bytes(size_t n);
 // d_count (optional): the number of pairs actually present, on the device (n is then the capacity)
 bool sort_pairs_takes_device_count(int end_bit);
 int sort_pairs(const u32 *keys_in, u32 *keys_out, const u32 *vals_in, u32 *vals_out, size_t n, int end_bit,
-               void *tmp, size_t tmp_bytes, hipStream_t s, const u32 *d_count = nullptr);
+               void *tmp, size_t tmp_bytes, hipStream_t s, const u32 *d_count = nullptr, u32 lowmask = 0xffffffffu,
+               u32 inv_from = 0xffffffffu); // (lowmask, inv_from): sort by key & lowmask, keys >= inv_from last -- sort.hip sort_key
 
 } // namespace mg

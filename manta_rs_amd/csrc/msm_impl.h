@@ -1590,6 +1590,21 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         while (nb > 1 && (1u << end_bit_real) <= nb - 1) ++end_bit_real;
         if ((end_bit + 7) / 8 > (end_bit_real + 7) / 8) sparse = true;
         if (sparse) end_bit = end_bit_real; // no pair carries the invalid key there
+        // Several scalar vectors in the fixed layout (the dense h MSM of a batched pass): the digit kernel writes vector q's pairs
+        // behind vector q - 1's, and key = q * seg_keys + bucket with seg_keys a power of two -- a stable sort by the BUCKET bits
+        // (+ one value for the invalid key) keeps every (q, bucket) run contiguous and needs bits(seg_keys) + 1 bits instead of
+        // bits(batch * seg_keys) + 1: 14 instead of 19 for 32 proofs at c = 14, two radix passes over 40 M pairs instead of three
+        // (sort.hip sort_key). MANTA_SORT_LOW=0: the full key (A/B).
+        u32 sort_mask = 0xffffffffu, sort_inv = 0xffffffffu;
+        static const bool sort_low = [] {
+            const char *e = getenv("MANTA_SORT_LOW");
+            return !(e && atoi(e) == 0);
+        }();
+        if (sort_low && !sparse && batch > 1 && nsets == 1 && (seg_keys & (seg_keys - 1)) == 0) {
+            int eb = 1;
+            while ((1u << eb) <= seg_keys) ++eb; // keys 0 .. seg_keys - 1, and seg_keys for the invalid ones
+            if ((eb + 7) / 8 < (end_bit + 7) / 8) sort_mask = seg_keys - 1, sort_inv = invalid, end_bit = eb;
+        }
         // zero digits are compacted away by the digit kernel; how many pairs remain is known on the device only
         u32 *d_count = nullptr;
         if (sparse && sort_pairs_takes_device_count(end_bit)) {
@@ -1671,7 +1686,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         const u32 *skeys = no_sort ? ws->keys_in.as<u32>() : ws->keys_out.as<u32>();
         const u32 *svals = no_sort ? ws->vals_in.as<u32>() : ws->vals_out.as<u32>();
         if (!no_sort && (rc = sort_pairs(ws->keys_in.as<u32>(), ws->keys_out.as<u32>(), ws->vals_in.as<u32>(),
-                                         ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count)))
+                                         ws->vals_out.as<u32>(), M, end_bit, ws->sort_tmp.p, tmpb, s, d_count, sort_mask, sort_inv)))
             return rc;
         u32 *const std_final = direct ? ws->redS.as<u32>() : (u32 *)nullptr;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));

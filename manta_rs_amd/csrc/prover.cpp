@@ -207,6 +207,19 @@ static GraphMode graph_mode() {
     return m;
 }
 static bool graphs_enabled() { return graph_mode() != GRAPH_OFF; }
+// Batched passes (k >= 4 proofs) may take another topology than single proofs: their launch cost is spread over the batch, and a
+// pass replayed from SINGLE-STREAM graphs (split) or launched eagerly (off) can run the work-efficient front levels of the bucket
+// reduce, which the multi-branch graph of the "single" mode cannot (msm_impl.h, in_graph_slot). MANTA_GRAPH_BATCH = single | split |
+// off; MANTA_GRAPH, when set, rules every pass.
+static GraphMode graph_mode_for(u32 k) {
+    static const GraphMode batch = [] {
+        const char *e = std::getenv("MANTA_GRAPH_BATCH");
+        if (std::getenv("MANTA_GRAPH") || std::getenv("MANTA_NO_GRAPH") || !e) return graph_mode();
+        if (!std::strcmp(e, "off")) return GRAPH_OFF;
+        return std::strcmp(e, "split") ? GRAPH_SINGLE : GRAPH_SPLIT;
+    }();
+    return k >= 4 ? batch : graph_mode();
+}
 
 class ProverImpl : public Prover {
   public:
@@ -707,7 +720,7 @@ class ProverImpl : public Prover {
                 delete w;
                 return nullptr;
             }
-            w->mw[i]->in_graph_slot = graphs_enabled();
+            w->mw[i]->in_graph_slot = graph_mode_for(k) == GRAPH_SINGLE; // (multi-branch capture: no front levels)
         }
         // z3 slots: the combined a | b_g1 | l MSM announces its end through a pinned flag (MsmWorkspace::notify), so that the host
         // can fold its three results into s A + r B1 -- the one long piece of host work of a proof, ~0.1 ms -- while the h chain is
@@ -1006,7 +1019,7 @@ class ProverImpl : public Prover {
     }
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
-        if (graph_mode() == GRAPH_SINGLE) {
+        if (graph_mode_for(w->k) == GRAPH_SINGLE) {
             // (Round 4, measured and withdrawn: the combined MSM of a z3 slot captured as a LINEAR graph of its own and replayed next to
             // the G2 one started with the upload instead of 210-290 us into the proof and was worth 2-3 % of a sequential proof -- but
             // with other contexts' passes in flight on the GPU the proof's C element came out WRONG, on a pooled high-priority
@@ -1339,7 +1352,7 @@ class ProverImpl : public Prover {
                 if (!e) ok = ok && hipEventCreate(&e) == hipSuccess;
             w->timed = ok;
         }
-        if (!w->graphs_ready && graphs_enabled() && !w->no_graph && w->eager_runs >= 2 && !w->timed) build_graphs(w);
+        if (!w->graphs_ready && graph_mode_for(w->k) != GRAPH_OFF && !w->no_graph && w->eager_runs >= 2 && !w->timed) build_graphs(w);
         if (w->mw[0]->notify && w->mw[0]->h_flag) { // the combined MSM's end-of-chain token of THIS pass (z3 slots)
             *(volatile u32 *)w->mw[0]->h_flag = 0;
             std::atomic_thread_fence(std::memory_order_seq_cst);
@@ -1347,7 +1360,7 @@ class ProverImpl : public Prover {
         if (w->timed) {
             rc = enqueue_proof(w, z_src, false);
         } else if (w->graphs_ready) {
-            rc = enqueue_proof(w, z_src, graph_mode() == GRAPH_SPLIT);
+            rc = enqueue_proof(w, z_src, graph_mode_for(w->k) == GRAPH_SPLIT);
             if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
                 hipStreamSynchronize(w->stream);
                 hipStreamSynchronize(msm_stream(w, 2));
