@@ -123,6 +123,13 @@ struct ProveWs {
     // this slot runs the three G1 MSMs over the assignment (a, b_g1, l) as ONE pass of the MSM pipeline over the concatenated
     // query (ProverImpl::z3_bs_full_) on mw[0]; mw[1] and mw[3] stay idle. Fixed for the slot's lifetime (its graphs capture it).
     bool z3 = false;
+    // round 5: a z3 slot replays THREE linear graphs -- (witness map + h MSM) on `stream`, the combined a | b_g1 | l MSM on side[1],
+    // the G2 MSM on side[0] -- instead of a forked part A: a captured multi-branch graph starts its branches one after the other
+    // (the combined MSM began 210-290 us into the proof) and its hipGraphLaunch costs ~110 us of host time against 15-30 us for a
+    // linear one. Round 4 built exactly this and withdrew it because C came out wrong next to other contexts: that was the memset
+    // node of the witness map in a packet-captured linear graph (profiles/r05_linear_graph_defect.txt), gone now. MANTA_Z3_LINEAR=0:
+    // the forked graph (A/B).
+    bool linear3 = false;
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
@@ -736,6 +743,16 @@ class ProverImpl : public Prover {
         // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
         // stream per MSM.
         w->mw[2]->run_on = w->side[0]; // the G2 MSM (the critical path) gets a high-priority stream of its own
+        static const bool z3_linear = [] {
+            const char *e = std::getenv("MANTA_Z3_LINEAR");
+            return !(e && std::atoi(e) == 0);
+        }();
+        if (z3 && k == 1 && z3_linear && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE) {
+            w->linear3 = true;
+            w->mw[0]->run_on = w->side[1]; // the combined MSM: a high-priority pooled stream of its own
+            w->mw[4]->run_on = w->stream;  // the h MSM follows the witness map on the main stream
+            for (int i = 0; i < 5; ++i) w->mw[i]->in_graph_slot = false; // (single-stream captures only: front levels allowed)
+        } else
         if (prove_streams() == 3) {
             w->mw[0]->run_on = w->side[1];
             w->mw[1]->run_on = w->side[1];
@@ -989,6 +1006,16 @@ class ProverImpl : public Prover {
             MG_HIP(hipEventRecord(w->tev[14], g2s));
             return MG_OK;
         }
+        if (w->linear3 && w->g_all && w->g_g2 && w->g_msm[0]) { // three linear graphs, each behind the upload
+            hipStream_t z3s = msm_stream(w, 0);
+            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
+            MG_HIP(hipGraphLaunch(w->g_g2, g2s)); // the longest chain first
+            if (z3s != w->stream) MG_HIP(hipStreamWaitEvent(z3s, w->z_ready, 0));
+            MG_HIP(hipGraphLaunch(w->g_msm[0], z3s));
+            MG_HIP(hipGraphLaunch(w->g_all, w->stream));
+            for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
+            return MG_OK;
+        }
         if (w->g_all && w->g_g2) { // "single" mode replay
             // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
             // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
@@ -1019,6 +1046,32 @@ class ProverImpl : public Prover {
     }
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
+        if (w->linear3) {
+            const MsmArgs a = msm_args(w);
+            w->mw[4]->capturing = true; // linear captures: nothing inside them waits on a `done` event
+            bool ok = capture_segment(w->stream, &w->g_all, [&] {
+                const int rc = enqueue_witness_map_body(w);
+                return rc ? rc : enqueue_msm(w, a, 4, false);
+            });
+            w->mw[4]->capturing = false;
+            if (ok) {
+                w->mw[0]->capturing = true;
+                ok = capture_segment(msm_stream(w, 0), &w->g_msm[0], [&] { return enqueue_msm(w, a, 0, false); });
+                w->mw[0]->capturing = false;
+            }
+            if (ok) {
+                w->mw[2]->capturing = true;
+                ok = capture_segment(msm_stream(w, 2), &w->g_g2, [&] { return enqueue_part_b(w, false); });
+                w->mw[2]->capturing = false;
+            }
+            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
+            if (!ok) {
+                w->drop_graphs();
+                w->no_graph = true;
+            }
+            w->graphs_ready = ok;
+            return ok;
+        }
         if (graph_mode_for(w->k) == GRAPH_SINGLE) {
             // (Round 4, measured and withdrawn: the combined MSM of a z3 slot captured as a LINEAR graph of its own and replayed next to
             // the G2 one started with the upload instead of 210-290 us into the proof and was worth 2-3 % of a sequential proof -- but
@@ -1363,7 +1416,7 @@ class ProverImpl : public Prover {
             rc = enqueue_proof(w, z_src, graph_mode_for(w->k) == GRAPH_SPLIT);
             if (rc) { // do not trust the graphs again; the failed pass is reported to the caller
                 hipStreamSynchronize(w->stream);
-                hipStreamSynchronize(msm_stream(w, 2));
+                for (int i = 0; i < 5; ++i) hipStreamSynchronize(msm_stream(w, i));
                 w->drop_graphs();
                 w->no_graph = true;
             }
@@ -1391,6 +1444,13 @@ class ProverImpl : public Prover {
             if (w->z3 && (i == 1 || i == 3)) continue; // part of the combined MSM on mw[0]
             if (w->z3 && i == 0 && p.z3_folded) continue; // finish_pass_body took its results when its chain ended
             if (w->z3 && i == 0 && w->mw[0]->pending) { // three results per proof: a, b_g1, l
+                if (w->linear3) { // (its graph runs on a stream of its own, joined by nothing)
+                    const hipError_t e3 = hipStreamSynchronize(msm_stream(w, 0));
+                    if (e3 != hipSuccess && !rc) {
+                        set_last_hip_error(e3, "prove: hipStreamSynchronize", __FILE__, __LINE__);
+                        rc = MG_ERR_HIP;
+                    }
+                }
                 std::vector<HostPoint> t3((size_t)3 * p.k);
                 int rc2 = w->me[0]->msm_finish(w->mw[0], t3.data(), true);
                 if (!rc) rc = rc2;
@@ -1935,7 +1995,7 @@ class ProverImpl : public Prover {
                     break;
                 }
                 // (a failed launch or a device fault never writes the token: every few microseconds ask the stream itself)
-                if ((spin & 1023u) == 1023u && hipStreamQuery(w->stream) != hipErrorNotReady) break;
+                if ((spin & 1023u) == 1023u && hipStreamQuery(w->linear3 ? msm_stream(w, 0) : w->stream) != hipErrorNotReady) break;
                 cpu_relax();
                 if (spin >= 2048u && (spin & 15u) == 15u) std::this_thread::yield();
             }
