@@ -338,11 +338,12 @@ template <class F> struct XYZZ {
 // and swap the results through LDS (one barrier per level). All the linear work and the exceptional cases
 // (infinity on either side, P = Q -> doubling, P = -Q) are evaluated redundantly and identically by every wave, so
 // the copies stay bit-identical. `lds` = 2 x 4 exchange slots of F::XWORDS words (double-buffered).
-template <class F> struct CoopAdd {
+template <class F, bool ALLOW_DOUBLE = true> struct CoopAdd {
     static constexpr int SLOT = F::XWORDS;
     // two exchange areas used alternately (one barrier per level) while they fit 48 KB; the largest field (Fp2 over
-    // BLS12-381: 8 KB per slot) uses one area and a second barrier per level instead
-    static constexpr bool DOUBLE = 2 * 4 * SLOT * 4 <= 49152;
+    // BLS12-381: 8 KB per slot) uses one area and a second barrier per level instead (ALLOW_DOUBLE = false: always one area --
+    // callers whose LDS footprint decides their occupancy)
+    static constexpr bool DOUBLE = ALLOW_DOUBLE && 2 * 4 * SLOT * 4 <= 49152;
     static constexpr int LDS_WORDS = (DOUBLE ? 2 : 1) * 4 * SLOT;
     // publish this wave's product, fetch all four (16-byte LDS accesses)
     static MG_DEV void swap(u32 *buf, int wave, int lane, const F &mine, F (&all)[4]) {

@@ -89,6 +89,26 @@ __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *_
     const u32 nlo = (1u << lo_bits) >> cb;
     const u32 lo_base = (blockIdx.x % nlo) << cb, hi = blockIdx.x / nlo;
     const size_t base = ((size_t)hi << (lo_bits + ns)) + lo_base;
+    // Round 5, single-column tiles (cb = 0: the passes of ONE proof's witness map, a chain of six launches with ~1.5 wavefronts per
+    // SIMD): the tile's 2^ns - 1 twiddles -- entry 2^(tl-1) - 1 + jl for local stage tl -- are fetched ONCE, next to the tile, into
+    // LDS behind it. Before, every stage waited for its own 48 B gather from a table that the accumulate kernels' GB of table
+    // traffic keep out of the L2: eight dependent memory latencies per pass (io.packed bit 2; MANTA_NTT_TWL=0 turns it off).
+    const bool twl = (io.packed & 4u) != 0;
+    u32 *__restrict__ stw = sm + (size_t)K * TOT;
+    if (twl) {
+        for (u32 x = threadIdx.x + 1; x < E; x += blockDim.x) {
+            const unsigned tl = 32u - (unsigned)__clz(x);
+            const unsigned s = s0 + tl - 1;
+            if (s > 1) {
+                const size_t j = ((size_t)(x - (1u << (tl - 1))) << lo_bits) | lo_base;
+                const uint4 *q = reinterpret_cast<const uint4 *>(tw + (j << (lg - s)) * 12);
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+                u32 *o = stw + (x - 1);
+                o[0 * E] = q0.x, o[1 * E] = q0.y, o[2 * E] = q0.z, o[3 * E] = q0.w, o[4 * E] = q1.x, o[5 * E] = q1.y, o[6 * E] = q1.z,
+                o[7 * E] = q1.w, o[8 * E] = q2.x;
+            }
+        }
+    }
     for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
         const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
         if (io.in_std) { // arkworks format at the bit-reversed index -> work form (< 2p)
@@ -125,7 +145,11 @@ __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *_
 #pragma unroll
             for (int l = 0; l < K; ++l) a.v[l] = sm[l * TOT + i0], b.v[l] = sm[l * TOT + i1];
             R w;
-            if (has_w) {
+            if (has_w && twl) {
+                const u32 *o = stw + (half - 1 + jl);
+#pragma unroll
+                for (int l = 0; l < K; ++l) w.v[l] = o[l * E];
+            } else if (has_w) {
                 const size_t j = ((size_t)jl << lo_bits) | (lo_base + c);
                 const uint4 *q = reinterpret_cast<const uint4 *>(tw + (j << (lg - s)) * 12); // 48 B records
                 const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
@@ -205,12 +229,16 @@ template <bool DIF> MG_DEV bool ntt_lazy_stage(int q, int lr, unsigned bit, unsi
 }
 template <class FrC, bool DIF, int LR, int Q>
 MG_DEV void ntt_reg_stage(FpR<FrC> (&v)[1 << LR], const u32 *__restrict__ tw, bool has_w, bool red, unsigned b0, u32 e_lo,
-                          u32 lo_bits, u32 col, unsigned tw_shift, bool lazy = false) {
+                          u32 lo_bits, u32 col, unsigned tw_shift, bool lazy = false, const u32 *__restrict__ stw = nullptr, u32 ntw = 0) {
     typedef FpR<FrC> R;
 #pragma unroll
     for (int u = 0; u < (1 << Q); ++u) {
         R w;
-        if (has_w) {
+        if (has_w && stw) { // the tile's twiddles staged in LDS (single-column tiles): entry 2^bit - 1 + jl, bit = b0 + Q
+            const u32 *o = stw + ((1u << (b0 + (unsigned)Q)) - 1u + (((u32)u << b0) | e_lo));
+#pragma unroll
+            for (int l = 0; l < R::K; ++l) w.v[l] = o[l * ntw];
+        } else if (has_w) {
             const u32 jl = ((u32)u << b0) | e_lo; // the stage bits below the paired one
             const size_t j = ((size_t)jl << lo_bits) | col;
             const uint4 *qp = reinterpret_cast<const uint4 *>(tw + (j << tw_shift) * 12); // 48 B records
@@ -267,6 +295,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MG_NTT_REG_
     const u32 lo_base = (blockIdx.x % nlo) << cb, hi_blk = blockIdx.x / nlo;
     const size_t base = ((size_t)hi_blk << (lo_bits + ns)) + lo_base;
     auto pad = [](u32 t) { return t + (t >> 5); };
+    const bool twl = (io.packed & 4u) != 0; // single-column tiles: the tile's 2^ns - 1 twiddles in LDS behind it (see ntt_pass_rr)
+    u32 *__restrict__ stw = sm + (size_t)K * TOTP;
+    if (twl) {
+        for (u32 x = threadIdx.x + 1; x < E; x += blockDim.x) {
+            const unsigned tl = 32u - (unsigned)__clz(x);
+            const unsigned s = s0 + tl - 1;
+            if (s > 1) {
+                const size_t j = ((size_t)(x - (1u << (tl - 1))) << lo_bits) | lo_base;
+                const uint4 *q = reinterpret_cast<const uint4 *>(tw + (j << (lg - s)) * 12);
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+                u32 *o = stw + (x - 1);
+                o[0 * E] = q0.x, o[1 * E] = q0.y, o[2 * E] = q0.z, o[3 * E] = q0.w, o[4 * E] = q1.x, o[5 * E] = q1.y, o[6 * E] = q1.z,
+                o[7 * E] = q1.w, o[8 * E] = q2.x;
+            }
+        }
+    }
     for (u32 t = threadIdx.x; t < TOT; t += blockDim.x) {
         const size_t gi = base + ((size_t)(t >> cb) << lo_bits) + (t & CM);
         const u32 o = pad(t);
@@ -315,7 +359,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MG_NTT_REG_
                 const unsigned s = s0 + bit;               // global stage
                 // DIT: a stage whose outputs are consumed by another stage of this group (not stored) may leave them lazy
                 const bool lazy = ntt_lazy_stage<DIF>(Q, LR, bit, first_bit, gs, s);
-                ntt_reg_stage<FrC, DIF, LR, Q>(v, tw, s > 1, DIF && 2 * B > 8, b0, e_lo, lo_bits, lo_base + c, lg - s, lazy);
+                ntt_reg_stage<FrC, DIF, LR, Q>(v, tw, s > 1, DIF && 2 * B > 8, b0, e_lo, lo_bits, lo_base + c, lg - s, lazy,
+                                               twl ? stw : (const u32 *)nullptr, E);
                 const bool red = DIF && 2 * B > 8;
                 if (DIF) B = red ? 2 : 2 * B;
                 else B = s > 1 ? B + (lazy ? 3 : 2) : B + 5;
@@ -658,13 +703,19 @@ template <class FrC> class FrEngineT : public FrEngine {
             const u32 threads = ntt_threads() ? ntt_threads() : (tot >= 2048 ? 1024u : tot >= 128 ? tot / 2 : 64u);
             // public transform (arkworks format in and out, d0 = a scratch vector): the passes hand the vector on in the packed form
             const bool pack = io.in_std && io.out_std && npass > 1 && !DIF;
+            static const bool twl_on = [] {
+                const char *e = getenv("MANTA_NTT_TWL");
+                return !(e && atoi(e) == 0);
+            }();
+            const bool twl = twl_on && cb == 0 && ns >= 2; // single-column tiles: twiddles staged in LDS (E entries of 36 B more)
+            const size_t twl_bytes = twl ? ((size_t)(4 * RK) << ns) : 0;
             NttIo pio{p == 0 ? io.in_std : nullptr, p == 0 ? io.pre_rr : nullptr, last ? io.out_std : nullptr, last ? io.scale_rr : nullptr,
-                      pack ? (p > 0 ? 1u : 0u) | (last ? 0u : 2u) : 0u};
+                      (pack ? (p > 0 ? 1u : 0u) | (last ? 0u : 2u) : 0u) | (twl ? 4u : 0u)};
             // round 4: three stages per LDS round trip in registers (ntt_pass_reg) for every tile with a full wavefront of
             // 8-element lanes; MANTA_NTT_R = 0 restores the stage-per-round-trip kernel, 2 = four elements per lane
             const int lr = ntt_reg_bits(DIF);
             if (lr && tot >= (64u << lr) && ns >= (unsigned)lr) {
-                const size_t lds_p = (size_t)(4 * RK) * (tot + (tot >> 5));
+                const size_t lds_p = (size_t)(4 * RK) * (tot + (tot >> 5)) + twl_bytes;
                 const u32 th = std::min<u32>(512u, tot >> lr);
                 if (lr == 3)
                     hipLaunchKernelGGL((ntt_pass_reg<FrC, DIF, 3>), dim3(blocks, nvec, batch), dim3(th), lds_p, s, d0, d1, d2, tw_rr, lg, s0,
@@ -673,7 +724,7 @@ template <class FrC> class FrEngineT : public FrEngine {
                     hipLaunchKernelGGL((ntt_pass_reg<FrC, DIF, 2>), dim3(blocks, nvec, batch), dim3(th), lds_p, s, d0, d1, d2, tw_rr, lg, s0,
                                        ns, cb, last ? post_rr : (const u32 *)nullptr, pio);
             } else
-            hipLaunchKernelGGL((ntt_pass_rr<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds, s, d0, d1, d2, tw_rr, lg, s0,
+            hipLaunchKernelGGL((ntt_pass_rr<FrC, DIF>), dim3(blocks, nvec, batch), dim3(threads), lds + twl_bytes, s, d0, d1, d2, tw_rr, lg, s0,
                                ns, cb, last ? post_rr : (const u32 *)nullptr, pio);
             done += ns;
         }

@@ -288,6 +288,71 @@ __global__ __launch_bounds__(256) MG_ACC_ATTR void accumulate_chunks(const u32 *
         if (t == 0) clk[0] = (unsigned long long)(clock64() - c0), clk[1] = wall_clock64() - w0;
 }
 
+// Round 5 -- the accumulate stage of a SINGLE-KEY MSM (full tables, one scalar vector: every pair's key is 0 and the sum of all
+// table entries IS the result -- the h MSM and the G2 MSM of a single proof). accumulate_chunks leaves two partials per lane and
+// the first merge level then folds 16 of them serially per lane and scans: ~22 dependent additions on the chain that bounds a
+// single proof (107 of the 168 us of merge kernels behind the h accumulate: gpurun timeline, round 5). With one key no run
+// detection is needed and a workgroup can sum its own lanes: the accumulators go to LDS, ONE wavefront folds four of them per
+// lane and runs six butterfly levels of shuffles -- nine dependent additions in one wavefront while the other three have retired
+// (the accumulate kernel is throughput-bound: a first version that ran the butterfly in all four wavefronts added 8 wave-additions
+// to the 21 of the main loop and LOST 10 % of a proof; this one adds ~2.5). One partial per WORKGROUP (768 entries instead of 393 216
+// for a round of three wavefronts per SIMD) and two short merge levels behind it. Over Fp2 the lanes pair up through one shuffle
+// first, which halves the LDS (72-104 words per point).
+template <class F> struct AccSingle {
+    static constexpr int XW = XYZZ<F>::WORDS;
+    static constexpr int PAIR = F::EXT ? 1 : 0;
+    static constexpr int SLOTS = 256 >> PAIR, PER = SLOTS / 64;
+    typedef CoopAdd<F, false> Coop; // one exchange area: the footprint decides how many workgroups a CU holds
+    static constexpr size_t LDS_BYTES = ((size_t)SLOTS * XW + Coop::LDS_WORDS) * 4; // dynamic: above 64 KB for the wide fields
+};
+template <class F>
+__global__ __launch_bounds__(256) MG_TAIL_ATTR void accumulate_single(const u32 *__restrict__ vals, u32 M, u32 L, const u32 *__restrict__ bases,
+                                                                      u32 astride, u32 *__restrict__ pkeys, u32 *__restrict__ ppts, u32 T,
+                                                                      const u32 *__restrict__ count, u32 adapt, u32 invalid) {
+    extern __shared__ __attribute__((aligned(16))) u32 acc_single_lds[];
+    constexpr int XW = AccSingle<F>::XW, PAIR = AccSingle<F>::PAIR, SLOTS = AccSingle<F>::SLOTS, PER = AccSingle<F>::PER;
+    u32 *xs = acc_single_lds;            // the workgroup's accumulators
+    u32 *cx = acc_single_lds + SLOTS * XW; // exchange area of the cooperative additions
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (count) {
+        M = *count;
+        if (adapt) {
+            const u32 l = (M + T - 1) / T;
+            L = l > L ? l : L;
+        }
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    const size_t begin = (size_t)t * L;
+    size_t end = begin + L;
+    if (end > M) end = M;
+    if (t < T)
+        for (size_t j = begin; j < end; ++j) {
+            const u32 v = vals[j];
+            const Affine<F> p = Affine<F>::load(bases + (size_t)(v & 0x7fffffffu) * astride);
+            acc.madd_throughput(p, (v >> 31) != 0);
+        }
+    if ((size_t)blockIdx.x * blockDim.x * L >= M) { // (uniform) no pair reached this workgroup
+        if (threadIdx.x == 0) pkeys[blockIdx.x] = invalid;
+        return;
+    }
+    if constexpr (PAIR) acc.add(XYZZ<F>::shfl(acc, lane ^ 1));
+    if (!PAIR || !(lane & 1)) acc.store(xs + (size_t)(threadIdx.x >> PAIR) * XW);
+    __syncthreads();
+    // from here on the four wavefronts hold IDENTICAL copies of one 64-lane problem -- lane l folds accumulators PER l .. PER l +
+    // PER - 1, then six butterfly levels -- and every addition is cooperative (ec_dev.h CoopAdd: each wavefront one of the four
+    // independent products of a level): a dependent addition costs ~4 product-times instead of 14
+    acc = XYZZ<F>::load(xs + (size_t)(lane * PER) * XW);
+#pragma unroll 1
+    for (int k = 1; k < PER; ++k) AccSingle<F>::Coop::add(acc, XYZZ<F>::load(xs + (size_t)(lane * PER + k) * XW), cx, wave, lane);
+#pragma unroll 1
+    for (int d = 1; d < 64; d <<= 1) AccSingle<F>::Coop::add(acc, XYZZ<F>::shfl(acc, lane ^ d), cx, wave, lane);
+    if (threadIdx.x == 0) {
+        pkeys[blockIdx.x] = 0u;
+        acc.store(ppts + (size_t)blockIdx.x * XW);
+    }
+}
+
 #ifdef MG_CALIBRATION
 // Calibration twin of accumulate_chunks -- compiled ONLY into -DMG_CALIBRATION builds (tools/gather_calibration.py builds
 // one with tools/build_variant.sh and selects it through MANTA_LIB; the shipped library has neither this kernel nor the
@@ -1440,7 +1505,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // lanes of one full round of the accumulate kernel: what the device holds at the kernel's own occupancy (single MSMs: the
     // shortest chain) or at two wavefronts per SIMD (batched passes: that saturates the integer pipe, and fewer lanes mean fewer
     // partials to merge). MANTA_ACC_ROUND_WAVES = wavefronts per SIMD, 0 = off (host-side chunk length only).
-    u32 acc_round_lanes(u32 batch) {
+    u32 acc_round_lanes(u32 batch, bool single = false) {
         static const int knob = [] {
             const char *e = getenv("MANTA_ACC_ROUND_WAVES");
             return e ? atoi(e) : -1;
@@ -1448,13 +1513,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (knob == 0) return 0;
         const int dev = current_device();
         if (dev < 0 || dev >= 64 || !occ_[dev].cus.load(std::memory_order_acquire)) return 0; // (primed by bases_create)
-        u32 w = occ_[dev].blocks; // 256-thread blocks per CU = wavefronts per SIMD
+        u32 w = single && occ_[dev].blocks_single ? occ_[dev].blocks_single : occ_[dev].blocks; // 256-thread blocks per CU = wavefronts per SIMD
         if (knob > 0) w = (u32)knob < w ? (u32)knob : w;
         else if (batch > 1 && w > 2) w = 2;
         return w * 256u * occ_[dev].cus.load(std::memory_order_relaxed);
     }
     struct Occ {
-        u32 blocks = 0;
+        u32 blocks = 0, blocks_single = 0; // accumulate_chunks / accumulate_single (more registers, LDS: its own round size)
         std::atomic<u32> cus{0};
     } occ_[64];
     // (asked once per device outside any stream capture: bases_create runs before the first MSM on its device)
@@ -1467,7 +1532,15 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             (void)hipGetLastError();
             return;
         }
+        int nbs = 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&accumulate_single<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)AccSingle<F>::LDS_BYTES) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbs, accumulate_single<F>, 256, AccSingle<F>::LDS_BYTES) != hipSuccess || nbs < 1) {
+            (void)hipGetLastError();
+            nbs = 0;
+        }
         std::lock_guard<std::mutex> g(side_mu_);
+        occ_[dev].blocks_single = (u32)nbs;
         occ_[dev].blocks = (u32)nb;
         occ_[dev].cus.store((u32)cus, std::memory_order_release);
     }
@@ -1638,8 +1711,20 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // balanced ones do. Launch one round of lanes and let the kernel derive the chunk length from the pair count.
         u32 Tl = T, adapt = 0;
         u32 Lk = pl.L; // the chunk length the kernel starts from
+        // single-key MSMs sum inside the workgroup: one partial per workgroup (MANTA_ACC_SINGLE=0: the general kernel, A/B)
+        // MANTA_ACC_SINGLE: bit 0 = G1, bit 1 = G2. Default G1 only (sequential PrivateTransfer proofs, sparse / W / dense, two
+        // alternations on one box: off 0.770 / 0.859 / 1.258 ms, G1 0.755 / 0.852 / 1.270, G2 0.749 / 0.853 / 1.286, both 0.739 /
+        // 0.863 / 1.314 -- over Fp2 the cooperative additions are ~20 us each and the dense G2 chain gets longer)
+        static const bool acc_single_on = [] {
+            const char *e = getenv("MANTA_ACC_SINGLE");
+            const int v = e ? atoi(e) : 1;
+            return ((v >> (GROUP - 1)) & 1) != 0;
+        }();
+        const int dev_now = current_device();
+        const bool acc_single = nb == 1 && d_count && acc_single_on && !(kernel_timing() && !ws->capturing) && dev_now >= 0 && dev_now < 64 &&
+                                occ_[dev_now].cus.load(std::memory_order_acquire) && occ_[dev_now].blocks_single;
         if (d_count) {
-            const u32 tgt = acc_round_lanes(batch);
+            const u32 tgt = acc_round_lanes(batch, acc_single);
             if (tgt && Tl > tgt) Tl = tgt, adapt = 1;
             // one LARGE scalar vector (host chunk length above 6: 2^20 scalars): whatever the lane count came to, the pair count
             // decides (a batched pass that fits one round keeps its host-side chunk length: measured, -12 % otherwise)
@@ -1698,6 +1783,10 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                                (const u32 *)d_count);
         else
 #endif
+        if (acc_single)
+            hipLaunchKernelGGL((accumulate_single<F>), dim3(cdiv(Tl, 256)), dim3(256), AccSingle<F>::LDS_BYTES, s, svals, (u32)M, Lk, bs->d_pts, (u32)AWS,
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, adapt, invalid);
+        else
         if (ws->timed)
             hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
                                svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
@@ -1707,12 +1796,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                                svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
                                ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, (unsigned long long *)nullptr, adapt);
         if (ws->timed) MG_HIP(hipEventRecord(ws->t1, s));
-        u32 cnt = 2 * Tl;
+        u32 cnt = acc_single ? cdiv(Tl, 256) : 2 * Tl;
         int src = 0;
         for (int level = 0;; ++level) {
             // entries folded serially per lane: the first level is throughput-bound (as many entries as
             // accumulate lanes x 2), later ones are pure latency; <= 512 entries finish in one wave
-            u32 G = level == 0 ? merge_g1(M) : 2;
+            u32 G = level == 0 && !acc_single ? merge_g1(M) : 2;
             if (cnt <= 512) G = cnt <= 64 ? 1 : cdiv(cnt, 64);
             const u32 waves = cdiv(cdiv(cnt, G), 64);
             const int fin = waves == 1;

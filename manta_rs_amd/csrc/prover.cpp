@@ -1008,11 +1008,23 @@ class ProverImpl : public Prover {
         }
         if (w->linear3 && w->g_all && w->g_g2 && w->g_msm[0]) { // three linear graphs, each behind the upload
             hipStream_t z3s = msm_stream(w, 0);
-            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
-            MG_HIP(hipGraphLaunch(w->g_g2, g2s)); // the longest chain first
-            if (z3s != w->stream) MG_HIP(hipStreamWaitEvent(z3s, w->z_ready, 0));
-            MG_HIP(hipGraphLaunch(w->g_msm[0], z3s));
-            MG_HIP(hipGraphLaunch(w->g_all, w->stream));
+            // launch order (MANTA_Z3_ORDER, three letters of a = witness map + h, b = G2, z = combined): the chain that bounds the
+            // proof first -- each hipGraphLaunch is 10-20 us of host time, which the chains launched later start behind
+            static const char *order = [] {
+                const char *e = std::getenv("MANTA_Z3_ORDER");
+                return e && std::strlen(e) == 3 ? e : "abz";
+            }();
+            for (int t = 0; t < 3; ++t) {
+                if (order[t] == 'a') {
+                    MG_HIP(hipGraphLaunch(w->g_all, w->stream));
+                } else if (order[t] == 'b') {
+                    if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
+                    MG_HIP(hipGraphLaunch(w->g_g2, g2s));
+                } else {
+                    if (z3s != w->stream) MG_HIP(hipStreamWaitEvent(z3s, w->z_ready, 0));
+                    MG_HIP(hipGraphLaunch(w->g_msm[0], z3s));
+                }
+            }
             for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
             return MG_OK;
         }
