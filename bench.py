@@ -535,7 +535,8 @@ def config2_bench(env, log_d=20):
     ctx.close()
     z.free()
     hist = synth.histogram(c.z_int)
-    return {"workload": "one Groth16 proof, BLS12-381, D = V = 2^%d, P = 16: 3 SpMV + 7 NTT of 2^%d + 4 G1 MSM + 1 G2 MSM of ~2^%d terms" % (log_d, log_d, log_d),
+    return {"_cpu_todo": (c, pk, rs, first),
+            "workload": "one Groth16 proof, BLS12-381, D = V = 2^%d, P = 16: 3 SpMV + 7 NTT of 2^%d + 4 G1 MSM + 1 G2 MSM of ~2^%d terms" % (log_d, log_d, log_d),
             "witness_profile": "W", "z_histogram": {k: (round(v, 4) if k != "n" else v) for k, v in hist.items()},
             "prove_ms": round(min(ts) * 1e3, 3), "prove_ms_median": round(float(np.median(ts)) * 1e3, 3), "proofs_per_s": round(1 / min(ts), 2),
             "phases_ms": phases,
@@ -955,11 +956,36 @@ def prove_bench(args, env, shape="private_transfer", full=True, profile="W", lit
     return res
 
 
+def config2_cpu_baseline(c, pk, rs, first):
+    """the same 2^20 proof on the host's cores (the arkworks-`parallel` decomposition of the restatement), once: a CPU number next to
+    config2.ms and a byte comparison of the proof the GPU leg timed"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O  # the checker, here as the timed CPU baseline
+    cores = O.set_threads(O.usable_cpus())
+    t = time.perf_counter()
+    want = O.groth16_prove(c, pk, rs[0], rs[1], msm_algo=1)
+    t = time.perf_counter() - t
+    O.set_threads(1)
+    assert want == first, "config2: GPU proof bytes differ from the CPU restatement"
+    return {"seconds": round(t, 2), "cores": cores, "kind": "port", "proofs_per_s": round(1 / t, 4), "bytes_equal_gpu": True}
+
+
 def finish_cpu_baselines(line):
     """the timed CPU legs, after every GPU measurement of the run"""
     todo = line.pop("_cpu_todo", None)
     if todo:
         line["cpu_baseline"] = msm_cpu_baseline(*todo)
+    c2 = line.get("config2")
+    if isinstance(c2, dict):
+        todo = c2.pop("_cpu_todo", None)
+        if todo and line.get("cpu_baseline") is not None:  # (--no-cpu-baseline skips this one too)
+            try:
+                c2["cpu_all_cores"] = config2_cpu_baseline(*todo)
+                c2["speedup_vs_cpu_all_cores"] = round(c2["cpu_all_cores"]["seconds"] * 1e3 / c2["prove_ms"], 1)
+            except AssertionError:
+                raise
+            except Exception as e:  # noqa: BLE001
+                c2["cpu_all_cores"] = {"error": str(e)}
     res = line.get("proofs")
     if res is not None:
         todo = res.pop("_cpu_todo", None)
@@ -1115,7 +1141,8 @@ def compact_line(full):
                       "coset_ifft_ms": _g(full, "ntt", "coset_ifft", "device_ms")}
     if full.get("config2"):
         out["config2"] = {"ms": _g(full, "config2", "prove_ms"), "profile": _g(full, "config2", "witness_profile"),
-                          "cpu_all_cores_s": _g(full, "config2", "cpu_all_cores_s"), "error": _g(full, "config2", "error")}
+                          "cpu_all_cores_s": _g(full, "config2", "cpu_all_cores", "seconds"), "cpu_cores": _g(full, "config2", "cpu_all_cores", "cores"),
+                          "error": _g(full, "config2", "error")}
     if full.get("hbm_reference"):
         out["hbm_copy_TBps"] = _g(full, "hbm_reference", "d2d_copy_TBps")
     ss = full.get("strong_scaling")

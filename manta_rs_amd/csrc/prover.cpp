@@ -982,6 +982,9 @@ class ProverImpl : public Prover {
         for (int i = 0; i < 5; ++i) {
             if (!in_part_a(i) || !runs(w, i)) continue;
             hipStream_t ms = msm_stream(w, i);
+            // (round 5, measured and dropped: for LARGE proofs -- 2^20 variables -- the a / b_g1 / l MSMs launched BEHIND the witness
+            // map instead of beside it: the witness map falls from 5.9 to 3.8 ms and each of the three MSMs from 4-7 to 2-3 ms, but the
+            // proof goes from 10.5 to 11.0 ms -- the chip is busy either way: profiles/r05_config2_ab.txt)
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
             if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }

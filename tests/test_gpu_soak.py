@@ -1,0 +1,17 @@
+"""The 60-second version of tools/soak.py in the suite (the 10-minute run is profiles/r05_soak.txt): three contexts, six threads,
+single and batched calls mixed, a context replaced every three seconds, every proof byte-compared with the oracle's."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_soak_60_seconds(gpu):
+    import soak
+    st = soak.soak(seconds=60.0, threads=6, recycle_every=3.0, pool=4, log=lambda *_: None)
+    assert st["errors"] == 0 and st["mismatches"] == 0, st
+    assert st["proofs"] > 5000 and st["contexts_created"] >= 10 and st["batch_calls"] > 50 and st["single_calls"] > 500, st

@@ -1,0 +1,147 @@
+"""Soak run: what a signer process does for hours, compressed into minutes.
+
+Three ProvingContexts (ToPrivate / ToPublic / PrivateTransfer shapes: `MultiProvingContext`, manta-accounting/src/transfer/
+canonical.rs:561-588) shared by six host threads (manta-pay/src/bin/simulation.rs:36-38) that mix single calls (coalesced by the library
+when they overlap) with batches of 2 / 5 / 32 proofs; a recycler thread replaces one context every few seconds (create -> set_r1cs ->
+swap in -> drain the old one -> destroy), so graphs are captured, replayed and destroyed next to other contexts' passes the whole time.
+EVERY proof is byte-compared with the CPU oracle's proof of the same (circuit, key, r, s), precomputed before the run.
+
+usage: python tools/soak.py [seconds=600] [threads=6] [recycle_every_s=4]      -> a report on stdout, exit code 1 on any mismatch / error
+"""
+import os
+import random
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_private", "to_public", "private_transfer"), log=print):
+    import numpy as np
+    import oracle_lib as O
+    import helpers as H
+    from manta_rs_amd import api, synth, keygen
+    api.init(0)
+    curve = api.BN254
+    O.set_threads(O.usable_cpus())
+    t_setup = time.perf_counter()
+    S = {}
+    for si, name in enumerate(shapes):
+        c = synth.make_shape(curve, name, profile="W")
+        pk = keygen.generate(c, synth.from_mont(H.toxic(curve, seed=40 + si), synth.FR_MODULUS[curve]))
+        rs = H.rand_fr_mont(curve, 2 * pool, seed=500 + si)
+        rs[1][:] = 0  # one pair with r = 0 (b_g1 unused: ark-groth16 skips it)
+        want = [O.groth16_prove(c, pk, rs[j], rs[pool + j]) for j in range(pool)]
+        S[name] = {"c": c, "pk": pk, "rs": rs, "want": want, "r1cs": api.R1CS.from_circuit(c), "box": None, "gen": 0}
+    O.set_threads(1)
+    reg = threading.Lock()
+    drained = threading.Condition(reg)
+
+    def make_ctx(name):
+        s = S[name]
+        ctx = api.ProvingContext(curve, s["pk"], full_table_bytes=12 << 30)  # a signer's budget: three (at times four) contexts alive
+        ctx.set_r1cs(s["r1cs"])
+        return ctx
+
+    class Box:  # a context and the calls in flight on it
+        def __init__(self, ctx):
+            self.ctx, self.users = ctx, 0
+
+    for name in shapes:
+        S[name]["box"] = Box(make_ctx(name))
+    log("soak: %d shapes, %d oracle proofs each, setup %.1f s; running %.0f s with %d threads, a context recycled every %.1f s"
+        % (len(shapes), pool, time.perf_counter() - t_setup, seconds, threads, recycle_every))
+    stats = {"proofs": 0, "single_calls": 0, "batch_calls": 0, "mismatches": 0, "errors": 0, "contexts_created": len(shapes), "first_bad": None}
+    slock = threading.Lock()
+    deadline = time.perf_counter() + seconds
+    stop = threading.Event()
+
+    def acquire(name):
+        with reg:
+            b = S[name]["box"]
+            b.users += 1
+            return b
+
+    def release(b):
+        with reg:
+            b.users -= 1
+            drained.notify_all()
+
+    def worker(tid):
+        rnd = random.Random(1000 + tid)
+        while time.perf_counter() < deadline and not stop.is_set():
+            name = shapes[rnd.randrange(len(shapes))]
+            s = S[name]
+            box = acquire(name)
+            ctx = box.ctx
+            try:
+                k = rnd.choice((1, 1, 1, 1, 2, 5, 32)) if name != "private_transfer" or rnd.random() < 0.5 else 1
+                js = [rnd.randrange(pool) for _ in range(k)]
+                rs = s["rs"]
+                if k == 1:
+                    got = [api.Groth16.prove_with_randomness(ctx, s["c"].z, rs[js[0]], rs[pool + js[0]])]
+                else:
+                    got = api.Groth16.prove_batch(ctx, np.stack([s["c"].z] * k), rs[js], rs[[pool + j for j in js]])
+                bad = [(name, j) for j, g in zip(js, got) if g != s["want"][j]]
+                with slock:
+                    stats["proofs"] += k
+                    stats["single_calls" if k == 1 else "batch_calls"] += 1
+                    if bad:
+                        stats["mismatches"] += len(bad)
+                        if stats["first_bad"] is None:
+                            g, w = got[js.index(bad[0][1])], s["want"][bad[0][1]]
+                            stats["first_bad"] = {"shape": name, "k": k, "thread": tid, "gen": s["gen"], "t": round(seconds - (deadline - time.perf_counter()), 2),
+                                                  "elements_equal_A_B_C": [g[a:b] == w[a:b] for a, b in ((0, 32), (32, 96), (96, 128))]}
+            except Exception as e:  # noqa: BLE001
+                with slock:
+                    stats["errors"] += 1
+                    if stats["first_bad"] is None:
+                        stats["first_bad"] = {"shape": name, "error": repr(e)[:300]}
+            finally:
+                release(box)
+
+    def recycler():
+        rnd = random.Random(77)
+        while not stop.wait(recycle_every) and time.perf_counter() < deadline:
+            name = shapes[rnd.randrange(len(shapes))]
+            try:
+                fresh = make_ctx(name)  # built while the old one keeps serving
+            except Exception as e:  # noqa: BLE001
+                with slock:
+                    stats["errors"] += 1
+                    stats["first_bad"] = stats["first_bad"] or {"shape": name, "error": "recycle: " + repr(e)[:300]}
+                continue
+            with reg:
+                s = S[name]
+                old, s["box"] = s["box"], Box(fresh)
+                s["gen"] += 1
+                while old.users > 0:  # calls that took the old context before the swap: let them finish, then destroy it
+                    drained.wait(0.05)
+            old.ctx.close()
+            with slock:
+                stats["contexts_created"] += 1
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)] + [threading.Thread(target=recycler)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts[:-1]]
+    stop.set()
+    ts[-1].join()
+    dt = time.perf_counter() - t0
+    for name in shapes:
+        S[name]["box"].ctx.close()
+    stats["seconds"] = round(dt, 1)
+    stats["proofs_per_s"] = round(stats["proofs"] / dt, 1)
+    return stats
+
+
+if __name__ == "__main__":
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+    thr = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    rec = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
+    st = soak(secs, thr, rec)
+    print("soak result:", st, flush=True)
+    sys.exit(1 if (st["mismatches"] or st["errors"]) else 0)
