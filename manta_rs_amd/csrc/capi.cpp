@@ -170,17 +170,20 @@ static int bases_create_on(mg_curve_t curve, int group, const uint64_t *affine, 
 MG_API int mg_bases_create(mg_curve_t curve, int group, const uint64_t *affine, size_t n, int on_device,
                            int precompute_window_bits, mg_bases **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     return bases_create_on(curve, group, affine, n, on_device, precompute_window_bits, nullptr, 1, out);
     MG_CATCH
 }
 MG_API int mg_bases_create_sharded(mg_curve_t curve, int group, const uint64_t *affine, size_t n, const int *devices,
                                    int n_devices, int precompute_window_bits, mg_bases **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     if (!devices) return MG_ERROR_INVALID_ARGUMENT;
     return bases_create_on(curve, group, affine, n, 0, precompute_window_bits, devices, n_devices, out);
     MG_CATCH
 }
 MG_API void mg_bases_destroy(mg_bases *b) {
+    HeavyOp no_capture_meanwhile;
     if (b) bases_free(b);
 }
 MG_API size_t mg_bases_device_bytes(const mg_bases *b) {
@@ -528,6 +531,7 @@ void blake3_hash(const uint8_t *data, size_t len, uint8_t out[32]);
 MG_API int mg_ctx_create_from_bytes_ex(mg_curve_t curve, const uint8_t *bytes, size_t len, const uint8_t *checksum32,
                                        const mg_ctx_opts *opts, mg_ctx **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     if (!bytes || !out) return MG_ERROR_INVALID_ARGUMENT;
     ProverOptions o;
     int rc = opts_from_abi(opts, o);
@@ -578,6 +582,7 @@ MG_API int mg_groth16_assemble(const mg_ctx *ctx, uint64_t k, int n_parts, const
 MG_API int mg_ctx_create_from_bytes_sharded(mg_curve_t curve, const uint8_t *bytes, size_t len, const int *devices,
                                             int n_devices, mg_ctx **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     if (!bytes || !out || !devices || n_devices < 1) return MG_ERROR_INVALID_ARGUMENT;
     Prover *p = nullptr;
     int rc = prover_create_from_bytes((int)curve, bytes, len, &p, devices, n_devices);
@@ -625,6 +630,7 @@ MG_API int mg_groth16_setup(mg_curve_t curve, const mg_csr *a, const mg_csr *b, 
                             uint64_t n_inputs, const uint64_t *toxic, const uint64_t *g1_gen, const uint64_t *g2_gen,
                             const mg_pk_out *out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     return groth16_setup((int)curve, a, b, c, m, n_vars, n_inputs, toxic, g1_gen, g2_gen, out);
     MG_CATCH
 }
@@ -659,6 +665,7 @@ MG_API uint64_t mg_ctx_num_inputs(const mg_ctx *ctx) { return ctx ? ctx->p->n_in
 MG_API int mg_ctx_num_shards(const mg_ctx *ctx) { return ctx ? (int)ctx->p->n_shards() : 0; }
 MG_API void mg_ctx_destroy(mg_ctx *ctx) {
     if (!ctx) return;
+    HeavyOp no_capture_meanwhile;
     delete ctx->p;
     delete ctx;
 }
@@ -670,6 +677,7 @@ struct mg_vk {
 MG_API int mg_vk_create(mg_curve_t curve, const uint64_t *alpha_g1, const uint64_t *beta_g2, const uint64_t *gamma_g2,
                         const uint64_t *delta_g2, const uint64_t *gamma_abc_g1, uint64_t n_inputs, mg_vk **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     if (!out) return MG_ERROR_INVALID_ARGUMENT;
     Verifier *v = nullptr;
     int rc = verifier_create((int)curve, alpha_g1, beta_g2, gamma_g2, delta_g2, gamma_abc_g1, n_inputs, &v);
@@ -680,6 +688,7 @@ MG_API int mg_vk_create(mg_curve_t curve, const uint64_t *alpha_g1, const uint64
 }
 MG_API int mg_vk_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_t len, mg_vk **out) {
     MG_TRY
+    HeavyOp no_capture_meanwhile;
     if (!out) return MG_ERROR_INVALID_ARGUMENT;
     Verifier *v = nullptr;
     int rc = verifier_create_from_bytes((int)curve, bytes, len, &v);
@@ -689,6 +698,7 @@ MG_API int mg_vk_create_from_bytes(mg_curve_t curve, const uint8_t *bytes, size_
     MG_CATCH
 }
 MG_API void mg_vk_destroy(mg_vk *vk) {
+    HeavyOp no_capture_meanwhile;
     if (!vk) return;
     delete vk->v;
     delete vk;

@@ -3,6 +3,7 @@
 // C ABI (include/mantagpu.h) can dispatch on (curve, group) at run time.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <shared_mutex>
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
@@ -62,6 +63,18 @@ void get_last_prove_ms(float v[10]);
 // process-lifetime pool of non-blocking streams for proof slots (returned, never destroyed -- runtime.cpp)
 constexpr int MAX_DEVICES = 16;
 int current_device(); // hipGetDevice, clamped to the engine tables
+// Stream capture against the rest of the process (round 5, found by tools/soak.py): while ANY thread captures a proof slot's graphs,
+// another thread that creates or destroys a context / base set / verifying context (synchronous copies, kernels on the default
+// stream, hipDeviceSynchronize, hipFree) makes the runtime invalidate the capture -- every stream that had joined it then answers
+// hipErrorStreamCaptureInvalidated (901) to every later call and the slot is lost. Captures hold this lock exclusively (about a
+// millisecond, once per slot), the heavy operations hold it shared: they still run beside each other and beside proofs that replay.
+std::shared_mutex &capture_mutex();
+struct HeavyOp { // the shared side, re-entrant per thread (a failed creation destroys what it built; a context owns its peers)
+    HeavyOp();
+    ~HeavyOp();
+    HeavyOp(const HeavyOp &) = delete;
+    HeavyOp &operator=(const HeavyOp &) = delete;
+};
 hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 const char *last_error_string();

@@ -130,6 +130,7 @@ struct ProveWs {
     // node of the witness map in a packet-captured linear graph (profiles/r05_linear_graph_defect.txt), gone now. MANTA_Z3_LINEAR=0:
     // the forked graph (A/B).
     bool linear3 = false;
+    bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
@@ -172,9 +173,11 @@ struct ProveWs {
         if (fork) hipEventDestroy(fork);
         for (auto &e : tev)
             if (e) hipEventDestroy(e);
-        stream_pool_put(stream); // never destroyed: see stream_pool_get()
-        stream_pool_put(side[0]);
-        stream_pool_put(side[1]);
+        if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
+            stream_pool_put(stream);
+            stream_pool_put(side[0]);
+            stream_pool_put(side[1]);
+        }
         hipSetDevice(prev);
     }
 };
@@ -278,6 +281,7 @@ class ProverImpl : public Prover {
     static constexpr size_t MAX_IDLE_SLOTS = 16; // (eight batch sizes of coalesced calls x two passes in flight) per context: beyond it the least recently used idle slot is destroyed
 
     ~ProverImpl() override {
+        HeavyOp no_capture_meanwhile;
         exchange_destroy();
         for (ProverImpl *q : peers_) delete q;
         hipSetDevice(dev_);
@@ -591,6 +595,8 @@ class ProverImpl : public Prover {
         // circuit was being staged). With every shard locked no pass is in flight, none starts, nothing is capturing.
         std::vector<std::unique_lock<std::shared_mutex>> locks;
         for (ProverImpl *q : all) locks.emplace_back(q->shape_mu_);
+        // (after the shape locks, never before: a pass that holds a shape lock shared may be waiting for the capture lock)
+        HeavyOp no_capture_meanwhile;
         std::vector<StagedR1cs> st(all.size());
         for (size_t g = 0; g < all.size() && !rc; ++g) rc = all[g]->stage_r1cs(a, b, c, m, st[g]);
         if (rc) {
@@ -780,7 +786,7 @@ class ProverImpl : public Prover {
         std::vector<ProveWs *> doomed;
         {
             std::lock_guard<std::mutex> g(mu_);
-            if (w->gen != gen_) {
+            if (w->gen != gen_ || w->poisoned) {
                 doomed.push_back(w);
             } else {
                 w->last_use = ++lru_tick_;
@@ -1061,6 +1067,12 @@ class ProverImpl : public Prover {
     }
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
+        std::unique_lock<std::shared_mutex> no_heavy_ops_meanwhile(capture_mutex());
+        const bool ok = build_graphs_locked(w);
+        if (!ok) w->poisoned = true; // a capture that failed may leave streams in the invalidated state: the slot is not reused
+        return ok;
+    }
+    bool build_graphs_locked(ProveWs *w) {
         if (w->linear3) {
             const MsmArgs a = msm_args(w);
             w->mw[4]->capturing = true; // linear captures: nothing inside them waits on a `done` event
@@ -2091,6 +2103,7 @@ class ProverImpl : public Prover {
 //   exchange             how the partial points of an in-process sharded context meet: host-staged sum, or RCCL all_gather
 int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Prover **out) {
     if (!pk || !out) return MG_ERR_ARG;
+    HeavyOp no_capture_meanwhile;
     if (o.task_mask > 0x1f || o.n_shards == 0 || o.shard >= o.n_shards || o.n_shards > 64) return MG_ERR_ARG;
     if (o.exchange != 0 && o.exchange != 1) return MG_ERR_ARG;
     const bool listed = o.devices && o.n_devices > 0;

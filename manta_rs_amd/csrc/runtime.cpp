@@ -74,6 +74,17 @@ void DevBuf::release() {
 // come and gone; stream destruction unbalances the queue use counts and made it 7 in 8). The exec's internal
 // streams are normal-priority; a high-priority launch stream lives in the other hardware-queue pool and can
 // never alias them.
+std::shared_mutex &capture_mutex() {
+    static std::shared_mutex mu;
+    return mu;
+}
+static thread_local int tl_heavy_depth = 0;
+HeavyOp::HeavyOp() {
+    if (tl_heavy_depth++ == 0) capture_mutex().lock_shared();
+}
+HeavyOp::~HeavyOp() {
+    if (--tl_heavy_depth == 0) capture_mutex().unlock_shared();
+}
 static std::mutex g_stream_mu;
 static std::vector<hipStream_t> g_stream_pools[MAX_DEVICES]; // a stream belongs to the device it was created on
 static std::map<hipStream_t, int> g_stream_dev;
