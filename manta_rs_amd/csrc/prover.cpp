@@ -698,13 +698,23 @@ class ProverImpl : public Prover {
         have_r1cs_ = true;
     }
 
-    static u32 slot_key(u32 k, bool z3) { return k | (z3 ? 1u << 16 : 0u); }
-    ProveWs *ws_acquire(u32 k = 1, bool z3 = false) {
+    static bool lin_wanted(u32 k, bool z3, bool lone) {
+        static const bool z3_linear = [] {
+            const char *e = std::getenv("MANTA_Z3_LINEAR");
+            return !(e && std::atoi(e) == 0);
+        }();
+        return z3 && k == 1 && lone && z3_linear && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE;
+    }
+    static u32 slot_key(u32 k, bool z3, bool lin = false) { return k | (z3 ? 1u << 16 : 0u) | (lin ? 1u << 17 : 0u); }
+    // lone: no other pass of this context is in flight -- a z3 slot then replays three linear graphs (ProveWs::linear3: the shortest
+    // chain for ONE proof); beside another pass the forked graph is kept: two proofs in flight on 2 x 3 high-priority streams lost
+    // 18 % against 2 x 1 (two host threads: 1 063-1 091 against 1 223-1 373 proofs/s, profiles/r05_single_proof_ab.txt)
+    ProveWs *ws_acquire(u32 k = 1, bool z3 = false, bool lone = true) {
         u64 gen;
         {
             std::lock_guard<std::mutex> g(mu_);
             gen = gen_;
-            auto it = ws_free_.find(slot_key(k, z3));
+            auto it = ws_free_.find(slot_key(k, z3, lin_wanted(k, z3, lone)));
             while (it != ws_free_.end() && !it->second.empty()) {
                 ProveWs *w = it->second.back();
                 it->second.pop_back();
@@ -749,11 +759,7 @@ class ProverImpl : public Prover {
         // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
         // stream per MSM.
         w->mw[2]->run_on = w->side[0]; // the G2 MSM (the critical path) gets a high-priority stream of its own
-        static const bool z3_linear = [] {
-            const char *e = std::getenv("MANTA_Z3_LINEAR");
-            return !(e && std::atoi(e) == 0);
-        }();
-        if (z3 && k == 1 && z3_linear && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE) {
+        if (lin_wanted(k, z3, lone)) {
             w->linear3 = true;
             w->mw[0]->run_on = w->side[1]; // the combined MSM: a high-priority pooled stream of its own
             w->mw[4]->run_on = w->stream;  // the h MSM follows the witness map on the main stream
@@ -790,7 +796,7 @@ class ProverImpl : public Prover {
                 doomed.push_back(w);
             } else {
                 w->last_use = ++lru_tick_;
-                ws_free_[slot_key(w->k, w->z3)].push_back(w);
+                ws_free_[slot_key(w->k, w->z3, w->linear3)].push_back(w);
                 ++idle_slots_;
                 while (idle_slots_ > MAX_IDLE_SLOTS) {
                     std::vector<ProveWs *> *from = nullptr;
@@ -1209,11 +1215,12 @@ class ProverImpl : public Prover {
                     batch.push_back(cq_.front());
                     cq_.pop_front();
                 }
+                const bool lone = cq_inflight_ == 0; // nothing of this context on the GPU right now
                 ++cq_inflight_;
                 lk.unlock();
                 int rc; // nothing may escape here: the followers of this batch wait on cq_cv_ for their `done`
                 try {
-                    rc = prove_gathered(batch);
+                    rc = prove_gathered(batch, lone);
                 } catch (const std::bad_alloc &) {
                     rc = MG_ERR_OOM;
                 } catch (...) {
@@ -1230,9 +1237,9 @@ class ProverImpl : public Prover {
         }
     }
     // one pass over the requests of `batch` (padded to a power of two with copies of the first one)
-    int prove_gathered(const std::vector<Req *> &batch) {
+    int prove_gathered(const std::vector<Req *> &batch, bool lone = true) {
         const size_t k = batch.size();
-        if (k == 1) return prove_pass(1, batch[0]->z, batch[0]->r, batch[0]->s, batch[0]->out);
+        if (k == 1) return prove_pass(1, batch[0]->z, batch[0]->r, batch[0]->s, batch[0]->out, nullptr, lone);
         // pass sizes: exact up to 8 (a pass of k proofs costs ~0.65 + 0.42 k ms for the PrivateTransfer shape -- padding three
         // coalesced calls to four wastes a sixth of the pass; six signer threads produce passes of two to four), then multiples of
         // four: slots and their captured graphs exist per size, so the set of sizes stays small
@@ -1333,7 +1340,7 @@ class ProverImpl : public Prover {
         gate_cv_.notify_one();
     }
     int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out,
-                   const uint64_t *const *z_list = nullptr) {
+                   const uint64_t *const *z_list = nullptr, bool lone = true) {
         DeviceGuard restore_callers_device; // the pass visits every shard's device
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
@@ -1348,7 +1355,7 @@ class ProverImpl : public Prover {
         for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
         const auto t_enq = std::chrono::steady_clock::now();
-        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list);
+        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list, true, lone);
         p.enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enq).count();
         return finish_pass(p, rc, &pp);
     }
@@ -1374,11 +1381,11 @@ class ProverImpl : public Prover {
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
     // (z_list: the k assignments as separate buffers -- coalesced single calls -- gathered into the slot's staging copy)
     int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out,
-                    const uint64_t *const *z_list = nullptr, bool whole_proof = true) {
+                    const uint64_t *const *z_list = nullptr, bool whole_proof = true, bool lone = true) {
         MG_HIP(hipSetDevice(dev_));
         p.k = k, p.r = r, p.s = s, p.out = out;
         // (the partials interface folds every MSM on the device by its index: it keeps the five separate MSMs)
-        ProveWs *w = p.w = ws_acquire(k, whole_proof && wants_z3(k));
+        ProveWs *w = p.w = ws_acquire(k, whole_proof && wants_z3(k), lone);
         if (!w) return MG_ERR_HIP;
         int rc = MG_OK;
         const size_t zbytes = (size_t)k * V_ * 32;
