@@ -66,6 +66,20 @@ __global__ __launch_bounds__(256) void powers_kernel(u32 *__restrict__ out, cons
 #define MG_NTT_MUL(x, y) R::template mul_t<true>(x, y)
 #endif
 #define MG_NTT_MUL_RR(x, y) MG_NTT_MUL(x, y) // (the stage-per-round-trip kernel: 82 -> 64 VGPRs, DIF passes -4 %)
+// The witness map is the head of the chain that bounds a single proof (witness map -> h MSM) and runs beside the accumulate kernels
+// of the other MSMs: its wavefronts ask for issue priority 2 -- above the accumulate kernels (0), below the MSMs' tail kernels (3).
+// Sequential PrivateTransfer proofs, sparse / W / dense, library variants alternating on one box (profiles/r05_single_proof_ab.txt):
+// level 0: 0.728 / 0.872 / 1.290 ms, 1: 0.714 / 0.867 / 1.253, 2: 0.707 / 0.864 / 1.249, 3: 0.716 / 0.925 / 1.245 (level 3 takes issue
+// slots from the a | b_g1 | l and G2 chains' own tails: W +6 % -- what round 3 saw when it tried level 3 and dropped it);
+// batched passes do not move. MG_WM_PRIO = the s_setprio level at build time (0: off).
+#ifndef MG_WM_PRIO
+#define MG_WM_PRIO 2
+#endif
+#if MG_WM_PRIO
+#define MG_PRIO_WM() __builtin_amdgcn_s_setprio(MG_WM_PRIO)
+#else
+#define MG_PRIO_WM() ((void)0)
+#endif
 struct NttIo {
     const u32 *in_std, *pre_rr;
     u32 *out_std;
@@ -79,6 +93,7 @@ template <class FrC, bool DIF>
 __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
                                                    const u32 *__restrict__ tw, unsigned lg, unsigned s0, unsigned ns,
                                                    unsigned cb, const u32 *__restrict__ post, NttIo io) {
+    MG_PRIO_WM();
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     typedef FpR<FrC> R;
     constexpr int K = R::K;
@@ -203,6 +218,157 @@ __global__ __launch_bounds__(1024) void ntt_pass_rr(u32 *__restrict__ d0, u32 *_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Round 5: pass FUSION for the witness map of ONE proof. With single-column tiles the low pass of the inverse
+// transform and the low pass of the forward coset transform that follows it work on the SAME contiguous tile, and so do the high pass
+// of the forward transform, the pointwise step and the high pass of the last inverse transform on the same strided tile: 7 launches
+// (2 + 2 + pointwise + 2) become 4, three LDS fill / drain pairs and three trips through HBM of a | b | c go away -- on a chain whose
+// every launch is latency (six launches of 30-45 us at ~1.5 wavefronts per SIMD).
+// ntt_tile_stages = the stage loop of ntt_pass_rr at cb = 0 over one tile already in LDS (limb-major, stride E).
+template <class FrC, bool DIF>
+MG_DEV void ntt_tile_stages(u32 *__restrict__ sm, u32 E, unsigned ns, unsigned s0, unsigned lg, u32 lo_bits, u32 lo_base,
+                            const u32 *__restrict__ tw, int &B, u32 tid, u32 nthr) {
+    typedef FpR<FrC> R;
+    constexpr int K = R::K;
+    for (unsigned st = 0; st < ns; ++st) {
+        const unsigned tl = DIF ? ns - st : st + 1; // local stage 1..ns
+        const unsigned s = s0 + tl - 1;             // global stage
+        const u32 half = 1u << (tl - 1);
+        const bool has_w = s > 1;
+        const bool red = DIF && 2 * B > 8; // uniform
+        for (u32 k = tid; k < E / 2; k += nthr) {
+            const u32 jl = k & (half - 1), g = k >> (tl - 1);
+            const u32 i0 = (g << tl) | jl, i1 = i0 + half;
+            R a, b;
+#pragma unroll
+            for (int l = 0; l < K; ++l) a.v[l] = sm[l * E + i0], b.v[l] = sm[l * E + i1];
+            R w;
+            if (has_w) {
+                const size_t j = ((size_t)jl << lo_bits) | lo_base;
+                const uint4 *q = reinterpret_cast<const uint4 *>(tw + (j << (lg - s)) * 12); // 48 B records
+                const uint4 q0 = q[0], q1 = q[1], q2 = q[2];
+                w.v[0] = q0.x, w.v[1] = q0.y, w.v[2] = q0.z, w.v[3] = q0.w, w.v[4] = q1.x, w.v[5] = q1.y, w.v[6] = q1.z,
+                w.v[7] = q1.w, w.v[8] = q2.x;
+            }
+            R x, y;
+            if (DIF) {
+                x = R::add(a, b);                    // < 2B p
+                y = R::template sub<9>(a, b);        // a + 9p - b (b < 8p)
+                if (has_w) y = MG_NTT_MUL_RR(y, w);  // < 2p
+                else y = R::template reduce<17>(y);  // last DIF stage (w = 1)
+                if (red) x = R::template reduce<16>(x);
+            } else {
+                if (has_w) {
+                    b = MG_NTT_MUL_RR(b, w); // < 2p
+                    x = R::add(a, b);
+                    y = R::template sub<2>(a, b);
+                } else { // first DIT stage (w = 1): b < 4p
+                    x = R::add(a, b);
+                    y = R::template sub<5>(a, b);
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < K; ++l) sm[l * E + i0] = x.v[l], sm[l * E + i1] = y.v[l];
+        }
+        if (DIF) B = red ? 2 : 2 * B;
+        else B = has_w ? B + 2 : B + 5;
+        __syncthreads();
+    }
+}
+// low pass of the inverse transform (DIF stages ns .. 1, then the table `post`) + low pass of the forward transform (DIT stages 1 .. ns)
+// on one contiguous tile of 2^ns elements; grid (n >> ns, vectors, batch), E / 2 threads
+template <class FrC>
+__global__ __launch_bounds__(512) void ntt_fused_low(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
+                                                     const u32 *__restrict__ tw_inv, const u32 *__restrict__ tw_fwd, unsigned lg,
+                                                     unsigned ns, const u32 *__restrict__ post) {
+    MG_PRIO_WM();
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    typedef FpR<FrC> R;
+    constexpr int K = R::K;
+    static_assert(K == 9 && R::LIM >= 64, "bound analysis of ntt_pass_rr");
+    u32 *__restrict__ data = (blockIdx.y == 0 ? d0 : (blockIdx.y == 1 ? d1 : d2)) + ((size_t)blockIdx.z << lg) * K;
+    const u32 E = 1u << ns;
+    const size_t base = (size_t)blockIdx.x << ns;
+    for (u32 t = threadIdx.x; t < E; t += blockDim.x) {
+        const u32 *p = data + (base + t) * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) sm[l * E + t] = p[l];
+    }
+    __syncthreads();
+    int B = 4; // every value of the tile is < B p (the high pass left < 4p)
+    ntt_tile_stages<FrC, true>(sm, E, ns, 1, lg, 0, 0, tw_inv, B, threadIdx.x, blockDim.x);
+    for (u32 t = threadIdx.x; t < E; t += blockDim.x) { // n^-1 g^bitrev(i): any B <= 27 times a canonical entry -> < 2p
+        R v;
+#pragma unroll
+        for (int l = 0; l < K; ++l) v.v[l] = sm[l * E + t];
+        v = R::mul(v, R::load(post + (base + t) * K));
+#pragma unroll
+        for (int l = 0; l < K; ++l) sm[l * E + t] = v.v[l];
+    }
+    __syncthreads();
+    B = 2;
+    ntt_tile_stages<FrC, false>(sm, E, ns, 1, lg, 0, 0, tw_fwd, B, threadIdx.x, blockDim.x);
+    for (u32 t = threadIdx.x; t < E; t += blockDim.x) {
+        R v;
+#pragma unroll
+        for (int l = 0; l < K; ++l) v.v[l] = sm[l * E + t];
+        v = R::template reduce<32>(v);
+        u32 *p = data + (base + t) * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) p[l] = v.v[l];
+    }
+}
+// high pass of the forward transform on a, b, c (DIT stages lo + 1 .. lg; a third of the workgroup each) + (a b - c) / Z + high pass of
+// the inverse transform on the result (DIF stages lg .. lo + 1), one strided tile (column blockIdx.x) of 2^ns elements per vector;
+// grid (n >> ns, 1, batch), 3 E / 2 threads
+template <class FrC>
+__global__ __launch_bounds__(1024) void ntt_fused_high_pw(u32 *__restrict__ a, u32 *__restrict__ b, u32 *__restrict__ c,
+                                                          const u32 *__restrict__ tw_fwd, const u32 *__restrict__ tw_inv, unsigned lg,
+                                                          unsigned ns, const u32 *__restrict__ zinv_rr) {
+    MG_PRIO_WM();
+    extern __shared__ __attribute__((aligned(16))) u32 sm[];
+    typedef FpR<FrC> R;
+    constexpr int K = R::K;
+    const u32 E = 1u << ns, lo_bits = lg - ns, s0 = lo_bits + 1, lo_base = blockIdx.x;
+    const u32 per = blockDim.x / 3, vec = threadIdx.x / per, tid = threadIdx.x - vec * per;
+    u32 *__restrict__ data = (vec == 0 ? a : (vec == 1 ? b : c)) + ((size_t)blockIdx.z << lg) * K;
+    u32 *__restrict__ tile = sm + (size_t)vec * K * E;
+    for (u32 t = tid; t < E; t += per) {
+        const u32 *p = data + ((size_t)lo_base + ((size_t)t << lo_bits)) * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) tile[l * E + t] = p[l];
+    }
+    __syncthreads();
+    int B = 4;
+    ntt_tile_stages<FrC, false>(tile, E, ns, s0, lg, lo_bits, lo_base, tw_fwd, B, tid, per);
+    const R zinv = R::load(zinv_rr);
+    u32 *ta = sm, *tb = sm + (size_t)K * E, *tc = sm + (size_t)2 * K * E;
+    for (u32 t = threadIdx.x; t < E; t += blockDim.x) { // h = (a b - c) (g^D - 1)^-1 on the coset, < 2p
+        R x, y, z;
+#pragma unroll
+        for (int l = 0; l < K; ++l) x.v[l] = ta[l * E + t], y.v[l] = tb[l * E + t], z.v[l] = tc[l * E + t];
+        x = R::template reduce<32>(x), y = R::template reduce<32>(y), z = R::template reduce<32>(z);
+        R ab = R::mul(x, y);
+        ab = R::template sub<5>(ab, z);
+        ab = R::mul(ab, zinv);
+#pragma unroll
+        for (int l = 0; l < K; ++l) ta[l * E + t] = ab.v[l];
+    }
+    __syncthreads();
+    B = 2;
+    ntt_tile_stages<FrC, true>(ta, E, ns, s0, lg, lo_bits, lo_base, tw_inv, B, threadIdx.x, blockDim.x);
+    u32 *__restrict__ out = a + ((size_t)blockIdx.z << lg) * K;
+    for (u32 t = threadIdx.x; t < E; t += blockDim.x) {
+        R v;
+#pragma unroll
+        for (int l = 0; l < K; ++l) v.v[l] = ta[l * E + t];
+        if (B > 4) v = R::template reduce<32>(v);
+        u32 *p = out + ((size_t)lo_base + ((size_t)t << lo_bits)) * K;
+#pragma unroll
+        for (int l = 0; l < K; ++l) p[l] = v.v[l];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Round 4: the same pass with the butterflies of up to THREE consecutive stages done in REGISTERS. PMC of the kernel above
 // (profiles/r04_pmc_ntt.txt, 2^20): 394 VALU instructions per butterfly of which 171 are multiply-adds, 40 LDS instructions per
 // butterfly and bank conflicts in 54 % of the LDS-active cycles (stages whose partner distance is below 64 elements touch every
@@ -284,6 +450,7 @@ template <class FrC, bool DIF, int LR>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MG_NTT_REG_WAVES, 8))) void ntt_pass_reg(u32 *__restrict__ d0, u32 *__restrict__ d1, u32 *__restrict__ d2,
                                                    const u32 *__restrict__ tw, unsigned lg, unsigned s0, unsigned ns,
                                                    unsigned cb, const u32 *__restrict__ post, NttIo io) {
+    MG_PRIO_WM();
     extern __shared__ __attribute__((aligned(16))) u32 sm[];
     typedef FpR<FrC> R;
     constexpr int K = R::K, NE = 1 << LR;
@@ -472,6 +639,7 @@ struct Csr3 {
 template <class FrC>
 __global__ __launch_bounds__(256) void spmv3_kernel(Csr3 M, const u32 *__restrict__ z, u32 m, u32 P, size_t z_stride, size_t out_stride,
                                                     u32 rows_total) {
+    MG_PRIO_WM();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const int t = blockIdx.z;
     z += (size_t)blockIdx.y * z_stride; // batch member
@@ -508,6 +676,7 @@ template <class FrC>
 __global__ __launch_bounds__(256) void qap_pointwise_kernel(u32 *__restrict__ a, const u32 *__restrict__ b,
                                                             const u32 *__restrict__ c, const u32 *__restrict__ zinv_rr,
                                                             u32 n) {
+    MG_PRIO_WM();
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     typedef FpR<FrC> R;
@@ -798,6 +967,50 @@ template <class FrC> class FrEngineT : public FrEngine {
         const u32 n = 1u << lg;
         if (lg == 0) { // degenerate domain: h = (a b - c) / (g - 1) scaled as the general path would
             hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3(1, batch), dim3(256), 0, s, a, b, c, d->consts_rr + RK, n);
+            MG_HIP(hipGetLastError());
+            return MG_OK;
+        }
+        // single proofs (single-column tiles, two passes per transform): four fused launches instead of seven (MANTA_NTT_FUSE=0: A/B)
+        static const int fuse_on = [] { // bit 0: the low passes (ntt_fused_low), bit 1: high pass + pointwise + high pass
+            const char *e = getenv("MANTA_NTT_FUSE");
+            return e ? atoi(e) & 3 : 3;
+        }();
+        const unsigned L = lg / 2, H = lg - L; // low / high stages of every transform
+        if (fuse_on && lg >= 12 && lg <= 18 && (size_t)batch * 3 * ((size_t)n >> (H + 1)) < 512) {
+            static const bool attr_set = [] {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fused_high_pw<FrC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    3 * 36 * 512);
+                return true;
+            }();
+            (void)attr_set;
+            const NttIo none{nullptr, nullptr, nullptr, nullptr, 0u};
+            // inverse transform, high stages lg .. L + 1 (strided tiles of 2^H), a | b | c
+            hipLaunchKernelGGL((ntt_pass_rr<FrC, true>), dim3(n >> H, 3, batch), dim3(std::max(64u, (1u << H) / 2)), (size_t)(4 * RK) << H, s, a, b, c,
+                               d->tw_inv_rr, lg, L + 1, H, 0u, (const u32 *)nullptr, none);
+            // its low stages + n^-1 g^i + the forward coset transform's low stages (contiguous tiles of 2^L)
+            if (fuse_on & 1) {
+                hipLaunchKernelGGL((ntt_fused_low<FrC>), dim3(n >> L, 3, batch), dim3(std::max(64u, (1u << L) / 2)), (size_t)(4 * RK) << L, s, a, b, c,
+                                   d->tw_inv_rr, d->tw_fwd_rr, lg, L, d->t1_br_rr);
+            } else {
+                hipLaunchKernelGGL((ntt_pass_rr<FrC, true>), dim3(n >> L, 3, batch), dim3(std::max(64u, (1u << L) / 2)), (size_t)(4 * RK) << L, s, a, b, c,
+                                   d->tw_inv_rr, lg, 1u, L, 0u, d->t1_br_rr, none);
+                hipLaunchKernelGGL((ntt_pass_rr<FrC, false>), dim3(n >> L, 3, batch), dim3(std::max(64u, (1u << L) / 2)), (size_t)(4 * RK) << L, s, a, b, c,
+                                   d->tw_fwd_rr, lg, 1u, L, 0u, (const u32 *)nullptr, none);
+            }
+            // forward high stages on a, b, c + (a b - c) / Z + the last inverse transform's high stages
+            if (fuse_on & 2) {
+                hipLaunchKernelGGL((ntt_fused_high_pw<FrC>), dim3(n >> H, 1, batch), dim3(3 * std::max(64u, (1u << H) / 2)), (size_t)(3 * 4 * RK) << H, s,
+                                   a, b, c, d->tw_fwd_rr, d->tw_inv_rr, lg, H, d->consts_rr + RK);
+            } else {
+                hipLaunchKernelGGL((ntt_pass_rr<FrC, false>), dim3(n >> H, 3, batch), dim3(std::max(64u, (1u << H) / 2)), (size_t)(4 * RK) << H, s, a, b, c,
+                                   d->tw_fwd_rr, lg, L + 1, H, 0u, (const u32 *)nullptr, none);
+                hipLaunchKernelGGL((qap_pointwise_kernel<FrC>), dim3((n + 255) / 256, batch), dim3(256), 0, s, a, b, c, d->consts_rr + RK, n);
+                hipLaunchKernelGGL((ntt_pass_rr<FrC, true>), dim3(n >> H, 1, batch), dim3(std::max(64u, (1u << H) / 2)), (size_t)(4 * RK) << H, s, a, a, a,
+                                   d->tw_inv_rr, lg, L + 1, H, 0u, (const u32 *)nullptr, none);
+            }
+            // its low stages + n^-1 g^-i
+            hipLaunchKernelGGL((ntt_pass_rr<FrC, true>), dim3(n >> L, 1, batch), dim3(std::max(64u, (1u << L) / 2)), (size_t)(4 * RK) << L, s, a, a, a,
+                               d->tw_inv_rr, lg, 1u, L, 0u, d->t2_br_rr, none);
             MG_HIP(hipGetLastError());
             return MG_OK;
         }

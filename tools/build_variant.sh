@@ -9,6 +9,7 @@ make -s -j8
 mkdir -p ../lib/obj_$tag
 objs=""
 for o in ../lib/obj/*.o; do
+  [ "$(basename $o)" = "prover_diag.o" ] && continue
   b=$(basename $o .o); use=$o
   for u in "$@"; do
     if [ "$u" = "$b" ]; then
