@@ -258,6 +258,7 @@ static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, co
 MG_API int mg_msm_launch(const mg_bases *b, const uint64_t *d_scalars, size_t n, int scalar_flags, int window_bits,
                          mg_msm_job **job) {
     MG_TRY
+    HeavyOp may_allocate_no_capture_meanwhile;
     if (!b || !d_scalars || !job || n == 0 || b->sh.size() != 1) return MG_ERROR_INVALID_ARGUMENT;
     if (n > b->n) return MG_ERROR_INVALID_ARGUMENT;
     const uint64_t *one[1] = {d_scalars};
@@ -267,6 +268,7 @@ MG_API int mg_msm_launch(const mg_bases *b, const uint64_t *d_scalars, size_t n,
 MG_API int mg_msm_launch_sharded(const mg_bases *b, const uint64_t *const *d_scalars_per_shard, int scalar_flags,
                                  int window_bits, mg_msm_job **job) {
     MG_TRY
+    HeavyOp may_allocate_no_capture_meanwhile;
     if (!b || !d_scalars_per_shard || !job) return MG_ERROR_INVALID_ARGUMENT;
     for (size_t g = 0; g < b->sh.size(); ++g)
         if (!d_scalars_per_shard[g]) return MG_ERROR_INVALID_ARGUMENT;

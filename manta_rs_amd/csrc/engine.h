@@ -77,6 +77,8 @@ struct HeavyOp { // the shared side, re-entrant per thread (a failed creation de
 };
 hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
+hipStream_t stream_pool_get_normal(); // normal-priority streams: pooled and never destroyed either (runtime.cpp)
+void stream_pool_put_normal(hipStream_t s);
 const char *last_error_string();
 
 // makes `dev` the current device for a scope and restores the caller's on the way out: a host thread that drives several

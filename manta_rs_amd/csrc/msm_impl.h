@@ -1226,6 +1226,7 @@ static inline u32 cdiv(size_t a, size_t b) { return (u32)((a + b - 1) / b); }
 // to replay with a wrong fill pattern once other work had gone through the runtime (round 5: profiles/r05_linear_graph_defect.txt;
 // the runtime pre-builds the AQL packets of such graphs, its own fill kernel included). No node of the library's graphs is a
 // runtime-generated fill any more; one launch instead of two or three also shortens the chain.
+static __global__ void set_word_kernel(u32 *p, u32 v) { *p = v; }
 struct ZeroRanges {
     u32 *p[3];
     u32 n[3]; // words
@@ -2003,8 +2004,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             }
             if (!ws->d_token) {
                 const u32 one = 1;
-                MG_HIP(hipMalloc((void **)&ws->d_token, 64));
-                MG_HIP(hipMemcpy(ws->d_token, &one, 4, hipMemcpyHostToDevice));
+                // (written by a kernel on THIS stream, not by a synchronous copy: a legacy-stream operation fails with error 906
+                // while any other thread captures a stream -- tools/soak.py, round 5 -- and left the token unwritten for good)
+                (void)one;
+                u32 *tok = nullptr;
+                MG_HIP(hipMalloc((void **)&tok, 64));
+                hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, tok, 1u);
+                ws->d_token = tok;
             }
             MG_HIP(hipMemcpyAsync(ws->h_flag, ws->d_token, 4, hipMemcpyDeviceToHost, s));
         }
@@ -2236,8 +2242,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         u32 *da = nullptr, *db = nullptr, *tmp = nullptr, *dout = nullptr;
         // a stream of its own (not stream 0: a synchronous copy anywhere else in the process -- another thread creating a base
         // set, say -- would wait for this kernel, a millisecond of one-lane latency for 128-bit multipliers)
-        hipStream_t st = nullptr;
-        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        hipStream_t st = stream_pool_get_normal(); // (pooled: the library destroys no stream, runtime.cpp)
+        hipError_t e = st ? hipSuccess : hipErrorOutOfMemory;
         if (e == hipSuccess) e = hipMalloc((void **)&da, ab);
         if (e == hipSuccess) e = hipMalloc((void **)&db, bb);
         if (e == hipSuccess) e = hipMalloc((void **)&tmp, n * XW_IO * 4);
@@ -2258,7 +2264,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (st) {
             const hipError_t e2 = hipStreamSynchronize(st);
             if (e == hipSuccess) e = e2;
-            hipStreamDestroy(st);
+            stream_pool_put_normal(st);
         }
         hipFree(da);
         hipFree(db);

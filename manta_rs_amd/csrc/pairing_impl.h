@@ -298,8 +298,7 @@ template <class K> class PairingEngineT : public PairingEngine {
         }
         if (!w) {
             w = new Ws();
-            if (hipStreamCreateWithFlags(&w->s, hipStreamNonBlocking) != hipSuccess ||
-                hipStreamCreateWithFlags(&w->s2, hipStreamNonBlocking) != hipSuccess ||
+            if (!(w->s = stream_pool_get_normal()) || !(w->s2 = stream_pool_get_normal()) ||
                 hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&w->ev3, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&w->evx, hipEventDisableTiming) != hipSuccess) {

@@ -157,6 +157,14 @@ struct ProveWs {
         int prev = 0;
         hipGetDevice(&prev);
         hipSetDevice(device);
+        // nothing of this slot may still be tracked by the runtime when its graph execs, events and buffers go (tools/soak.py,
+        // round 5: a heap corruption inside the process after ~5 minutes of contexts being recycled under load)
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (hipStream_t sd : side)
+            if (sd) (void)hipStreamSynchronize(sd);
+        for (int i = 0; i < 5; ++i)
+            if (mw[i] && mw[i]->stream) (void)hipStreamSynchronize(mw[i]->stream);
+        (void)hipGetLastError();
         drop_graphs();
         for (int i = 0; i < 5; ++i)
             if (mw[i]) {
@@ -1445,6 +1453,7 @@ class ProverImpl : public Prover {
             std::atomic_thread_fence(std::memory_order_seq_cst);
         }
         if (w->timed) {
+            HeavyOp eager_passes_allocate; // (see below)
             rc = enqueue_proof(w, z_src, false);
         } else if (w->graphs_ready) {
             rc = enqueue_proof(w, z_src, graph_mode_for(w->k) == GRAPH_SPLIT);
@@ -1455,6 +1464,10 @@ class ProverImpl : public Prover {
                 w->no_graph = true;
             }
         } else {
+            // An eager pass sizes the slot's buffers (hipMalloc / hipFree / hipHostMalloc inside msm_launch and the witness map):
+            // like context creation it must not run while another thread captures (capture_mutex, engine.h) -- with contexts
+            // recycled every 2 s the soak saw 70 000 calls fail on a slot whose first pass had met a capture
+            HeavyOp eager_passes_allocate;
             rc = enqueue_proof(w, z_src, false);
             w->eager_runs++;
         }
@@ -1476,7 +1489,13 @@ class ProverImpl : public Prover {
         for (int i = 0; i < 5; ++i) {
             if (in_part_a(i) != part_a) continue;
             if (w->z3 && (i == 1 || i == 3)) continue; // part of the combined MSM on mw[0]
-            if (w->z3 && i == 0 && p.z3_folded) continue; // finish_pass_body took its results when its chain ended
+            if (w->z3 && i == 0 && p.z3_folded) { // finish_pass_body took its results when its chain ended
+                // (a linear3 slot: the combined MSM's graph runs on a stream nothing joins; its end-of-chain token has been seen, but
+                // the RUNTIME only retires a launch when its stream is waited on -- without this the stream is never synchronised
+                // in the slot's whole life and its graph exec could be destroyed with launches the runtime still tracks)
+                if (w->linear3) (void)hipStreamSynchronize(msm_stream(w, 0));
+                continue;
+            }
             if (w->z3 && i == 0 && w->mw[0]->pending) { // three results per proof: a, b_g1, l
                 if (w->linear3) { // (its graph runs on a stream of its own, joined by nothing)
                     const hipError_t e3 = hipStreamSynchronize(msm_stream(w, 0));
@@ -1812,7 +1831,7 @@ class ProverImpl : public Prover {
             hipSetDevice(ex_->shard[g]->dev_);
             if (e->d_send[g]) hipFree(e->d_send[g]);
             if (e->d_recv[g]) hipFree(e->d_recv[g]);
-            if (e->st[g]) hipStreamDestroy(e->st[g]);
+            if (e->st[g]) (void)hipStreamSynchronize(e->st[g]), stream_pool_put_normal(e->st[g]); // (pooled, never destroyed)
         }
         if (e->h_recv) hipHostFree(e->h_recv);
         delete e;
@@ -1837,7 +1856,7 @@ class ProverImpl : public Prover {
         for (size_t g = 0; g < G && ok; ++g) {
             ok = hipSetDevice(ex_->shard[g]->dev_) == hipSuccess && hipMalloc((void **)&e->d_send[g], ex_->words * 4) == hipSuccess &&
                  hipMalloc((void **)&e->d_recv[g], G * ex_->words * 4) == hipSuccess &&
-                 hipStreamCreateWithFlags(&e->st[g], hipStreamNonBlocking) == hipSuccess;
+                 (e->st[g] = stream_pool_get_normal()) != nullptr;
         }
         ok = ok && hipHostMalloc((void **)&e->h_recv, G * ex_->words * 4, hipHostMallocDefault) == hipSuccess;
         if (!ok) {

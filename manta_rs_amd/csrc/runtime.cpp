@@ -118,6 +118,36 @@ void stream_pool_put(hipStream_t s) {
     auto it = g_stream_dev.find(s);
     g_stream_pools[it == g_stream_dev.end() ? 0 : it->second].push_back(s);
 }
+// The same for the NORMAL-priority streams of MSM workspaces (the branch streams of a proof slot's forked capture) and every other
+// short-lived stream of the library: pooled, never destroyed. Round 5, tools/soak.py with a context recycled every 2 s: the engine's
+// idle pool overflowed, workspaces were deleted, their streams destroyed -- and the process died within a minute with
+// "free(): corrupted unsorted chunks" (or answered MG_ERROR_HIP under a debugger's timing): the stream-destruction defect of
+// hip::Graph::UpdateStreams described above, now reached through the workspaces. No hipStreamDestroy is left on any product path.
+static std::vector<hipStream_t> g_nstream_pools[MAX_DEVICES];
+static std::map<hipStream_t, int> g_nstream_dev;
+hipStream_t stream_pool_get_normal() {
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        std::vector<hipStream_t> &pool = g_nstream_pools[dev];
+        if (!pool.empty()) {
+            hipStream_t s = pool.back();
+            pool.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    g_nstream_dev[s] = dev;
+    return s;
+}
+void stream_pool_put_normal(hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    auto it = g_nstream_dev.find(s);
+    g_nstream_pools[it == g_nstream_dev.end() ? 0 : it->second].push_back(s);
+}
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
@@ -131,7 +161,10 @@ MsmWorkspace::~MsmWorkspace() {
     if (t1) hipEventDestroy(t1);
     if (side_fork) hipEventDestroy(side_fork);
     if (side_join) hipEventDestroy(side_join);
-    if (stream) hipStreamDestroy(stream);
+    if (stream) { // (drained, then pooled: never destroyed)
+        (void)hipStreamSynchronize(stream);
+        stream_pool_put_normal(stream);
+    }
 }
 
 MsmWorkspace *GroupEngine::ws_acquire() {
@@ -145,7 +178,7 @@ MsmWorkspace *GroupEngine::ws_acquire() {
     }
     MsmWorkspace *w = new MsmWorkspace();
     w->device = current_device();
-    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (!(w->stream = stream_pool_get_normal()) ||
         hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&w->t0) != hipSuccess || hipEventCreate(&w->t1) != hipSuccess) {
         delete w;

@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_private", "to_public", "private_transfer"), log=print):
+def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_private", "to_public", "private_transfer"), log=print,
+         mix=(1, 1, 1, 1, 2, 5, 32)):
     import numpy as np
     import oracle_lib as O
     import helpers as H
@@ -78,7 +79,7 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
             box = acquire(name)
             ctx = box.ctx
             try:
-                k = rnd.choice((1, 1, 1, 1, 2, 5, 32)) if name != "private_transfer" or rnd.random() < 0.5 else 1
+                k = rnd.choice(mix) if name != "private_transfer" or rnd.random() < 0.5 else 1
                 js = [rnd.randrange(pool) for _ in range(k)]
                 rs = s["rs"]
                 if k == 1:
@@ -91,10 +92,16 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
                     stats["single_calls" if k == 1 else "batch_calls"] += 1
                     if bad:
                         stats["mismatches"] += len(bad)
+                        g, w = got[js.index(bad[0][1])], s["want"][bad[0][1]]
+                        ev = {"shape": name, "k": k, "j": bad[0][1], "thread": tid, "gen": s["gen"], "t": round(seconds - (deadline - time.perf_counter()), 2),
+                              "elements_equal_A_B_C": [g[a:b] == w[a:b] for a, b in ((0, 32), (32, 96), (96, 128))],
+                              "equals_another_pool_proof": [jj for jj in range(pool) if g == s["want"][jj]],
+                              "A_equals_pool_A": [jj for jj in range(pool) if g[:32] == s["want"][jj][:32]]}
+                        stats.setdefault("bad_events", [])
+                        if len(stats["bad_events"]) < 12:
+                            stats["bad_events"].append(ev)
                         if stats["first_bad"] is None:
-                            g, w = got[js.index(bad[0][1])], s["want"][bad[0][1]]
-                            stats["first_bad"] = {"shape": name, "k": k, "thread": tid, "gen": s["gen"], "t": round(seconds - (deadline - time.perf_counter()), 2),
-                                                  "elements_equal_A_B_C": [g[a:b] == w[a:b] for a, b in ((0, 32), (32, 96), (96, 128))]}
+                            stats["first_bad"] = ev
             except Exception as e:  # noqa: BLE001
                 with slock:
                     stats["errors"] += 1
@@ -142,6 +149,11 @@ if __name__ == "__main__":
     secs = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
     thr = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     rec = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
-    st = soak(secs, thr, rec)
+    kw = {}
+    if os.environ.get("SOAK_SHAPES"):
+        kw["shapes"] = tuple(os.environ["SOAK_SHAPES"].split(","))
+    if os.environ.get("SOAK_MIX"):
+        kw["mix"] = tuple(int(x) for x in os.environ["SOAK_MIX"].split(","))
+    st = soak(secs, thr, rec, **kw)
     print("soak result:", st, flush=True)
     sys.exit(1 if (st["mismatches"] or st["errors"]) else 0)
