@@ -1226,7 +1226,19 @@ static inline u32 cdiv(size_t a, size_t b) { return (u32)((a + b - 1) / b); }
 // to replay with a wrong fill pattern once other work had gone through the runtime (round 5: profiles/r05_linear_graph_defect.txt;
 // the runtime pre-builds the AQL packets of such graphs, its own fill kernel included). No node of the library's graphs is a
 // runtime-generated fill any more; one launch instead of two or three also shortens the chain.
-static __global__ void set_word_kernel(u32 *p, u32 v) { *p = v; }
+// two word ranges device -> pinned host memory, a system-scope fence, then the token (msm_launch, MsmWorkspace::notify)
+static __global__ __launch_bounds__(256) void stage_and_notify_kernel(const u32 *__restrict__ src0, u32 *__restrict__ dst0, u32 n0,
+                                                                      const u32 *__restrict__ src1, u32 *__restrict__ dst1, u32 n1,
+                                                                      u32 *__restrict__ flag) {
+    for (u32 i = threadIdx.x; i < n0; i += 256) dst0[i] = src0[i];
+    for (u32 i = threadIdx.x; i < n1; i += 256) dst1[i] = src1[i];
+    __threadfence_system(); // every lane's stores are visible system-wide before it reaches the barrier ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_store_n(flag, 1u, __ATOMIC_RELEASE); // ... and the token goes last
+        __threadfence_system();
+    }
+}
 struct ZeroRanges {
     u32 *p[3];
     u32 n[3]; // words
@@ -1927,7 +1939,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = segs;
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             ws->d_tail = ws->redS.as<u32>();
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
             if (coop_tiles(segs) && rn > 1) // (rn = 1, full tables: the scan kernel has no addition to make, it converts the point)
@@ -1938,7 +1950,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = segs;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->redS.as<u32>();
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 <= 64) { // two launches: tiles, then (X, sumS) per window
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
                 (rc = ws->misc.reserve((size_t)segs * 2 * XW_IO * 4)))
@@ -1957,7 +1969,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = (size_t)segs * 2;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->misc.as<u32>();
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
             T1 = 0xffffffffu; // marks the (X, sumS) layout for msm_finish
         } else {
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
@@ -1984,35 +1996,32 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = (size_t)segs * (2 * T1 + nP);
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->misc.as<u32>();
-            MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
         if (n_extra && side) { // the plain sums ran on the side stream: join
             MG_HIP(hipEventRecord(ws->side_join, side));
             MG_HIP(hipStreamWaitEvent(s, ws->side_join, 0));
         }
-        if (n_extra)
+        if (n_extra && !ws->notify)
             MG_HIP(hipMemcpyAsync((u32 *)ws->h_stage + stage_pts * XW_IO, ws->extra.p, (size_t)n_extra * segs * XW_IO * 4,
                                   hipMemcpyDeviceToHost, s));
         ws->tail_shift = tail_shift;
         ws->n_extra = n_extra;
         for (u32 e = 0; e < n_extra; ++e) ws->extra_shift[e] = extra_shift[e];
         ws->extra_off_pts = stage_pts;
-        if (ws->notify) { // (the staged copies above are earlier commands of the same stream)
+        if (ws->notify) {
+            // The host polls *h_flag to learn that THIS chain has ended (prover.cpp finish_pass_body). Rounds 4-5 wrote the staged
+            // points with one D2H copy and the token with a second one behind it in the same stream: stream order says when each
+            // copy may START, not in which order two different dispatches' writes become visible to a host that polls memory -- the
+            // soak (tools/soak.py, distinct assignments) caught one single proof in ~10^5 whose a / l sum was read before it had
+            // arrived (A and C, or C alone, wrong; status 0). One kernel now writes the staged points to pinned memory, fences at
+            // system scope, and only then writes the token.
             if (!ws->h_flag) {
                 MG_HIP(hipHostMalloc((void **)&ws->h_flag, 64, hipHostMallocDefault));
                 *ws->h_flag = 0;
             }
-            if (!ws->d_token) {
-                const u32 one = 1;
-                // (written by a kernel on THIS stream, not by a synchronous copy: a legacy-stream operation fails with error 906
-                // while any other thread captures a stream -- tools/soak.py, round 5 -- and left the token unwritten for good)
-                (void)one;
-                u32 *tok = nullptr;
-                MG_HIP(hipMalloc((void **)&tok, 64));
-                hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, tok, 1u);
-                ws->d_token = tok;
-            }
-            MG_HIP(hipMemcpyAsync(ws->h_flag, ws->d_token, 4, hipMemcpyDeviceToHost, s));
+            hipLaunchKernelGGL(stage_and_notify_kernel, dim3(1), dim3(256), 0, s, ws->d_tail, (u32 *)ws->h_stage, (u32)(stage_pts * XW_IO),
+                               (const u32 *)ws->extra.p, (u32 *)ws->h_stage + stage_pts * XW_IO, (u32)((size_t)n_extra * segs * XW_IO), ws->h_flag);
         }
         if (!ws->capturing) MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());

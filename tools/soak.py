@@ -4,7 +4,8 @@ Three ProvingContexts (ToPrivate / ToPublic / PrivateTransfer shapes: `MultiProv
 canonical.rs:561-588) shared by six host threads (manta-pay/src/bin/simulation.rs:36-38) that mix single calls (coalesced by the library
 when they overlap) with batches of 2 / 5 / 32 proofs; a recycler thread replaces one context every few seconds (create -> set_r1cs ->
 swap in -> drain the old one -> destroy), so graphs are captured, replayed and destroyed next to other contexts' passes the whole time.
-EVERY proof is byte-compared with the CPU oracle's proof of the same (circuit, key, r, s), precomputed before the run.
+EVERY proof is byte-compared with the CPU oracle's proof of the same (circuit, key, assignment, r, s), precomputed before the run; the
+pool entries have DISTINCT assignments.
 
 usage: python tools/soak.py [seconds=600] [threads=6] [recycle_every_s=4]      -> a report on stdout, exit code 1 on any mismatch / error
 """
@@ -35,8 +36,12 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
         pk = keygen.generate(c, synth.from_mont(H.toxic(curve, seed=40 + si), synth.FR_MODULUS[curve]))
         rs = H.rand_fr_mont(curve, 2 * pool, seed=500 + si)
         rs[1][:] = 0  # one pair with r = 0 (b_g1 unused: ark-groth16 skips it)
-        want = [O.groth16_prove(c, pk, rs[j], rs[pool + j]) for j in range(pool)]
-        S[name] = {"c": c, "pk": pk, "rs": rs, "want": want, "r1cs": api.R1CS.from_circuit(c), "box": None, "gen": 0}
+        # every pool entry has its OWN satisfying assignment (fresh public inputs and witnesses): consecutive passes of a slot see
+        # different MSM results, so a pass that read a previous pass's staged data would be caught (with one z for all it could not)
+        R = synth.Reassigner(c)
+        zs = [c.z] + [R.assign(0x50AC0000 + 16 * si + j).z for j in range(1, pool)]
+        want = [O.groth16_prove(c, pk, rs[j], rs[pool + j], z=zs[j]) for j in range(pool)]
+        S[name] = {"c": c, "pk": pk, "rs": rs, "zs": zs, "want": want, "r1cs": api.R1CS.from_circuit(c), "box": None, "gen": 0}
     O.set_threads(1)
     reg = threading.Lock()
     drained = threading.Condition(reg)
@@ -83,9 +88,9 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
                 js = [rnd.randrange(pool) for _ in range(k)]
                 rs = s["rs"]
                 if k == 1:
-                    got = [api.Groth16.prove_with_randomness(ctx, s["c"].z, rs[js[0]], rs[pool + js[0]])]
+                    got = [api.Groth16.prove_with_randomness(ctx, s["zs"][js[0]], rs[js[0]], rs[pool + js[0]])]
                 else:
-                    got = api.Groth16.prove_batch(ctx, np.stack([s["c"].z] * k), rs[js], rs[[pool + j for j in js]])
+                    got = api.Groth16.prove_batch(ctx, np.stack([s["zs"][j] for j in js]), rs[js], rs[[pool + j for j in js]])
                 bad = [(name, j) for j, g in zip(js, got) if g != s["want"][j]]
                 with slock:
                     stats["proofs"] += k
