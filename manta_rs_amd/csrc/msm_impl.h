@@ -1234,7 +1234,7 @@ static __global__ __launch_bounds__(256) void stage_and_notify_kernel(const u32 
     for (u32 i = threadIdx.x; i < n1; i += 256) dst1[i] = src1[i];
     __threadfence_system(); // every lane's stores are visible system-wide before it reaches the barrier ...
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && flag) {
         __atomic_store_n(flag, 1u, __ATOMIC_RELEASE); // ... and the token goes last
         __threadfence_system();
     }
@@ -1935,11 +1935,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         u32 T1 = 0, nP = 0;
         size_t stage_pts;
         constexpr int XWM = XW > XW_IO ? XW : XW_IO;
+        // small results (every MSM of a proof) leave through stage_and_notify_kernel; large ones keep the runtime's copy
+        auto own_stage = [&](size_t pts) { return ws->notify || (pts + (size_t)n_extra * segs) * XW_IO <= 16384; };
         if (direct) { // the last merge level left the result in redS
             stage_pts = segs;
             if ((rc = stage_reserve(ws, stage_pts * XW_IO * 4))) return rc;
             ws->d_tail = ws->redS.as<u32>();
-            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!own_stage(stage_pts)) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 == 1) { // a single tile per window: its S is the window sum
             if ((rc = ws->redA.reserve((size_t)segs * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * XWM * 4))) return rc;
             if (coop_tiles(segs) && rn > 1) // (rn = 1, full tables: the scan kernel has no addition to make, it converts the point)
@@ -1950,7 +1952,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = segs;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->redS.as<u32>();
-            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!own_stage(stage_pts)) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->redS.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         } else if (T0 <= 64) { // two launches: tiles, then (X, sumS) per window
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XW * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XW * 4)) ||
                 (rc = ws->misc.reserve((size_t)segs * 2 * XW_IO * 4)))
@@ -1969,7 +1971,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = (size_t)segs * 2;
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->misc.as<u32>();
-            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!own_stage(stage_pts)) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
             T1 = 0xffffffffu; // marks the (X, sumS) layout for msm_finish
         } else {
             if ((rc = ws->redA.reserve((size_t)segs * T0 * XWM * 4)) || (rc = ws->redS.reserve((size_t)segs * T0 * XWM * 4)))
@@ -1996,32 +1998,34 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             stage_pts = (size_t)segs * (2 * T1 + nP);
             if ((rc = stage_reserve(ws, (stage_pts + (size_t)n_extra * segs) * XW_IO * 4))) return rc;
             ws->d_tail = ws->misc.as<u32>();
-            if (!ws->notify) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
+            if (!own_stage(stage_pts)) MG_HIP(hipMemcpyAsync(ws->h_stage, ws->misc.p, stage_pts * XW_IO * 4, hipMemcpyDeviceToHost, s));
         }
         if (n_extra && side) { // the plain sums ran on the side stream: join
             MG_HIP(hipEventRecord(ws->side_join, side));
             MG_HIP(hipStreamWaitEvent(s, ws->side_join, 0));
         }
-        if (n_extra && !ws->notify)
+        if (n_extra && !own_stage(stage_pts))
             MG_HIP(hipMemcpyAsync((u32 *)ws->h_stage + stage_pts * XW_IO, ws->extra.p, (size_t)n_extra * segs * XW_IO * 4,
                                   hipMemcpyDeviceToHost, s));
         ws->tail_shift = tail_shift;
         ws->n_extra = n_extra;
         for (u32 e = 0; e < n_extra; ++e) ws->extra_shift[e] = extra_shift[e];
         ws->extra_off_pts = stage_pts;
-        if (ws->notify) {
-            // The host polls *h_flag to learn that THIS chain has ended (prover.cpp finish_pass_body). Rounds 4-5 wrote the staged
+        if (own_stage(stage_pts)) {
+            // The staged points leave through a kernel of ours (no copy node of the runtime's in a captured graph), and where the host
+            // polls for the end of this chain, the same kernel raises the token. The host polls *h_flag to learn that THIS chain has ended (prover.cpp finish_pass_body). Rounds 4-5 wrote the staged
             // points with one D2H copy and the token with a second one behind it in the same stream: stream order says when each
             // copy may START, not in which order two different dispatches' writes become visible to a host that polls memory -- the
             // soak (tools/soak.py, distinct assignments) caught one single proof in ~10^5 whose a / l sum was read before it had
             // arrived (A and C, or C alone, wrong; status 0). One kernel now writes the staged points to pinned memory, fences at
             // system scope, and only then writes the token.
-            if (!ws->h_flag) {
+            if (ws->notify && !ws->h_flag) {
                 MG_HIP(hipHostMalloc((void **)&ws->h_flag, 64, hipHostMallocDefault));
                 *ws->h_flag = 0;
             }
             hipLaunchKernelGGL(stage_and_notify_kernel, dim3(1), dim3(256), 0, s, ws->d_tail, (u32 *)ws->h_stage, (u32)(stage_pts * XW_IO),
-                               (const u32 *)ws->extra.p, (u32 *)ws->h_stage + stage_pts * XW_IO, (u32)((size_t)n_extra * segs * XW_IO), ws->h_flag);
+                               (const u32 *)ws->extra.p, (u32 *)ws->h_stage + stage_pts * XW_IO, (u32)((size_t)n_extra * segs * XW_IO),
+                               ws->notify ? ws->h_flag : (u32 *)nullptr);
         }
         if (!ws->capturing) MG_HIP(hipEventRecord(ws->done, s));
         MG_HIP(hipGetLastError());
