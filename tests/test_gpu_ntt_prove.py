@@ -173,6 +173,63 @@ def test_single_proof_host_fold_variants(gpu):
         assert [ln.split()[1] for ln in out.stdout.split("\n") if ln.startswith("PROOF")] == want, knobs
 
 
+_R5_SCRIPT = '''
+import os, sys
+sys.path.insert(0, r"{root}"); sys.path.insert(0, os.path.join(r"{root}", "tests"))
+import numpy as np
+import helpers as H
+from manta_rs_amd import api as gpu, synth, keygen
+gpu.init(0)
+c = synth.make_shape(0, "to_public", profile="W")
+pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+ctx = gpu.ProvingContext(0, pk)
+ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+rs = H.rand_fr_mont(0, 4, seed=98)
+rs[2][:] = 0  # r = 0: b_g1 is not used
+z2 = synth.Reassigner(c).assign(0x5EED).z
+for i in range(5):  # eager, eager, capture, replay, replay; two assignments alternate
+    print("PROOF", gpu.Groth16.prove_with_randomness(ctx, z2 if i & 1 else c.z, rs[2 * (i & 1)], rs[2 * (i & 1) + 1]).hex())
+for rep in range(4):  # a pass of 8 (two assignments): eager, eager, capture, replay
+    got = gpu.Groth16.prove_batch(ctx, np.stack([c.z, z2] * 4), np.stack([rs[0], rs[2]] * 4), np.stack([rs[1], rs[3]] * 4))
+    print("BATCH", " ".join(g.hex() for g in got))
+'''
+
+
+def test_round5_knobs_do_not_change_results(gpu):
+    """Every environment knob added in round 5 selects between code paths that must ALL give the oracle's bytes (VERDICT r4: two
+    knobs of earlier rounds could change results; none may): three linear graphs or the forked one for a lone single proof, the
+    launch order of the three, fused / unfused witness-map passes (both halves), twiddles in LDS, the in-workgroup sum of
+    single-key MSMs (G1, G2, both, none), the two-pass sort of batched dense MSMs, the graph topology of batched passes. Single
+    proofs (eager and replayed, r = 0 included, two assignments alternating on one slot) and passes of 8; knobs are read once
+    per process, hence the children."""
+    import os
+    import subprocess
+    import sys
+    from manta_rs_amd import keygen
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = synth.make_shape(0, "to_public", profile="W")
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+    rs = H.rand_fr_mont(0, 4, seed=98)
+    rs[2][:] = 0
+    z2 = synth.Reassigner(c).assign(0x5EED).z
+    O.set_threads(O.usable_cpus())
+    two = [O.groth16_prove(c, pk, rs[0], rs[1]).hex(), O.groth16_prove(c, pk, rs[2], rs[3], z=z2).hex()]
+    want = [two[i & 1] for i in range(5)]
+    want_batch = " ".join(two * 4)
+    variants = ({}, {"MANTA_Z3_LINEAR": "0"}, {"MANTA_Z3_ORDER": "zba"}, {"MANTA_NTT_FUSE": "0"}, {"MANTA_NTT_FUSE": "1"}, {"MANTA_NTT_FUSE": "2"},
+                {"MANTA_NTT_TWL": "0", "MANTA_NTT_FUSE": "0"}, {"MANTA_ACC_SINGLE": "0"}, {"MANTA_ACC_SINGLE": "2"}, {"MANTA_ACC_SINGLE": "3"},
+                {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"})
+    for knobs in variants:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_")}
+        env.update(knobs)
+        out = subprocess.run([sys.executable, "-c", _R5_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, (knobs, out.stdout[-2000:] + out.stderr[-2000:])
+        lines = out.stdout.split("\n")
+        assert [ln.split()[1] for ln in lines if ln.startswith("PROOF")] == want, knobs
+        batches = [ln[6:] for ln in lines if ln.startswith("BATCH")]
+        assert len(batches) == 4 and all(b == want_batch for b in batches), knobs
+
+
 def test_captured_graphs_survive_other_contexts(gpu):
     """A context's captured graphs (part A forked, the G2 chain linear; passes of 1, 2, 3 and 8 proofs) must keep giving the
     oracle's bytes while OTHER contexts of the process are created, load a circuit (window tables built on the default stream,
