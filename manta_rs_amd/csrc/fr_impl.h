@@ -876,7 +876,10 @@ template <class FrC> class FrEngineT : public FrEngine {
                 const char *e = getenv("MANTA_NTT_TWL");
                 return !(e && atoi(e) == 0);
             }();
-            const bool twl = twl_on && cb == 0 && ns >= 2; // single-column tiles: twiddles staged in LDS (E entries of 36 B more)
+            // single-column tiles of a LATENCY-bound launch (one proof's witness map: <= 2 workgroups per CU): twiddles staged in LDS
+            // (E entries of 36 B more). A 2^20 transform is 1 024 workgroups per pass and throughput-bound: there the larger LDS
+            // footprint costs 8 % (0.154 -> 0.166 ms, tools/ntt_ab_r5.sh), so it keeps the per-stage gathers.
+            const bool twl = twl_on && cb == 0 && ns >= 2 && (size_t)blocks * nvec * batch <= 512;
             const size_t twl_bytes = twl ? ((size_t)(4 * RK) << ns) : 0;
             NttIo pio{p == 0 ? io.in_std : nullptr, p == 0 ? io.pre_rr : nullptr, last ? io.out_std : nullptr, last ? io.scale_rr : nullptr,
                       (pack ? (p > 0 ? 1u : 0u) | (last ? 0u : 2u) : 0u) | (twl ? 4u : 0u)};
