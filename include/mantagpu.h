@@ -90,6 +90,11 @@ int mg_last_prove_phases_ms(float out10[10]);
  * out3 = { staging z and enqueuing the pass (graph launches or ~100 kernel launches), waiting for the GPU, assembly after the
  * last MSM result arrived } in ms. A pass whose first figure approaches its wall time is bound by launches, not by kernels. */
 int mg_last_pass_host_ms(float out3[3]);
+/* Introspection: the hardware queues the library found behind the current device's streams -- out2 = { normal priority, high
+ * priority }, 0 / 0 before the first proving context exists or with MANTA_QUEUE_AWARE=0. The HIP runtime multiplexes streams onto a
+ * few hardware queues per priority level and kernels of streams that share one run one behind the other; the library measures the
+ * sharing once per device (csrc/queues.hip) and gives every single-proof slot three streams on three different queues. */
+int mg_hw_queues(int out2[2]);
 
 /* ---- variable-base MSM: replaces ark_ec::msm::VariableBaseMSM::multi_scalar_mul(bases, scalars)
  *      (ark-ec 0.3.0 msm/variable_base.rs; called 5x per proof from ark-groth16 create_proof, reached

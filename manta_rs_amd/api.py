@@ -68,7 +68,7 @@ EXPORTS = [
     "mg_vk_alpha_beta", "mg_vk_num_inputs", "mg_vk_destroy", "mg_groth16_verify", "mg_groth16_verify_batch", "mg_pairing_check", "mg_proof_decode", "mg_group_ntt",
     "mg_msm_result_to_device", "mg_xyzz_limbs", "mg_xyzz_sum", "mg_ctx_create_shard", "mg_partials_slot_limbs",
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
-    "mg_last_ntt_ms", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
+    "mg_last_ntt_ms", "mg_hw_queues", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
     "mg_ctx_opts_init", "mg_ctx_create_ex", "mg_ctx_create_from_bytes_ex", "mg_last_pass_host_ms",
 ]
 
@@ -132,6 +132,14 @@ def last_ntt_ms():
     v = (ctypes.c_float * 4)()
     _chk(LIB.mg_last_ntt_ms(v), "mg_last_ntt_ms")
     return [float(x) for x in v]
+
+
+def hw_queues():
+    """(normal-priority, high-priority) hardware queues the library found behind the current device's streams; (0, 0) before the
+    first ProvingContext of the process or with MANTA_QUEUE_AWARE=0 (mantagpu.h mg_hw_queues)"""
+    v = (ctypes.c_int * 2)()
+    _chk(LIB.mg_hw_queues(v), "mg_hw_queues")
+    return int(v[0]), int(v[1])
 
 
 def last_prove_phases_ms():

@@ -113,6 +113,12 @@ MG_API int mg_last_ntt_ms(float out4[4]) {
     get_last_ntt_ms(out4);
     return MG_SUCCESS;
 }
+MG_API int mg_hw_queues(int out2[2]) {
+    if (!out2) return MG_ERROR_INVALID_ARGUMENT;
+    out2[0] = out2[1] = 0;
+    (void)stream_queue_counts(&out2[0], &out2[1]);
+    return MG_SUCCESS;
+}
 MG_API int mg_last_pass_host_ms(float out3[3]) {
     if (!out3) return MG_ERROR_INVALID_ARGUMENT;
     get_last_pass_host_ms(out3);

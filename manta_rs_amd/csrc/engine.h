@@ -79,6 +79,19 @@ hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 hipStream_t stream_pool_get_normal(); // normal-priority streams: pooled and never destroyed either (runtime.cpp)
 void stream_pool_put_normal(hipStream_t s);
+// Queue-aware streams of a single-proof slot (queues.hip, runtime.cpp): three streams on three DIFFERENT hardware queues, chosen so
+// that slots with neighbouring ids share as few queues as the hardware has (set i: high-priority classes 2i and 2i+1 for the
+// witness map + h chain and the G2 chain, normal-priority class i -- or high-priority class 2i+2 -- for the combined MSM).
+struct StreamSet {
+    hipStream_t main = nullptr, g2 = nullptr, z3 = nullptr;
+    int id = -1, dev = 0;
+    bool z3_high = false;
+};
+bool stream_sets_ready();                            // probes the current device's queues on first use; false: disabled / failed
+int stream_queue_counts(int *normal, int *high);     // hardware queues found per priority level (0: not probed)
+bool stream_set_acquire(StreamSet &s, bool z3_high); // false: queues unknown -- use the plain pools
+void stream_set_release(StreamSet &s);
+int streams_share_queue(hipStream_t a, hipStream_t b, unsigned *mem, unsigned *token_counter); // queues.hip
 const char *last_error_string();
 
 // makes `dev` the current device for a scope and restores the caller's on the way out: a host thread that drives several

@@ -130,6 +130,8 @@ struct ProveWs {
     // node of the witness map in a packet-captured linear graph (profiles/r05_linear_graph_defect.txt), gone now. MANTA_Z3_LINEAR=0:
     // the forked graph (A/B).
     bool linear3 = false;
+    int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 linear3 beside other passes
+    StreamSet sset; // linear3 slots: three streams on three different hardware queues (runtime.cpp); id < 0: plain pooled streams
     bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
@@ -181,7 +183,10 @@ struct ProveWs {
         if (fork) hipEventDestroy(fork);
         for (auto &e : tev)
             if (e) hipEventDestroy(e);
-        if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
+        if (sset.id >= 0) {
+            if (poisoned) sset.main = sset.g2 = sset.z3 = nullptr; // (abandoned, the set id is free again)
+            stream_set_release(sset);
+        } else if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
             stream_pool_put(stream);
             stream_pool_put(side[0]);
             stream_pool_put(side[1]);
@@ -258,6 +263,7 @@ class ProverImpl : public Prover {
     u64 V_ = 0, P_ = 0, h_len_ = 0, m_ = 0;
     unsigned log_d_ = 0;
     bool have_r1cs_ = false;
+    bool sets_ok_ = false; // queue-aware stream sets available on this device (runtime.cpp)
     BaseSet *a_bs_ = nullptr, *b1_bs_ = nullptr, *b2_bs_ = nullptr, *h_bs_ = nullptr, *l_bs_ = nullptr;
     BaseSet *h_bs_wide_ = nullptr; // the h query again with wider windows, for batched passes (nullptr: same as h_bs_)
     // the z queries again with 10-bit windows for batched passes (fewer mixed additions; single proofs want the
@@ -447,6 +453,7 @@ class ProverImpl : public Prover {
         g1_ = get_engine(curve, 1);
         g2_ = get_engine(curve, 2);
         if (!fr_ || !g1_ || !g2_) return MG_ERR_ARG;
+        sets_ok_ = stream_sets_ready(); // (the caller holds HeavyOp; the first context of a device probes its hardware queues)
         V_ = pk->n_vars;
         P_ = pk->n_inputs;
         h_len_ = pk->h_len;
@@ -706,23 +713,29 @@ class ProverImpl : public Prover {
         have_r1cs_ = true;
     }
 
-    static bool lin_wanted(u32 k, bool z3, bool lone) {
-        static const bool z3_linear = [] {
+    // How a SINGLE proof's slot replays (ProveWs::linear3). 0: the forked graph. 1: three linear graphs -- witness map + h | a|b_g1|l
+    // | G2 -- on three high-priority streams: the shortest chain for a LONE proof (no other pass of this context in flight). 2: the
+    // same beside another pass, with the combined MSM on a normal-priority stream. The streams of 1 and 2 come from
+    // stream_set_acquire (runtime.cpp): three DIFFERENT hardware queues per slot, and the two flavour-2 slots that two host threads
+    // keep in flight share none -- before, which chains of the two proofs met on one queue was decided by the order in which the
+    // process had created its streams, and two threads ran at 976 or 1 364 proofs/s from process to process
+    // (profiles/r05_hw_queues.txt). A normal-priority combined MSM costs a lone proof 18 %: flavour 1 keeps it high.
+    // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 (default) every single proof.
+    int lin_flavour(u32 k, bool z3, bool lone) const {
+        static const int z3_linear = [] {
             const char *e = std::getenv("MANTA_Z3_LINEAR");
-            return !(e && std::atoi(e) == 0);
+            return e ? std::atoi(e) : 2;
         }();
-        return z3 && k == 1 && lone && z3_linear && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE;
+        if (!(z3 && k == 1 && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE)) return 0;
+        return lone ? (z3_linear >= 1 ? 1 : 0) : (z3_linear >= 2 && sets_ok_ ? 2 : 0); // (2 needs queues of its own: -18 % without)
     }
-    static u32 slot_key(u32 k, bool z3, bool lin = false) { return k | (z3 ? 1u << 16 : 0u) | (lin ? 1u << 17 : 0u); }
-    // lone: no other pass of this context is in flight -- a z3 slot then replays three linear graphs (ProveWs::linear3: the shortest
-    // chain for ONE proof); beside another pass the forked graph is kept: two proofs in flight on 2 x 3 high-priority streams lost
-    // 18 % against 2 x 1 (two host threads: 1 063-1 091 against 1 223-1 373 proofs/s, profiles/r05_single_proof_ab.txt)
+    static u32 slot_key(u32 k, bool z3, int flavour = 0) { return k | (z3 ? 1u << 16 : 0u) | ((u32)flavour << 17); }
     ProveWs *ws_acquire(u32 k = 1, bool z3 = false, bool lone = true) {
         u64 gen;
         {
             std::lock_guard<std::mutex> g(mu_);
             gen = gen_;
-            auto it = ws_free_.find(slot_key(k, z3, lin_wanted(k, z3, lone)));
+            auto it = ws_free_.find(slot_key(k, z3, lin_flavour(k, z3, lone)));
             while (it != ws_free_.end() && !it->second.empty()) {
                 ProveWs *w = it->second.back();
                 it->second.pop_back();
@@ -736,8 +749,16 @@ class ProverImpl : public Prover {
         w->z3 = z3;
         w->gen = gen;
         w->device = dev_;
-        if (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
-            !(w->side[1] = stream_pool_get()) || hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
+        static const int z3_high = [] { // A/B: the combined MSM's stream of every linear3 slot normal (0) / high (1) priority
+            const char *e = std::getenv("MANTA_Z3_HIGH");
+            return e ? std::atoi(e) : -1;
+        }();
+        w->flavour = lin_flavour(k, z3, lone);
+        if (w->flavour && stream_set_acquire(w->sset, z3_high >= 0 ? z3_high != 0 : w->flavour == 1))
+            w->stream = w->sset.main, w->side[0] = w->sset.g2, w->side[1] = w->sset.z3;
+        if ((w->sset.id < 0 && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
+                                !(w->side[1] = stream_pool_get()))) ||
+            hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->fork, hipEventDisableTiming) != hipSuccess) {
             delete w;
@@ -767,7 +788,7 @@ class ProverImpl : public Prover {
         // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
         // stream per MSM.
         w->mw[2]->run_on = w->side[0]; // the G2 MSM (the critical path) gets a high-priority stream of its own
-        if (lin_wanted(k, z3, lone)) {
+        if (w->flavour) {
             w->linear3 = true;
             w->mw[0]->run_on = w->side[1]; // the combined MSM: a high-priority pooled stream of its own
             w->mw[4]->run_on = w->stream;  // the h MSM follows the witness map on the main stream
@@ -804,7 +825,7 @@ class ProverImpl : public Prover {
                 doomed.push_back(w);
             } else {
                 w->last_use = ++lru_tick_;
-                ws_free_[slot_key(w->k, w->z3, w->linear3)].push_back(w);
+                ws_free_[slot_key(w->k, w->z3, w->flavour)].push_back(w);
                 ++idle_slots_;
                 while (idle_slots_ > MAX_IDLE_SLOTS) {
                     std::vector<ProveWs *> *from = nullptr;

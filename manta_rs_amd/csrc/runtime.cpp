@@ -142,6 +142,139 @@ hipStream_t stream_pool_get_normal() {
     g_nstream_dev[s] = dev;
     return s;
 }
+// ---- queue-aware stream sets (see queues.hip) -------------------------------------------------------------------------------
+namespace {
+struct QueueClasses {
+    std::vector<hipStream_t> rep;               // one stream of every hardware queue seen so far
+    std::vector<std::vector<hipStream_t>> idle; // pooled streams by queue
+    std::map<hipStream_t, int> cls;
+};
+struct DevQueues {
+    QueueClasses pr[2]; // 0: normal priority, 1: high priority (the two levels have hardware queues of their own)
+    std::vector<char> set_used;
+    unsigned *mem = nullptr, token = 0;
+    bool failed = false, ready = false;
+};
+DevQueues g_q[MAX_DEVICES];
+std::mutex g_q_mu;
+bool queue_aware_on() {
+    static const bool on = [] {
+        const char *e = std::getenv("MANTA_QUEUE_AWARE");
+        return !(e && std::atoi(e) == 0);
+    }();
+    return on;
+}
+hipStream_t new_stream(int pr) {
+    hipStream_t s = nullptr;
+    int lo = 0, hi = 0;
+    if (pr) {
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess)
+            return nullptr;
+    } else if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+        return nullptr;
+    return s;
+}
+// creates one stream of priority level pr, finds its queue and pools it; returns the class or -1
+int add_classified_stream(DevQueues &q, int pr) {
+    QueueClasses &c = q.pr[pr];
+    hipStream_t s = new_stream(pr);
+    if (!s) return -1;
+    int found = -1;
+    for (size_t k = 0; k < c.rep.size() && found < 0; ++k) {
+        const int r = streams_share_queue(c.rep[k], s, q.mem, &q.token);
+        if (r < 0) return -1; // (the stream is leaked: the library destroys none)
+        if (r == 1) found = (int)k;
+    }
+    if (found < 0) {
+        found = (int)c.rep.size();
+        c.rep.push_back(s);
+        c.idle.emplace_back();
+    }
+    c.cls[s] = found;
+    c.idle[found].push_back(s);
+    return found;
+}
+hipStream_t take_in_class(DevQueues &q, int pr, int want) {
+    QueueClasses &c = q.pr[pr];
+    const int n = (int)c.rep.size();
+    if (n == 0) return nullptr;
+    want %= n;
+    for (int tries = 0; c.idle[want].empty() && tries < 4 * n + 4; ++tries)
+        if (add_classified_stream(q, pr) < 0) return nullptr;
+    if (c.idle[want].empty()) return nullptr;
+    hipStream_t s = c.idle[want].back();
+    c.idle[want].pop_back();
+    return s;
+}
+void give_back(DevQueues &q, int pr, hipStream_t s) {
+    if (!s) return;
+    auto it = q.pr[pr].cls.find(s);
+    if (it != q.pr[pr].cls.end()) q.pr[pr].idle[it->second].push_back(s);
+}
+} // namespace
+// the hardware queues of the current device are known (probed on the first call: ~10 ms); false: disabled or the probe failed
+static bool sets_ready_locked(DevQueues &q) {
+    if (q.failed) return false;
+    if (!q.ready) {
+        // eight streams per level: with the runtime's least-used-queue rule that is two per hardware queue
+        q.failed = hipHostMalloc((void **)&q.mem, 64) != hipSuccess;
+        if (!q.failed) q.mem[0] = q.mem[1] = 0;
+        for (int pr = 0; pr < 2 && !q.failed; ++pr)
+            for (int i = 0; i < 8 && !q.failed; ++i) q.failed = add_classified_stream(q, pr) < 0;
+        // fewer than three high-priority queues: a slot cannot have three of its own
+        if (!q.failed) q.failed = q.pr[1].rep.size() < 3 || q.pr[0].rep.empty();
+        if (q.failed) {
+            (void)hipGetLastError();
+            return false;
+        }
+        q.ready = true;
+    }
+    return true;
+}
+bool stream_sets_ready() {
+    if (!queue_aware_on()) return false;
+    const int dev = current_device();
+    HeavyOp probes_synchronise_streams; // (not beside a capture)
+    std::lock_guard<std::mutex> g(g_q_mu);
+    return sets_ready_locked(g_q[dev]);
+}
+int stream_queue_counts(int *normal, int *high) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> g(g_q_mu);
+    if (!g_q[dev].ready) return 0;
+    *normal = (int)g_q[dev].pr[0].rep.size(), *high = (int)g_q[dev].pr[1].rep.size();
+    return 1;
+}
+bool stream_set_acquire(StreamSet &out, bool z3_high) {
+    if (!queue_aware_on()) return false;
+    const int dev = current_device();
+    HeavyOp probes_synchronise_streams;
+    std::lock_guard<std::mutex> g(g_q_mu);
+    DevQueues &q = g_q[dev];
+    if (!sets_ready_locked(q)) return false;
+    size_t id = 0;
+    while (id < q.set_used.size() && q.set_used[id]) ++id;
+    if (id == q.set_used.size()) q.set_used.push_back(0);
+    const int i = (int)id;
+    hipStream_t a = take_in_class(q, 1, 2 * i), b = take_in_class(q, 1, 2 * i + 1);
+    hipStream_t c = z3_high ? take_in_class(q, 1, 2 * i + 2) : take_in_class(q, 0, i);
+    if (!a || !b || !c) {
+        give_back(q, 1, a), give_back(q, 1, b), give_back(q, z3_high ? 1 : 0, c);
+        (void)hipGetLastError();
+        return false;
+    }
+    q.set_used[id] = 1;
+    out.main = a, out.g2 = b, out.z3 = c, out.id = i, out.dev = dev, out.z3_high = z3_high;
+    return true;
+}
+void stream_set_release(StreamSet &s) {
+    if (s.id < 0) return;
+    std::lock_guard<std::mutex> g(g_q_mu);
+    DevQueues &q = g_q[s.dev];
+    give_back(q, 1, s.main), give_back(q, 1, s.g2), give_back(q, s.z3_high ? 1 : 0, s.z3);
+    if ((size_t)s.id < q.set_used.size()) q.set_used[s.id] = 0;
+    s = StreamSet();
+}
 void stream_pool_put_normal(hipStream_t s) {
     if (!s) return;
     std::lock_guard<std::mutex> g(g_stream_mu);

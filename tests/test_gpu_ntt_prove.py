@@ -192,6 +192,14 @@ for i in range(5):  # eager, eager, capture, replay, replay; two assignments alt
 for rep in range(4):  # a pass of 8 (two assignments): eager, eager, capture, replay
     got = gpu.Groth16.prove_batch(ctx, np.stack([c.z, z2] * 4), np.stack([rs[0], rs[2]] * 4), np.stack([rs[1], rs[3]] * 4))
     print("BATCH", " ".join(g.hex() for g in got))
+import threading
+def worker(t):  # two host threads at once: single proofs beside another pass (slots of their own: eager, capture, replay)
+    for i in range(10):
+        j = (i + t) & 1
+        print("CONC %d %s" % (j, gpu.Groth16.prove_with_randomness(ctx, z2 if j else c.z, rs[2 * j], rs[2 * j + 1]).hex()), flush=True)
+ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+[t.start() for t in ts]
+[t.join() for t in ts]
 '''
 
 
@@ -199,9 +207,10 @@ def test_round5_knobs_do_not_change_results(gpu):
     """Every environment knob added in round 5 selects between code paths that must ALL give the oracle's bytes (two
     knobs of earlier rounds could change results; none may): three linear graphs or the forked one for a lone single proof, the
     launch order of the three, fused / unfused witness-map passes (both halves), twiddles in LDS, the in-workgroup sum of
-    single-key MSMs (G1, G2, both, none), the two-pass sort of batched dense MSMs, the graph topology of batched passes. Single
-    proofs (eager and replayed, r = 0 included, two assignments alternating on one slot) and passes of 8; knobs are read once
-    per process, hence the children."""
+    single-key MSMs (G1, G2, both, none), the two-pass sort of batched dense MSMs, the graph topology of batched passes, the
+    queue-aware stream sets (off; linear graphs for lone proofs only; the combined MSM's stream forced to either priority). Single
+    proofs (eager and replayed, r = 0 included, two assignments alternating on one slot), passes of 8, and single proofs from
+    two host threads at once; knobs are read once per process, hence the children."""
     import os
     import subprocess
     import sys
@@ -218,7 +227,8 @@ def test_round5_knobs_do_not_change_results(gpu):
     want_batch = " ".join(two * 4)
     variants = ({}, {"MANTA_Z3_LINEAR": "0"}, {"MANTA_Z3_ORDER": "zba"}, {"MANTA_NTT_FUSE": "0"}, {"MANTA_NTT_FUSE": "1"}, {"MANTA_NTT_FUSE": "2"},
                 {"MANTA_NTT_TWL": "0", "MANTA_NTT_FUSE": "0"}, {"MANTA_ACC_SINGLE": "0"}, {"MANTA_ACC_SINGLE": "2"}, {"MANTA_ACC_SINGLE": "3"},
-                {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"})
+                {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"}, {"MANTA_QUEUE_AWARE": "0"},
+                {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
     for knobs in variants:
         env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_")}
         env.update(knobs)
@@ -228,6 +238,8 @@ def test_round5_knobs_do_not_change_results(gpu):
         assert [ln.split()[1] for ln in lines if ln.startswith("PROOF")] == want, knobs
         batches = [ln[6:] for ln in lines if ln.startswith("BATCH")]
         assert len(batches) == 4 and all(b == want_batch for b in batches), knobs
+        conc = [ln.split() for ln in lines if ln.startswith("CONC")]
+        assert len(conc) == 20 and all(two[int(j)] == h for _, j, h in conc), knobs
 
 
 def test_captured_graphs_survive_other_contexts(gpu):
@@ -759,3 +771,32 @@ def test_witness_map_matches_oracle_across_domain_sizes(gpu, curve):
         ctx.set_r1cs(gpu.R1CS.from_circuit(c))
         assert (ctx.witness_map(c.z) == O.witness_map(c)).all(), lg
         ctx.close()
+
+
+def test_hardware_queues_are_probed_and_slots_get_their_own(gpu):
+    """Round 5: the library measures which of its streams share a hardware queue (csrc/queues.hip: a kernel on one stream waits,
+    bounded, for a word a kernel on the other writes) and gives every single-proof slot three streams on three different queues.
+    After the first ProvingContext the probe must have found the runtime's queues (GPU_MAX_HW_QUEUES, default 4, per priority
+    level; at least three high-priority ones or the sets are not used), and proofs from four threads at once -- a lone slot,
+    slots beside other passes, coalesced passes -- are the oracle's."""
+    import threading
+    from manta_rs_amd import keygen
+    c = synth.make_circuit(0, 700, 500, 9, seed=77)
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=8), synth.FR_MODULUS[0]))
+    ctx = gpu.ProvingContext(0, pk)
+    ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+    normal, high = gpu.hw_queues()
+    assert 1 <= normal <= 16 and 3 <= high <= 16, (normal, high)
+    rs = H.rand_fr_mont(0, 2, seed=99)
+    want = O.groth16_prove(c, pk, rs[0], rs[1])
+    bad = []
+
+    def worker():
+        for _ in range(12):
+            if gpu.Groth16.prove_with_randomness(ctx, c.z, rs[0], rs[1]) != want:
+                bad.append(1)
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not bad
+    ctx.close()
