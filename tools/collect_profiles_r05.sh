@@ -2,6 +2,7 @@
 # dev tool: round-5 measurement set on the GPU box -> gpurun_out/$1/ (run from the repo root)
 R=$PWD; O=$R/gpurun_out/${1:-r05set}; mkdir -p $O
 timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err
+cp $R/gpurun_out/bench_detail_n1.json $O/bench_detail.json 2>/dev/null  # (the --quick runs below write the same file again)
 cd /tmp && export TMPDIR=/tmp
 # the bench command itself under the profiler (pipelined headline, 3 MSMs in flight) and with one MSM at a time
 MANTA_BENCH_NO_PMC=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pb -o b -- python $R/bench.py --workload msm --quick --no-cpu-baseline > $O/bench_profiled.json 2>> $O/bench.err
