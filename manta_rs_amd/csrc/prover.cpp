@@ -130,7 +130,7 @@ struct ProveWs {
     // node of the witness map in a packet-captured linear graph (profiles/r05_linear_graph_defect.txt), gone now. MANTA_Z3_LINEAR=0:
     // the forked graph (A/B).
     bool linear3 = false;
-    int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 linear3 beside other passes
+    int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 / 3 linear3 beside other passes (combined / G2 MSM on the normal-priority stream)
     StreamSet sset; // linear3 slots: three streams on three different hardware queues (runtime.cpp); id < 0: plain pooled streams
     bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
@@ -714,28 +714,33 @@ class ProverImpl : public Prover {
     }
 
     // How a SINGLE proof's slot replays (ProveWs::linear3). 0: the forked graph. 1: three linear graphs -- witness map + h | a|b_g1|l
-    // | G2 -- on three high-priority streams: the shortest chain for a LONE proof (no other pass of this context in flight). 2: the
-    // same beside another pass, with the combined MSM on a normal-priority stream. The streams of 1 and 2 come from
-    // stream_set_acquire (runtime.cpp): three DIFFERENT hardware queues per slot, and the two flavour-2 slots that two host threads
-    // keep in flight share none -- before, which chains of the two proofs met on one queue was decided by the order in which the
-    // process had created its streams, and two threads ran at 976 or 1 364 proofs/s from process to process
-    // (profiles/r05_hw_queues.txt). A normal-priority combined MSM costs a lone proof 18 %: flavour 1 keeps it high.
-    // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 (default) every single proof.
-    int lin_flavour(u32 k, bool z3, bool lone) const {
+    // | G2 -- on three high-priority streams: the shortest chain for a LONE proof (company 0: no other pass of this context in
+    // flight). 2 / 3: the same beside other passes, with ONE chain on a normal-priority stream -- the combined MSM beside a batched
+    // pass (company 2), the G2 MSM beside single proofs only (company 1: two host threads). The streams come from
+    // stream_set_acquire (runtime.cpp): three DIFFERENT hardware queues per slot, and the two slots that two host threads keep in
+    // flight share none -- before, which chains of the two proofs met on one queue was decided by the order in which the process
+    // had created its streams, and two threads ran at 976 or 1 364 proofs/s from process to process (profiles/r05_hw_queues.txt).
+    // A normal-priority chain costs a lone proof 18 %: flavour 1 keeps all three high. Which chain yields beside others is measured:
+    // two threads 1 412-1 435 proofs/s with the combined MSM normal, 1 511-1 531 with the G2 MSM normal; six threads (singles beside
+    // coalesced passes) 1 794-1 898 against 1 624-1 700.
+    // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 no flavour 3, 3 (default) all of the above.
+    int lin_flavour(u32 k, bool z3, int company) const {
         static const int z3_linear = [] {
             const char *e = std::getenv("MANTA_Z3_LINEAR");
-            return e ? std::atoi(e) : 2;
+            return e ? std::atoi(e) : 3;
         }();
         if (!(z3 && k == 1 && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE)) return 0;
-        return lone ? (z3_linear >= 1 ? 1 : 0) : (z3_linear >= 2 && sets_ok_ ? 2 : 0); // (2 needs queues of its own: -18 % without)
+        if (company == 0) return z3_linear >= 1 ? 1 : 0;
+        if (!(z3_linear >= 2 && sets_ok_)) return 0; // (linear graphs beside others need queues of their own: -18 % without)
+        return company == 1 && z3_linear >= 3 ? 3 : 2;
     }
     static u32 slot_key(u32 k, bool z3, int flavour = 0) { return k | (z3 ? 1u << 16 : 0u) | ((u32)flavour << 17); }
-    ProveWs *ws_acquire(u32 k = 1, bool z3 = false, bool lone = true) {
+    ProveWs *ws_acquire(u32 k = 1, bool z3 = false, int company = 0) {
         u64 gen;
         {
             std::lock_guard<std::mutex> g(mu_);
             gen = gen_;
-            auto it = ws_free_.find(slot_key(k, z3, lin_flavour(k, z3, lone)));
+            auto it = ws_free_.find(slot_key(k, z3, lin_flavour(k, z3, company)));
             while (it != ws_free_.end() && !it->second.empty()) {
                 ProveWs *w = it->second.back();
                 it->second.pop_back();
@@ -753,9 +758,10 @@ class ProverImpl : public Prover {
             const char *e = std::getenv("MANTA_Z3_HIGH");
             return e ? std::atoi(e) : -1;
         }();
-        w->flavour = lin_flavour(k, z3, lone);
+        w->flavour = lin_flavour(k, z3, company);
         if (w->flavour && stream_set_acquire(w->sset, z3_high >= 0 ? z3_high != 0 : w->flavour == 1))
             w->stream = w->sset.main, w->side[0] = w->sset.g2, w->side[1] = w->sset.z3;
+        if (w->sset.id >= 0 && w->flavour == 3 && !w->sset.z3_high) std::swap(w->side[0], w->side[1]); // the G2 chain takes the normal-priority stream
         if ((w->sset.id < 0 && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
                                 !(w->side[1] = stream_pool_get()))) ||
             hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
@@ -1191,7 +1197,7 @@ class ProverImpl : public Prover {
     std::mutex cq_mu_;
     std::condition_variable cq_cv_;
     std::deque<Req *> cq_;
-    int cq_inflight_ = 0;
+    int cq_inflight_ = 0, cq_batched_inflight_ = 0; // passes of this context's coalescing queue on the GPU; those of more than one proof
     bool cq_gathering_ = false; // a leader is waiting for the callers of the pass that has just finished
     size_t cq_last_k_ = 1;      // size of the most recently finished pass
     static int coalesce_gather_us() {
@@ -1244,12 +1250,15 @@ class ProverImpl : public Prover {
                     batch.push_back(cq_.front());
                     cq_.pop_front();
                 }
-                const bool lone = cq_inflight_ == 0; // nothing of this context on the GPU right now
+                // what this pass runs beside: 0 nothing of this context on the GPU right now, 1 single proofs only, 2 a batched pass
+                const int company = cq_inflight_ == 0 ? 0 : (cq_batched_inflight_ == 0 ? 1 : 2);
+                const bool batched = batch.size() > 1;
                 ++cq_inflight_;
+                if (batched) ++cq_batched_inflight_;
                 lk.unlock();
                 int rc; // nothing may escape here: the followers of this batch wait on cq_cv_ for their `done`
                 try {
-                    rc = prove_gathered(batch, lone);
+                    rc = prove_gathered(batch, company);
                 } catch (const std::bad_alloc &) {
                     rc = MG_ERR_OOM;
                 } catch (...) {
@@ -1258,6 +1267,7 @@ class ProverImpl : public Prover {
                 lk.lock();
                 for (Req *q : batch) q->rc = rc, q->done = true;
                 --cq_inflight_;
+                if (batched) --cq_batched_inflight_;
                 cq_last_k_ = batch.size();
                 cq_cv_.notify_all();
                 continue;
@@ -1266,9 +1276,9 @@ class ProverImpl : public Prover {
         }
     }
     // one pass over the requests of `batch` (padded to a power of two with copies of the first one)
-    int prove_gathered(const std::vector<Req *> &batch, bool lone = true) {
+    int prove_gathered(const std::vector<Req *> &batch, int company = 0) {
         const size_t k = batch.size();
-        if (k == 1) return prove_pass(1, batch[0]->z, batch[0]->r, batch[0]->s, batch[0]->out, nullptr, lone);
+        if (k == 1) return prove_pass(1, batch[0]->z, batch[0]->r, batch[0]->s, batch[0]->out, nullptr, company);
         // pass sizes: exact up to 8 (a pass of k proofs costs ~0.65 + 0.42 k ms for the PrivateTransfer shape -- padding three
         // coalesced calls to four wastes a sixth of the pass; six signer threads produce passes of two to four), then multiples of
         // four: slots and their captured graphs exist per size, so the set of sizes stays small
@@ -1369,7 +1379,7 @@ class ProverImpl : public Prover {
         gate_cv_.notify_one();
     }
     int prove_pass(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out,
-                   const uint64_t *const *z_list = nullptr, bool lone = true) {
+                   const uint64_t *const *z_list = nullptr, int company = 0) {
         DeviceGuard restore_callers_device; // the pass visits every shard's device
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
@@ -1384,7 +1394,7 @@ class ProverImpl : public Prover {
         for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
         const auto t_enq = std::chrono::steady_clock::now();
-        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list, true, lone);
+        if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list, true, company);
         p.enqueue_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_enq).count();
         return finish_pass(p, rc, &pp);
     }
@@ -1410,11 +1420,11 @@ class ProverImpl : public Prover {
     // stage z, enqueue (or replay) the GPU side of k proofs on a slot; returns without waiting
     // (z_list: the k assignments as separate buffers -- coalesced single calls -- gathered into the slot's staging copy)
     int launch_pass(Pass &p, u32 k, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *out,
-                    const uint64_t *const *z_list = nullptr, bool whole_proof = true, bool lone = true) {
+                    const uint64_t *const *z_list = nullptr, bool whole_proof = true, int company = 0) {
         MG_HIP(hipSetDevice(dev_));
         p.k = k, p.r = r, p.s = s, p.out = out;
         // (the partials interface folds every MSM on the device by its index: it keeps the five separate MSMs)
-        ProveWs *w = p.w = ws_acquire(k, whole_proof && wants_z3(k), lone);
+        ProveWs *w = p.w = ws_acquire(k, whole_proof && wants_z3(k), company);
         if (!w) return MG_ERR_HIP;
         int rc = MG_OK;
         const size_t zbytes = (size_t)k * V_ * 32;

@@ -228,7 +228,7 @@ def test_round5_knobs_do_not_change_results(gpu):
     variants = ({}, {"MANTA_Z3_LINEAR": "0"}, {"MANTA_Z3_ORDER": "zba"}, {"MANTA_NTT_FUSE": "0"}, {"MANTA_NTT_FUSE": "1"}, {"MANTA_NTT_FUSE": "2"},
                 {"MANTA_NTT_TWL": "0", "MANTA_NTT_FUSE": "0"}, {"MANTA_ACC_SINGLE": "0"}, {"MANTA_ACC_SINGLE": "2"}, {"MANTA_ACC_SINGLE": "3"},
                 {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"}, {"MANTA_QUEUE_AWARE": "0"},
-                {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
+                {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_LINEAR": "2"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
     for knobs in variants:
         env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_")}
         env.update(knobs)
