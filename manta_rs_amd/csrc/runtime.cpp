@@ -185,10 +185,10 @@ int add_classified_stream(DevQueues &q, int pr) {
         if (r < 0) return -1; // (the stream is leaked: the library destroys none)
         if (r == 1) found = (int)k;
     }
-    if (found < 0) {
-        found = (int)c.rep.size();
+    if (found < 0) { // the first stream seen on a queue stays the library's own: later probes run on it, never inside a user's work
         c.rep.push_back(s);
         c.idle.emplace_back();
+        return (int)c.rep.size() - 1;
     }
     c.cls[s] = found;
     c.idle[found].push_back(s);
@@ -212,15 +212,15 @@ void give_back(DevQueues &q, int pr, hipStream_t s) {
     if (it != q.pr[pr].cls.end()) q.pr[pr].idle[it->second].push_back(s);
 }
 } // namespace
-// the hardware queues of the current device are known (probed on the first call: ~10 ms); false: disabled or the probe failed
+// the hardware queues of the current device are known (probed on the first call: ~20 ms); false: disabled or the probe failed
 static bool sets_ready_locked(DevQueues &q) {
     if (q.failed) return false;
     if (!q.ready) {
-        // eight streams per level: with the runtime's least-used-queue rule that is two per hardware queue
+        // twelve streams per level: with the runtime's least-used-queue rule that is three per hardware queue, one of them kept for probes
         q.failed = hipHostMalloc((void **)&q.mem, 64) != hipSuccess;
         if (!q.failed) q.mem[0] = q.mem[1] = 0;
         for (int pr = 0; pr < 2 && !q.failed; ++pr)
-            for (int i = 0; i < 8 && !q.failed; ++i) q.failed = add_classified_stream(q, pr) < 0;
+            for (int i = 0; i < 12 && !q.failed; ++i) q.failed = add_classified_stream(q, pr) < 0;
         // fewer than three high-priority queues: a slot cannot have three of its own
         if (!q.failed) q.failed = q.pr[1].rep.size() < 3 || q.pr[0].rep.empty();
         if (q.failed) {
