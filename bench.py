@@ -141,6 +141,69 @@ def host_info():
                       else "cargo and a registry exist: `cargo bench -p manta-benchmark --bench private_transfer` could be run by hand"}}
 
 
+def launch_plan(gpus, environ, argv):
+    """How `python bench.py --gpus N` gets its N ranks. -> None when this process IS a rank (N = 1, or a
+    launcher already set WORLD_SIZE: the driver's `python -m torch.distributed.run ... bench.py --gpus N`), else the command that
+    re-executes this file as N ranks on this node, one per GPU, rendezvous on 127.0.0.1 (the container hostname may not resolve)
+    with a free port of our own. Pure function of its arguments: tests/test_host.py checks the decision without a GPU."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(cmd):
+    """run the N-rank job; its rank 0 prints the one compact line on our stdout (inherited). -> exit code"""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MANTA_BENCH_LAUNCHER="self", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")  # torchrun would set 1 with a warning; the host side of a rank is a few threads
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
+def parity_gate(env):
+    """N > 1, BEFORE anything is timed: one PrivateTransfer-shape proof (BN254, same key / assignment / r, s on
+    every rank) through (a) this rank's own single-device context and (b) the range-sharded prover with the exchange the timed
+    legs use; the bytes of (b) must be identical on every rank, equal to (a), and verify. A failure ends the run before a number
+    exists."""
+    from manta_rs_amd import api, synth, keygen, distributed
+    curve = synth.BN254
+    p = synth.FR_MODULUS[curve]
+    c = synth.make_shape(curve, "private_transfer", profile="W")
+    rng = synth.XorShift(0x4D414E5441_0006)
+    pk = keygen.generate(c, [rng.field(p) for _ in range(5)])
+    rs = synth.to_mont([rng.field(p) for _ in range(2)], p, 4).reshape(2, 4)
+    r1cs = api.R1CS.from_circuit(c)
+    z = api.PinnedArray.like(c.z)
+    t0 = time.perf_counter()
+    ctx = api.ProvingContext(curve, pk, full_table_bytes=0)
+    it = iter(rs)
+    single = api.Groth16.prove(ctx, r1cs, lambda: next(it))
+    ctx.close()
+    sp = distributed.ShardedProver(curve, pk, max_batch=1)
+    sp.set_r1cs(r1cs)
+    sharded = sp.prove(z.array, rs[0], rs[1])
+    on_gpu = bool(sp.exchange.on_gpu)
+    sp.close()
+    mine = (bytes(single).hex(), bytes(sharded).hex())
+    alls = [None] * env.world
+    env.dist.all_gather_object(alls, mine)
+    if any(a != alls[0] for a in alls) or mine[0] != mine[1]:
+        raise SystemExit("bench.py parity gate: sharded proof bytes differ (rank %d: single %s... sharded %s...; ranks agree: %s)"
+                         % (env.rank, mine[0][:16], mine[1][:16], all(a == alls[0] for a in alls)))
+    vctx = api.VerifyingContext(curve, pk)
+    ok = api.groth16_verify(vctx, c.z[1:c.P], api.proof_decode(curve, sharded))
+    vctx.close()
+    if not ok:
+        raise SystemExit("bench.py parity gate: the sharded proof does not verify")
+    return {"sharded_proof_equals_single_device_on_all_ranks": True, "verified": True, "exchange_on_gpu": on_gpu,
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
 class Env:
     """Process-per-GPU plumbing: device, process group, barrier, max-over-ranks."""
 
@@ -152,17 +215,39 @@ class Env:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        assert self.world == args.gpus, f"WORLD_SIZE={self.world} but --gpus {args.gpus}"
-        # MANTA_BENCH_DEVICE pins every rank to one device (functional test of the multi-process path on a 1-GPU box)
-        self.dev = int(os.environ.get("MANTA_BENCH_DEVICE", self.local_rank))
-        self.backend = os.environ.get("MANTA_BENCH_BACKEND", "nccl")
+        if self.world != args.gpus:  # main() re-executes itself as N ranks when WORLD_SIZE is unset; a launcher that disagrees is an error
+            raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d" % (self.world, args.gpus))
+        # MANTA_BENCH_DEVICE pins every rank to one device (functional test of the multi-process path on a 1-GPU box); RCCL
+        # refuses one device twice in a clique, so that layout exchanges over gloo unless MANTA_BENCH_BACKEND says otherwise
+        pinned = os.environ.get("MANTA_BENCH_DEVICE")
+        self.dev = int(pinned) if pinned is not None else self.local_rank
+        self.backend = os.environ.get("MANTA_BENCH_BACKEND", "gloo" if pinned is not None and self.world > 1 else "nccl")
+        ndev = torch.cuda.device_count()
+        if self.dev >= ndev:
+            raise SystemExit("bench.py: rank %d wants device %d but this node shows %d GPU(s) -- --gpus N needs N visible devices "
+                             "(or MANTA_BENCH_DEVICE=<id> to stack the ranks on one device over gloo)" % (self.rank, self.dev, ndev))
         torch.cuda.set_device(self.dev)
         api.init(self.dev)
+        self.collective = {"backend": "none", "ranks": 1, "devices": [self.device_id()]}
         if self.world > 1:
             if self.backend == "nccl":
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.dev))
             else:
                 dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+            ids = [None] * self.world
+            dist.all_gather_object(ids, self.device_id())
+            # what the collective actually saw: the backend torch reports, the group's size, every DISTINCT physical device
+            self.collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "devices": sorted(set(ids)),
+                               "launcher": os.environ.get("MANTA_BENCH_LAUNCHER", "external")}
+
+    def device_id(self):
+        """a name for the PHYSICAL device this rank computes on: index + PCI bus id (two ranks stacked on one GPU report one id)"""
+        pr = self.torch.cuda.get_device_properties(self.dev)
+        bus = getattr(pr, "pci_bus_id", None)
+        dom, devn = getattr(pr, "pci_domain_id", None), getattr(pr, "pci_device_id", None)
+        if bus is None:
+            return "cuda:%d" % self.dev
+        return "cuda:%d@%04x:%02x:%02x" % (self.dev, dom or 0, bus, devn or 0)
 
     def barrier(self):
         self.api.synchronize()
@@ -1155,13 +1240,17 @@ def compact_line(full):
                                 "task_parallel_ms": _g(sp, "task_parallel", "sequential", "ms_per_proof"), "error": _g(sp, "error")}
     if full.get("errors"):
         out["errors"] = {k: str(v)[-160:] for k, v in full["errors"].items()}
+    co = full.get("collective")
+    if co:  # what the exchange actually ran on: torch's backend name, the group's size, the distinct physical devices
+        out["collective"] = {"backend": co.get("backend"), "ranks": co.get("ranks"), "devices": co.get("devices"), "launcher": co.get("launcher"),
+                             "parity_gate": None if not co.get("parity_gate") else "sharded proof == single-device proof on all ranks, verified"}
     out = _drop_none(out)
     for k in ("vs_baseline",):  # keys of the contract stay even when null
         out.setdefault(k, None)
     out["detail"] = full.get("_detail_path")
     s = json.dumps(out, separators=(",", ":"))
     if len(s) >= LINE_HARD_CAP:  # cannot happen with the fields above; if it ever does, shed the optional blocks rather than the headline
-        for k in ("strong_scaling", "sharded_proof", "hbm_copy_TBps", "verify", "ntt", "config2", "errors", "proofs"):
+        for k in ("strong_scaling", "sharded_proof", "hbm_copy_TBps", "verify", "ntt", "config2", "errors", "proofs", "collective"):
             out.pop(k, None)
             s = json.dumps(out, separators=(",", ":"))
             if len(s) < LINE_HARD_CAP:
@@ -1209,6 +1298,9 @@ def main():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)         # internal: print the proofs object only
     ap.add_argument("--batched-only", action="store_true", help=argparse.SUPPRESS)  # internal: skip the single-proof legs
     args = ap.parse_args()
+    cmd = launch_plan(args.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:  # `python bench.py --gpus N` with no launcher around it: become the launcher
+        sys.exit(self_launch(cmd))
     if args.workload == "prove" and not args.batched_only and os.environ.get("MANTA_BENCH_DISTINCT", "1") != "0":
         precompute_assignments(args.shape, 256, args.profile)  # before anything initialises HIP in this process
     env = Env(args)
@@ -1244,9 +1336,11 @@ def main():
                 raise
             errors[name] = "%s: %s" % (type(e).__name__, e)
             return None
+    gate = parity_gate(env) if env.world > 1 else None  # before anything is timed; any rank's failure ends the run
     if args.workload == "both" and not args.quick:
         proofs = leg("proofs", prove_leg_in_child, args, env)
     line, inst = msm_bench(args, env)
+    line["collective"] = dict(env.collective, parity_gate=gate) if gate else env.collective
     if args.workload == "both" and not args.quick and env.world == 1:
         inst.bases.close()  # the 2 GiB window tables: the legs below allocate their own
         line["ntt"] = leg("ntt", ntt_bench, env)

@@ -44,6 +44,26 @@ def test_two_ranks_on_one_gpu_weak_and_strong_scaling(gpu):
     assert detail["proofs"]["n_gpus"] == 2 and detail["sharded_proof"]["batched"]["proofs_per_pass"] == 32
 
 
+def test_bench_gpus_2_starts_itself(gpu):
+    """exactly `python3 bench.py --gpus 2 --steps 2 --warmup 1` -- NO launcher -- is what a driver that builds
+    its N > 1 command like its N = 1 command runs. bench.py becomes the launcher, rank 0 prints the one line as the last line of
+    stdout, and the line says what the collective saw. Both ranks sit on device 0 here (one GPU on the box), so the exchange is gloo
+    and `devices` holds ONE id; on the 8-GPU node the same path reports nccl and N ids. The parity gate (sharded PrivateTransfer
+    proof == single-device proof on every rank, verified) runs before anything is timed."""
+    env = dict(os.environ, MANTA_BENCH_DEVICE="0", MANTA_BENCH_LOGN="16")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "MANTA_BENCH_BACKEND"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.rstrip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    co = line["collective"]
+    assert co == {"backend": "gloo", "ranks": 2, "devices": co["devices"], "launcher": "self", "parity_gate": co["parity_gate"]}
+    assert len(co["devices"]) == 1 and co["devices"][0].startswith("cuda:0") and "verified" in co["parity_gate"]
+    assert line["sharded_proof"]["batched"] > 0 and line["strong_scaling"]["n_2^20"]["Mscalar_s"] > 0
+
+
 def test_world2_full_size_msm_only(gpu):
     """the BASELINE-size weak-scaling step (2 x 2^20 terms, closed-form checked) through two ranks"""
     line = _run({}, "--steps", "3", "--warmup", "1", "--quick", port="29542")

@@ -275,6 +275,9 @@ def _canned_bench_result(n_gpus=1):
                               "batched": {"proofs_per_pass": 32, "passes_in_flight": 3, "proofs_per_s": 2900.0, "ms_per_proof": 0.34},
                               "task_parallel": {"placement": "z" * 200, "sequential": {"ms_per_proof": 1.3, "proofs_per_s": 770.0}}}
         d["proofs"]["per_gpu_proofs_per_s"] = [3300.0] * n_gpus
+        d["collective"] = {"backend": "nccl", "ranks": n_gpus, "devices": ["cuda:%d@0000:%02x:00" % (i, 5 + 16 * i) for i in range(n_gpus)],
+                           "launcher": "self", "parity_gate": {"sharded_proof_equals_single_device_on_all_ranks": True, "verified": True,
+                                                               "exchange_on_gpu": True, "seconds": 9.1}}
         for k in ("ntt", "config2", "hbm_reference"):
             d.pop(k)
     return d
@@ -307,6 +310,8 @@ def test_bench_line_is_small_enough_for_the_driver(n_gpus):
     assert all(v["batched"] > 0 for v in p["witness_profiles"].values())
     if n_gpus > 1:
         assert d["sharded_proof"]["batched"] and d["strong_scaling"]["n_2^20"]["Mscalar_s"]
+        co = d["collective"]  # what the collective saw
+        assert co["backend"] == "nccl" and co["ranks"] == n_gpus and len(co["devices"]) == n_gpus and co["parity_gate"]
     else:
         assert d["ntt"]["ms"] and d["config2"]["ms"] and d["verify"]["batch_per_s"]
 
@@ -323,3 +328,26 @@ def test_bench_line_survives_missing_legs():
     full["cpu_baseline"] = None
     d = json.loads(bench.compact_line(full))
     assert d["value"] == full["value"] and "proofs" not in d and len(d["errors"]["proofs"]) <= 160 and d["roofline"]["frac"]
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python3 bench.py --gpus 8` (the shape of the driver's N = 1 command) must not die on WORLD_SIZE != N:
+    with no launcher around it bench.py re-executes itself as N ranks; under a launcher (WORLD_SIZE set) or at N = 1 it is a rank."""
+    import bench
+    assert bench.launch_plan(1, {}, ["--gpus", "1"]) is None
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, ["--gpus", "8"]) is None  # the driver's torch.distributed.run form
+    cmd = bench.launch_plan(8, {}, ["--gpus", "8", "--steps", "5", "--warmup", "2"])
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]  # the ranks see exactly the caller's flags
+
+
+def test_bench_rank_refuses_a_launcher_that_disagrees(tmp_path):
+    """WORLD_SIZE=2 with --gpus 4 is a launcher error: a one-line SystemExit naming both, not an AssertionError traceback, and
+    before any device is touched (this runs without a GPU)."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in out.stderr and "AssertionError" not in out.stderr
