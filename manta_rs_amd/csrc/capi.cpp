@@ -211,7 +211,7 @@ static void job_abandon(mg_msm_job *job) {
     DeviceGuard guard;
     for (JobShard &j : job->sh) {
         hipSetDevice(j.device);
-        hipStreamSynchronize(j.ws->stream);
+        hipStreamSynchronize(msm_stream_of(j.ws));
         if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
         j.ws->pending = 0;
         j.eng->ws_release(j.ws);
@@ -247,6 +247,9 @@ static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, co
         MsmWorkspace *ws = rc ? nullptr : s.eng->ws_acquire();
         if (!rc && !ws) rc = MG_ERROR_HIP;
         if (ws) {
+            // a stand-alone MSM: on a stream with a hardware queue of its own (engine.h MsmWorkspace::solo)
+            if (!ws->solo) ws->solo = stream_pool_get_dedicated();
+            ws->use_solo = ws->solo != nullptr;
             job->sh.push_back(JobShard{s.eng, ws, s.device, d_tmp});
             rc = s.eng->msm_launch(s.bs, d_sc, n, (scalar_flags & MG_SCALARS_MONT) ? SCALARS_MONT : SCALARS_CANONICAL, window_bits, ws, 1, 0,
                                    (scalar_flags & MG_SCALARS_SPARSE) != 0);
@@ -295,7 +298,7 @@ MG_API int mg_msm_finish(mg_msm_job *job, uint64_t *out_affine) {
         hipSetDevice(j.device);
         int rc2 = j.eng->msm_finish(j.ws, &hp);
         if (rc2) {
-            hipStreamSynchronize(j.ws->stream);
+            hipStreamSynchronize(msm_stream_of(j.ws));
             if (j.ws->side_stream) hipStreamSynchronize(j.ws->side_stream);
             j.ws->pending = 0;
         } else {
@@ -318,7 +321,7 @@ MG_API int mg_msm_result_to_device(mg_msm_job *job, uint64_t *d_out_xyzz, void *
     MG_HIP(hipSetDevice(j.device));
     int rc = j.eng->msm_fold_device(j.ws, (u32 *)d_out_xyzz, (size_t)j.eng->xyzz_words());
     if (rc) return rc;
-    hipStream_t ms = j.ws->run_on ? j.ws->run_on : j.ws->stream;
+    hipStream_t ms = msm_stream_of(j.ws);
     MG_HIP(hipEventRecord(j.ws->done, ms)); // mg_msm_finish waits for this event: now it covers the fold as well
     if ((hipStream_t)stream != ms) MG_HIP(hipStreamWaitEvent((hipStream_t)stream, j.ws->done, 0)); // NULL = the default stream
     return MG_SUCCESS;

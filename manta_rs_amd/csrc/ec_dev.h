@@ -79,12 +79,13 @@ template <int T, class F, int A> MG_DEV Bv<F, T> b_fit(const Bv<F, A> &a) {
 template <class F> struct Affine {
     F x, y;
     MG_DEV bool is_inf() const { return x.is_zero_exact() && y.is_zero_exact(); }
-    static MG_DEV Affine load(const u32 *p) { return Affine{F::load(p), F::load(p + F::N)}; }
+    // memory: x || y, each F::AFF_N words (the field's affine-coordinate format: packed 32-bit words for reduced-radix BN254)
+    static MG_DEV Affine load(const u32 *p) { return Affine{F::load_aff(p), F::load_aff(p + F::AFF_N)}; }
     MG_DEV void store(u32 *p) const {
-        x.store(p);
-        y.store(p + F::N);
+        x.store_aff(p);
+        y.store_aff(p + F::AFF_N);
     }
-    static constexpr int WORDS = 2 * F::N;
+    static constexpr int WORDS = 2 * F::AFF_N;
 };
 
 template <class F> struct XYZZ {

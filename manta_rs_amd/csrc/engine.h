@@ -79,6 +79,8 @@ hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 hipStream_t stream_pool_get_normal(); // normal-priority streams: pooled and never destroyed either (runtime.cpp)
 void stream_pool_put_normal(hipStream_t s);
+hipStream_t stream_pool_get_dedicated(); // a stream on a hardware queue of its own (MsmWorkspace::solo); nullptr: off / refused
+void stream_pool_put_dedicated(hipStream_t s);
 // Queue-aware streams of a single-proof slot (queues.hip, runtime.cpp): three streams on three DIFFERENT hardware queues, chosen so
 // that slots with neighbouring ids share as few queues as the hardware has (set i: high-priority classes 2i and 2i+1 for the
 // witness map + h chain and the G2 chain, normal-priority class i -- or high-priority class 2i+2 -- for the combined MSM).
@@ -175,12 +177,25 @@ struct MsmWorkspace {
     size_t extra_off_pts = 0;                                       // where the extras start in h_stage (points)
     const u32 *d_tail = nullptr; // device copy of what msm_launch staged for the host fold (arkworks-format XYZZ points)
     DevBuf folded;               // msm_fold_device: one arkworks-format XYZZ point per batch member
-    DevBuf clk;                  // kernel timing: (s_memtime ticks, wall-clock ticks) of the accumulate kernel's first wavefront
+    // kernel timing: (s_memtime ticks, wall-clock ticks) of the accumulate kernel's first wavefront, written by the kernel straight to
+    // page-locked HOST memory and read after the `done` event -- no copy on the NULL stream, which would order itself against every
+    // blocking stream of the process (the stand-alone MSMs' dedicated-queue streams are blocking: see `solo`)
+    unsigned long long *h_clk = nullptr;
     DevBuf scratch;              // caller-side scalars uploaded for one launch (the verifier's small MSMs)
     void *h_stage = nullptr; // pinned
     size_t h_stage_cap = 0;
     hipStream_t stream = nullptr;
     hipStream_t run_on = nullptr; // when set, msm_launch enqueues on this stream instead of the workspace's own
+    // Round 6 -- stand-alone MSMs (mg_msm_launch: no proof slot, no capture) run on a stream with a HARDWARE QUEUE OF ITS OWN. The HIP
+    // runtime multiplexes ordinary streams onto four hardware queues per priority level in creation order, kernels of streams that
+    // share a queue run one behind the other, and which of a process's streams shared one decided the pipelined 2^20 MSM rate:
+    // 317-394 Mscalar/s by the number of streams another library had created first (profiles/r05_hw_queues.txt (6)). A stream
+    // created through hipExtStreamCreateWithCUMask gets an HSA queue of its own, whatever its mask -- the mask here names every CU
+    // (profiles/r06_pipeline_phase.txt: 379-387 for every creation order). Such a stream is a BLOCKING stream (the extension takes
+    // no flags): it orders itself against NULL-stream work of the process; the library puts nothing on the NULL stream between an
+    // MSM's launch and its finish. Owned by the workspace, pooled with it, never destroyed.
+    hipStream_t solo = nullptr;
+    bool use_solo = false; // set by the stand-alone entry points for the lifetime of one job
     // stand-alone MSMs: the plain sums of the bucket reduce's front levels run here, beside the weighted chain
     hipStream_t side_stream = nullptr; // the ENGINE's side stream once this workspace has used it (not owned)
     hipEvent_t side_fork = nullptr, side_join = nullptr;
@@ -202,6 +217,11 @@ struct MsmWorkspace {
     int device = 0;
     ~MsmWorkspace();
 };
+
+// the stream an MSM of this workspace is enqueued on
+inline hipStream_t msm_stream_of(const MsmWorkspace *ws) {
+    return ws->run_on ? ws->run_on : (ws->use_solo && ws->solo ? ws->solo : ws->stream);
+}
 
 // Opaque host point (XYZZ, 64-bit limbs) big enough for G2/BLS12-381.
 struct HostPoint {

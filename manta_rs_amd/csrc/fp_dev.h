@@ -289,6 +289,9 @@ template <class C> struct Fp {
         }
         return acc;
     }
+    static constexpr int AFF_N = C::N; // affine coordinates in memory: the plain limbs (fpr_dev.h packs the reduced-radix ones)
+    static MG_DEV Fp load_aff(const u32 *p) { return load(p); }
+    MG_DEV void store_aff(u32 *p) const { store(p); }
     static MG_DEV Fp load(const u32 *p) {
         Fp r;
 #pragma unroll
@@ -350,6 +353,9 @@ template <class C> struct Fp2 {
         B u = B::mul(a.c0, a.c1);
         return Fp2{t, B::dbl(u)};
     }
+    static constexpr int AFF_N = N;
+    static MG_DEV Fp2 load_aff(const u32 *p) { return load(p); }
+    MG_DEV void store_aff(u32 *p) const { store(p); }
     static MG_DEV Fp2 load(const u32 *p) { return Fp2{B::load(p), B::load(p + C::N)}; }
     MG_DEV void store(u32 *p) const {
         c0.store(p);

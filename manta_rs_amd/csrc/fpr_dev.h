@@ -682,6 +682,25 @@ template <class C> struct FpR {
         }
         return r;
     }
+    // ---- memory format of AFFINE base coordinates (the records the accumulate kernels gather). A coordinate is < 2p with
+    // normalised limbs, so it fits the 32 N-bit packed form: BN254 G1 = 2 x 32 B = ONE aligned 64 B sector per gathered point
+    // where the 72 B limb form (96 B stride) touched two; the 18 v_alignbit/v_and of the unpacking are
+    // 0.6 % of a mixed addition's instructions. MG_PACK_AFFINE: 0 = limb form everywhere (the round-1..5 layout), 1 (default) =
+    // packed where the packed record is a whole number of 64 B sectors and smaller in sectors than the padded limb record
+    // (BN254: 64 against 96 B, G2 128 against 160 B), 2 = BLS12-381 too (96 against 128 B: fewer bytes, the same two sectors).
+#ifndef MG_PACK_AFFINE
+#define MG_PACK_AFFINE 1
+#endif
+    static constexpr bool PACK_AFF = MG_PACK_AFFINE == 2 || (MG_PACK_AFFINE == 1 && C::N == 8);
+    static constexpr int AFF_N = PACK_AFF ? C::N : K; // words per affine coordinate in memory
+    static MG_DEV FpR load_aff(const u32 *p) {
+        if constexpr (PACK_AFF) return load_packed(p);
+        else return load(p);
+    }
+    MG_DEV void store_aff(u32 *p) const {
+        if constexpr (PACK_AFF) store_packed(p);
+        else store(p);
+    }
     // limb i at p[i * stride]: LDS exchange areas keep one limb of all 64 lanes together (no bank conflicts)
     static MG_DEV FpR load_strided(const u32 *p, int stride) {
         FpR r;
@@ -866,6 +885,12 @@ template <class C> struct Fp2R {
     MG_DEV void store_strided(u32 *p, int stride) const {
         c0.store_strided(p, stride);
         c1.store_strided(p + B::N * stride, stride);
+    }
+    static constexpr int AFF_N = 2 * B::AFF_N;
+    static MG_DEV Fp2R load_aff(const u32 *p) { return Fp2R{B::load_aff(p), B::load_aff(p + B::AFF_N)}; }
+    MG_DEV void store_aff(u32 *p) const {
+        c0.store_aff(p);
+        c1.store_aff(p + B::AFF_N);
     }
     static MG_DEV Fp2R load(const u32 *p) { return Fp2R{B::load(p), B::load(p + B::N)}; }
     MG_DEV void store(u32 *p) const {

@@ -1027,8 +1027,8 @@ template <class FrC> class FrEngineT : public FrEngine {
     int work_words() const override { return RK; }
     int spmv3(const DevCsr &A, const DevCsr &B, const DevCsr &C, const u32 *d_z, u32 *d_a, u32 *d_b, u32 *d_c, u64 m, u64 P,
               hipStream_t s, u32 batch = 1, size_t z_stride = 0, size_t out_stride = 0, u64 rows_total = 0) override {
-        if (m == 0) return MG_OK;
         if (rows_total < m + P) rows_total = m + P; // (0: the caller has zeroed the vectors itself)
+        if (rows_total == 0) return MG_OK; // (m == 0 with rows to write still launches: the kernel owns the zero rows up to rows_total)
         Csr3 M{{A.row_ptr, B.row_ptr, C.row_ptr}, {A.col, B.col, C.col}, {A.val, B.val, C.val}, {d_a, d_b, d_c}};
         hipLaunchKernelGGL((spmv3_kernel<FrC>), dim3((u32)((rows_total + 255) / 256), batch, 3), dim3(256), 0, s, M, d_z, (u32)m, (u32)P,
                            z_stride, out_stride, (u32)rows_total);

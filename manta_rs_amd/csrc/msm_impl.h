@@ -953,7 +953,9 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t b0 = t * KB;
     if (b0 >= n) return;
-    // prefix products of d_k = zz*zzz (1 for infinity) are parked in the affine output's x slot
+    // prefix products of d_k = zz*zzz (1 for infinity) are parked at the front of the affine output record (F::N limb words: a
+    // record is 2 F::AFF_N >= F::N words in either format), then replaced by the record itself
+    static_assert(Affine<F>::WORDS >= F::N, "record too small to park a field element");
     F run = F::one();
     for (int k = 0; k < KB && b0 + k < n; ++k) {
         const u32 *src = xyzz + (b0 + k) * XYZZ<F>::WORDS;
@@ -970,8 +972,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
         u32 *dst = aff + (b0 + k) * astride;
         F zz = F::load(src + 2 * F::N), zzz = F::load(src + 3 * F::N);
         if (zz.is_zero_exact()) {
-            F::zero().store(dst);
-            F::zero().store(dst + F::N);
+            Affine<F>{F::zero(), F::zero()}.store(dst);
             continue;
         }
         F pre = F::load(dst);
@@ -979,8 +980,7 @@ __global__ __launch_bounds__(256) void xyzz_to_affine_batch(const u32 *__restric
         inv = F::mul(inv, F::mul(zz, zzz));
         F x = F::load(src), y = F::load(src + F::N);
         F izz = F::mul(dinv, zzz), izzz = F::mul(dinv, zz);
-        F::mul(x, izz).store(dst);
-        F::mul(y, izzz).store(dst + F::N);
+        Affine<F>{F::mul(x, izz), F::mul(y, izzz)}.store(dst); // products: < 2p, normalised -- what the packed format needs
     }
 }
 
@@ -1641,7 +1641,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
         if (bs->d_map || n > bs->n || nsets > 1) n = bs->n; // entries = stored points; the kernel zips to the shorter side
         const MsmPlan pl = plan_for(bs, n, c_override, batch);
-        hipStream_t s = ws->run_on ? ws->run_on : ws->stream;
+        hipStream_t s = msm_stream_of(ws);
         const size_t M = n * (size_t)pl.W * batch;
         // full tables: a digit addresses its summand, every pair of a scalar vector carries the same key and the "bucket" is the result
         const u32 KB = pl.full ? 1u : pl.B; // bucket keys per bucket window
@@ -1707,14 +1707,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         constexpr int XWM0 = XW > XW_IO ? XW : XW_IO;
         if (direct && ((rc = ws->redA.reserve((size_t)XWM0 * 4)) || (rc = ws->redS.reserve((size_t)XWM0 * 4)))) return rc;
         ws->timed = kernel_timing() && !ws->capturing;
-        if (ws->timed && (rc = ws->clk.reserve(64))) return rc;
+        if (ws->timed && !ws->h_clk) MG_HIP(hipHostMalloc((void **)&ws->h_clk, 64, hipHostMallocDefault));
         { // every zero-fill of this launch, up front (none of the targets is touched by the digit kernel or the sort)
             ZeroRanges zr{};
             zr.p[0] = d_count, zr.n[0] = d_count ? 1u : 0u;
             // direct: no pair at all means the sum is the point at infinity; else the buckets (+ the slot of the invalid key)
             zr.p[1] = direct ? ws->redS.as<u32>() : ws->buckets.as<u32>();
             zr.n[1] = direct ? (u32)XWM0 : (u32)((size_t)(nb + 1) * XW);
-            zr.p[2] = ws->timed ? ws->clk.as<u32>() : nullptr, zr.n[2] = ws->timed ? 4u : 0u;
+            zr.p[2] = ws->timed ? (u32 *)ws->h_clk : nullptr, zr.n[2] = ws->timed ? 4u : 0u;
             const u32 most = zr.n[1] > 4u ? zr.n[1] : 4u;
             hipLaunchKernelGGL((zero_ranges<F>), dim3(most > 256u * 1024u ? 1024u : cdiv(most, 256)), dim3(256), 0, s, zr);
         }
@@ -1803,7 +1803,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (ws->timed)
             hipLaunchKernelGGL((accumulate_chunks<F, true>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
                                svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
-                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, ws->clk.as<unsigned long long>(), adapt);
+                               ws->pkeys[0].as<u32>(), ws->ppts[0].as<u32>(), Tl, (const u32 *)d_count, ws->h_clk, adapt);
         else
             hipLaunchKernelGGL((accumulate_chunks<F, false>), dim3(cdiv(Tl, 256)), dim3(256), 0, s, skeys,
                                svals, (u32)M, Lk, invalid, bs->d_pts, (u32)AWS, ws->buckets.as<u32>(),
@@ -2056,9 +2056,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (ws->timed && !already_synced) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, ws->t0, ws->t1) == hipSuccess) set_last_accumulate_ms(ms);
-            unsigned long long ck[2] = {0, 0};
+            const unsigned long long ck[2] = {((volatile unsigned long long *)ws->h_clk)[0], ((volatile unsigned long long *)ws->h_clk)[1]};
             int khz = 0, dev = 0;
-            if (hipMemcpy(ck, ws->clk.p, 16, hipMemcpyDeviceToHost) == hipSuccess && ck[1] && hipGetDevice(&dev) == hipSuccess &&
+            if (ck[1] && hipGetDevice(&dev) == hipSuccess &&
                 hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess)
                 set_last_accumulate_mhz((float)((double)ck[0] / (double)ck[1] * (double)khz / 1e3));
         }
@@ -2117,7 +2117,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         d.kind = ws->T1 == 0xffffffffu ? 1u : (ws->T1 == 0 ? 0u : 2u);
         d.T1 = ws->T1, d.nP = ws->nP, d.segs = ws->batch, d.n_extra = ws->n_extra, d.tail_shift = ws->tail_shift;
         for (u32 e = 0; e < ws->n_extra; ++e) d.extra_shift[e] = ws->extra_shift[e];
-        hipStream_t s = on ? on : (ws->run_on ? ws->run_on : ws->stream);
+        hipStream_t s = on ? on : (msm_stream_of(ws));
         hipLaunchKernelGGL((fold_windows<F>), dim3(ws->batch), dim3(64), 0, s, d, d_out, out_stride_words);
         MG_HIP(hipGetLastError());
         return MG_OK;
@@ -2125,7 +2125,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     int msm_discard(MsmWorkspace *ws) override {
         if (!ws) return MG_ERR_STATE;
         ws->pending = 0;
-        MG_HIP(hipStreamSynchronize(ws->run_on ? ws->run_on : ws->stream));
+        MG_HIP(hipStreamSynchronize(msm_stream_of(ws)));
         return MG_OK;
     }
 

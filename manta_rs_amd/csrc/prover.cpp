@@ -32,6 +32,7 @@ const char *ncclGetErrorString(ncclResult_t result);
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -132,11 +133,12 @@ struct ProveWs {
     bool linear3 = false;
     int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 / 3 linear3 beside other passes (combined / G2 MSM on the normal-priority stream)
     StreamSet sset; // linear3 slots: three streams on three different hardware queues (runtime.cpp); id < 0: plain pooled streams
+    bool dedicated = false; // the slot's three streams have hardware queues of their own (stream_pool_get_dedicated)
     bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
     u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
-    int eager_runs = 0;
+    int eager_runs = 0, capture_tries = 0;
     bool no_graph = false;
     // kernel timing (bench.py's per-phase split of a single proof): timing events, created on first use; a timed pass is
     // enqueued eagerly -- [0] before the upload of z, [1] after it, [2] witness map done, [3 + 2i], [4 + 2i] around MSM i on
@@ -156,6 +158,10 @@ struct ProveWs {
         graphs_ready = false;
     }
     ~ProveWs() {
+        // hipFree / hipHostFree / hipGraphExecDestroy / hipEventDestroy beside another thread's stream capture invalidate that
+        // capture (error 901): like every allocating path, a slot's destruction takes the shared side of the capture lock
+        // (evicted, stale-generation and poisoned slots are deleted from proving threads)
+        HeavyOp not_beside_a_capture;
         int prev = 0;
         hipGetDevice(&prev);
         hipSetDevice(device);
@@ -173,7 +179,12 @@ struct ProveWs {
                 mw[i]->run_on = nullptr;
                 mw[i]->in_graph_slot = false;
                 mw[i]->notify = false;
-                me[i]->ws_release(mw[i]);
+                if (poisoned) { // its stream may have joined the invalidated capture: abandoned (leaked on purpose), never pooled
+                    mw[i]->stream = nullptr;
+                    delete mw[i];
+                } else {
+                    me[i]->ws_release(mw[i]);
+                }
             }
         z.release();
         a.release();
@@ -186,6 +197,8 @@ struct ProveWs {
         if (sset.id >= 0) {
             if (poisoned) sset.main = sset.g2 = sset.z3 = nullptr; // (abandoned, the set id is free again)
             stream_set_release(sset);
+        } else if (dedicated) {
+            if (!poisoned) stream_pool_put_dedicated(stream), stream_pool_put_dedicated(side[0]), stream_pool_put_dedicated(side[1]);
         } else if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
             stream_pool_put(stream);
             stream_pool_put(side[0]);
@@ -290,6 +303,8 @@ class ProverImpl : public Prover {
     mutable std::shared_mutex shape_mu_;
     u64 gen_ = 0; // bumped by every set_r1cs; a slot remembers the generation it was sized and captured for
     std::map<u32, std::vector<ProveWs *>> ws_free_; // idle proof slots, by batch size
+    std::set<u32> no_graph_keys_; // slot kinds whose capture failed for a deterministic reason: their slots stay eager (mu_)
+    static constexpr int CAPTURE_TRIES = 8; // passes that run eagerly because the capture lock was busy before build_graphs waits for it
     size_t idle_slots_ = 0;
     u64 lru_tick_ = 0;
     static constexpr size_t MAX_IDLE_SLOTS = 16; // (eight batch sizes of coalesced calls x two passes in flight) per context: beyond it the least recently used idle slot is destroyed
@@ -749,20 +764,38 @@ class ProverImpl : public Prover {
                 delete w; // sized / captured for a previous circuit
             }
         }
+        HeavyOp creates_streams_events_workspaces; // (not beside another thread's capture: ADVICE r5)
         ProveWs *w = new ProveWs();
         w->k = k;
         w->z3 = z3;
         w->gen = gen;
         w->device = dev_;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            w->no_graph = no_graph_keys_.count(slot_key(k, z3, lin_flavour(k, z3, company))) != 0; // (a capture of this kind failed for good)
+        }
         static const int z3_high = [] { // A/B: the combined MSM's stream of every linear3 slot normal (0) / high (1) priority
             const char *e = std::getenv("MANTA_Z3_HIGH");
             return e ? std::atoi(e) : -1;
         }();
         w->flavour = lin_flavour(k, z3, company);
+        static const int slot_dedicated = [] { // EXPERIMENT (round 6): linear3 slots on three dedicated hardware queues
+            const char *e = std::getenv("MANTA_SLOT_DEDICATED");
+            return e ? std::atoi(e) : 0;
+        }();
+        if (w->flavour && slot_dedicated) {
+            w->stream = stream_pool_get_dedicated(), w->side[0] = stream_pool_get_dedicated(), w->side[1] = stream_pool_get_dedicated();
+            w->dedicated = w->stream && w->side[0] && w->side[1];
+            if (!w->dedicated) {
+                stream_pool_put_dedicated(w->stream), stream_pool_put_dedicated(w->side[0]), stream_pool_put_dedicated(w->side[1]);
+                w->stream = w->side[0] = w->side[1] = nullptr;
+            }
+        }
+        if (!w->dedicated)
         if (w->flavour && stream_set_acquire(w->sset, z3_high >= 0 ? z3_high != 0 : w->flavour == 1))
             w->stream = w->sset.main, w->side[0] = w->sset.g2, w->side[1] = w->sset.z3;
         if (w->sset.id >= 0 && w->flavour == 3 && !w->sset.z3_high) std::swap(w->side[0], w->side[1]); // the G2 chain takes the normal-priority stream
-        if ((w->sset.id < 0 && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
+        if ((w->sset.id < 0 && !w->dedicated && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
                                 !(w->side[1] = stream_pool_get()))) ||
             hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
@@ -1093,11 +1126,27 @@ class ProverImpl : public Prover {
     }
 
     // capture one single-stream segment into an executable graph
+    // why the last failed capture_segment of this thread failed: true = the capture itself was invalidated / the stream cannot
+    // capture (streams that joined it are not trusted again), false = a deterministic failure (instantiation, out of memory)
+    static bool &capture_invalidated() {
+        static thread_local bool v = false;
+        return v;
+    }
     template <class Fn> static bool capture_segment(hipStream_t s, hipGraphExec_t *out, Fn &&body) {
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+        capture_invalidated() = false;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            capture_invalidated() = true; // (still capturing / invalidated from an earlier failure)
+            (void)hipGetLastError();
+            return false;
+        }
         const int rc = body();
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusActive) capture_invalidated() = true;
         hipGraph_t graph = nullptr;
         const hipError_t e = hipStreamEndCapture(s, &graph);
+        if (e == hipErrorStreamCaptureInvalidated || e == hipErrorStreamCaptureUnjoined || e == hipErrorStreamCaptureUnmatched ||
+            e == hipErrorStreamCaptureWrongThread || e == hipErrorStreamCaptureImplicit)
+            capture_invalidated() = true;
         bool ok = !rc && e == hipSuccess && graph && hipGraphInstantiate(out, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) hipGraphDestroy(graph);
         if (!ok) {
@@ -1108,12 +1157,33 @@ class ProverImpl : public Prover {
     }
     // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
     bool build_graphs(ProveWs *w) {
-        std::unique_lock<std::shared_mutex> no_heavy_ops_meanwhile(capture_mutex());
-        const bool ok = build_graphs_locked(w);
-        if (!ok) w->poisoned = true; // a capture that failed may leave streams in the invalidated state: the slot is not reused
+        // exclusive side of the capture lock, but never WAITED for at once: a context creation (seconds of table precompute on the
+        // shared side) or a stream of stand-alone MSM calls would stall this proving thread with its shape lock held (and libstdc++'s
+        // shared_mutex prefers readers). The pass runs eagerly instead and the capture is retried on a later pass; after
+        // CAPTURE_TRIES such passes it waits.
+        std::unique_lock<std::shared_mutex> no_heavy_ops_meanwhile(capture_mutex(), std::try_to_lock);
+        if (!no_heavy_ops_meanwhile.owns_lock()) {
+            if (++w->capture_tries < CAPTURE_TRIES) return false;
+            no_heavy_ops_meanwhile.lock();
+        }
+        w->capture_tries = 0;
+        bool invalidated = false;
+        const bool ok = build_graphs_locked(w, invalidated);
+        if (!ok) {
+            if (invalidated) {
+                // streams that joined an invalidated capture are not trusted again: the slot is destroyed after this pass, its
+                // streams and its workspaces' streams abandoned (~ProveWs)
+                w->poisoned = true;
+            } else {
+                // a deterministic failure (instantiation error, out of memory): destroying the slot would only repeat two eager
+                // passes, every hipMalloc and the failure on each call -- this kind of slot stays eager, here and in later slots
+                std::lock_guard<std::mutex> g(mu_);
+                no_graph_keys_.insert(slot_key(w->k, w->z3, w->flavour));
+            }
+        }
         return ok;
     }
-    bool build_graphs_locked(ProveWs *w) {
+    bool build_graphs_locked(ProveWs *w, bool &invalidated) {
         if (w->linear3) {
             const MsmArgs a = msm_args(w);
             w->mw[4]->capturing = true; // linear captures: nothing inside them waits on a `done` event
@@ -1134,6 +1204,7 @@ class ProverImpl : public Prover {
             }
             for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
             if (!ok) {
+                invalidated = capture_invalidated(); // (of the segment that failed: the chain stops at the first failure)
                 w->drop_graphs();
                 w->no_graph = true;
             }
@@ -1154,6 +1225,7 @@ class ProverImpl : public Prover {
             }
             for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
             if (!ok1) {
+                invalidated = capture_invalidated();
                 w->drop_graphs();
                 w->no_graph = true;
             }
@@ -1172,6 +1244,7 @@ class ProverImpl : public Prover {
             w->mw[i]->pending = 0;
         }
         if (!ok) {
+            invalidated = capture_invalidated();
             w->drop_graphs();
             w->no_graph = true;
         }
@@ -1445,6 +1518,7 @@ class ProverImpl : public Prover {
             }
             if (stage) {
                 if (w->h_z_cap < zbytes) {
+                    HeavyOp pinned_allocation_not_beside_a_capture;
                     if (w->h_z) hipHostFree(w->h_z);
                     w->h_z = nullptr;
                     w->h_z_cap = 0;
@@ -1461,6 +1535,7 @@ class ProverImpl : public Prover {
         }
         if (stage) {
             if (w->h_z_cap < zbytes) {
+                HeavyOp pinned_allocation_not_beside_a_capture;
                 if (w->h_z) hipHostFree(w->h_z);
                 w->h_z = nullptr;
                 w->h_z_cap = 0;

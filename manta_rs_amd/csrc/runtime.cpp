@@ -1,6 +1,7 @@
 // Common host runtime of the MI355X Groth16 hot path: error reporting, grow-only device buffers,
 // the per-engine MSM workspace pool and the (curve, group) engine registry.
 #include "engine.h"
+#include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,6 +143,74 @@ hipStream_t stream_pool_get_normal() {
     g_nstream_dev[s] = dev;
     return s;
 }
+// ---- streams on hardware queues of their own (engine.h MsmWorkspace::solo)
+static std::vector<hipStream_t> g_dstream_pools[MAX_DEVICES];
+static std::map<hipStream_t, int> g_dstream_dev;
+static bool g_dstream_refused[MAX_DEVICES] = {};
+hipStream_t stream_pool_get_dedicated() {
+    static const bool on = [] { // MANTA_MSM_DEDICATED_QUEUES=0: the workspace's ordinary pooled stream (A/B, and for hosts that need
+        const char *e = std::getenv("MANTA_MSM_DEDICATED_QUEUES"); // non-blocking semantics against their own NULL-stream work)
+        return !(e && std::atoi(e) == 0);
+    }();
+    if (!on) return nullptr;
+    const int dev = current_device();
+    {
+        std::lock_guard<std::mutex> g(g_stream_mu);
+        if (g_dstream_refused[dev]) return nullptr;
+        std::vector<hipStream_t> &pool = g_dstream_pools[dev];
+        if (!pool.empty()) {
+            hipStream_t s = pool.back();
+            pool.pop_back();
+            return s;
+        }
+    }
+    // The runtime's pool of shared normal-priority hardware queues must be FULL before the first dedicated queue exists: a process
+    // that has created fewer ordinary streams than the pool holds (GPU_MAX_HW_QUEUES, default 4) otherwise finds the dedicated queue
+    // counted as a pool member, and later ordinary streams -- the NULL stream included -- are multiplexed onto it (measured: 316
+    // Mscalar/s in a process with no foreign stream, 379-387 with two or more: profiles/r06_pipeline_phase.txt). Four ordinary
+    // streams are created once per device and kept in the library's normal-priority pool.
+    {
+        static std::mutex prime_mu;
+        static bool primed[MAX_DEVICES] = {};
+        std::lock_guard<std::mutex> g(prime_mu);
+        if (!primed[dev]) {
+            primed[dev] = true;
+            const char *e = std::getenv("GPU_MAX_HW_QUEUES");
+            int nq = e ? std::atoi(e) : 4;
+            nq = nq < 1 ? 4 : (nq > 16 ? 16 : nq);
+            std::vector<hipStream_t> fill;
+            for (int i = 0; i < nq; ++i) {
+                hipStream_t f = nullptr;
+                if (hipStreamCreateWithFlags(&f, hipStreamNonBlocking) != hipSuccess) break;
+                fill.push_back(f);
+            }
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> g2(g_stream_mu);
+            for (hipStream_t f : fill) g_nstream_dev[f] = dev, g_nstream_pools[dev].push_back(f);
+        }
+    }
+    int cus = 0;
+    hipStream_t s = nullptr;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u); // every CU: the point is the queue, not the mask
+        for (int b = 0; b < cus; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+        if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) s = nullptr;
+    }
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    if (!s) {
+        (void)hipGetLastError();
+        g_dstream_refused[dev] = true; // (not asked again: the MSMs use their ordinary streams)
+        return nullptr;
+    }
+    g_dstream_dev[s] = dev;
+    return s;
+}
+void stream_pool_put_dedicated(hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> g(g_stream_mu);
+    auto it = g_dstream_dev.find(s);
+    g_dstream_pools[it == g_dstream_dev.end() ? 0 : it->second].push_back(s);
+}
 // ---- queue-aware stream sets (see queues.hip) -------------------------------------------------------------------------------
 namespace {
 struct QueueClasses {
@@ -154,7 +223,9 @@ struct DevQueues {
     std::vector<char> set_used;
     unsigned *mem = nullptr, token = 0;
     bool failed = false, ready = false;
+    int probes = 0;
 };
+constexpr int PROBE_RETRIES = 4;
 DevQueues g_q[MAX_DEVICES];
 std::mutex g_q_mu;
 bool queue_aware_on() {
@@ -217,14 +288,20 @@ static bool sets_ready_locked(DevQueues &q) {
     if (q.failed) return false;
     if (!q.ready) {
         // twelve streams per level: with the runtime's least-used-queue rule that is three per hardware queue, one of them kept for probes
-        q.failed = hipHostMalloc((void **)&q.mem, 64) != hipSuccess;
-        if (!q.failed) q.mem[0] = q.mem[1] = 0;
+        if (!q.mem) {
+            q.failed = hipHostMalloc((void **)&q.mem, 64) != hipSuccess;
+            if (!q.failed) q.mem[0] = q.mem[1] = 0;
+        }
         for (int pr = 0; pr < 2 && !q.failed; ++pr)
             for (int i = 0; i < 12 && !q.failed; ++i) q.failed = add_classified_stream(q, pr) < 0;
         // fewer than three high-priority queues: a slot cannot have three of its own
         if (!q.failed) q.failed = q.pr[1].rep.size() < 3 || q.pr[0].rep.empty();
         if (q.failed) {
             (void)hipGetLastError();
+            // not latched for the life of the process: a probe that ran on a busy GPU (fewer than three high-priority classes
+            // seen) is repeated by a later context, at most PROBE_RETRIES times (the streams of a failed probe stay in the classes
+            // they were put in; the library destroys none)
+            if (++q.probes < PROBE_RETRIES) q.failed = false;
             return false;
         }
         q.ready = true;
@@ -284,10 +361,15 @@ void stream_pool_put_normal(hipStream_t s) {
 
 MsmWorkspace::~MsmWorkspace() {
     DevBuf *all[] = {&keys_in, &keys_out, &vals_in, &vals_out, &sort_tmp, &buckets, &pkeys[0], &pkeys[1],
-                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch, &clk};
+                     &ppts[0], &ppts[1], &redA,     &redS,    &misc, &count, &front, &extra, &folded, &scratch};
     for (DevBuf *b : all) b->release();
     if (h_stage) hipHostFree(h_stage);
     if (h_flag) hipHostFree(h_flag);
+    if (h_clk) hipHostFree(h_clk);
+    if (solo) { // (drained, then pooled: never destroyed)
+        (void)hipStreamSynchronize(solo);
+        stream_pool_put_dedicated(solo);
+    }
     if (d_token) hipFree(d_token);
     if (done) hipEventDestroy(done);
     if (t0) hipEventDestroy(t0);
@@ -323,6 +405,7 @@ MsmWorkspace *GroupEngine::ws_acquire() {
 // freed), so HBM held for past MSM sizes / dropped contexts does not accumulate.
 void GroupEngine::ws_release(MsmWorkspace *w) {
     if (!w) return;
+    w->use_solo = false;
     {
         std::lock_guard<std::mutex> g(ws_mu_);
         if (ws_free_.size() < MAX_IDLE_WS) {
