@@ -260,14 +260,68 @@ int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
  *   full_table_bytes  HBM this context may spend on FULL tables of its five queries together (single proofs run on them:
  *                     no sort, no bucket reduce on their latency chain), per device: the widest windows that fit are chosen,
  *                     0 = none (bucket tables only), negative = the default, a tenth of the device's HBM (28.8 GB on an
- *                     MI355X: three contexts use 30 %). Never more than 40 % of what is free at creation. The environment
- *                     variable MANTA_FULL_TABLE_GB, when set, overrides it (GB per context).
+ *                     MI355X: three contexts use 30 %). Never more than 40 % of what is free at creation. Negative: the tuning's
+ *                     full_table_bytes applies (where MANTA_FULL_TABLE_GB lands), else the default.
  *   devices/n_devices range-shard every MSM over these devices inside this process (mg_ctx_create_sharded)
  *   shard/n_shards    this process holds one slice (mg_ctx_create_shard); n_shards <= 1: the whole key
  *   task_mask         mg_ctx_create_task; 0 or 0x1f: all five MSMs
  * At most one of the three placements may be used. */
 #define MG_EXCHANGE_HOST 0u
 #define MG_EXCHANGE_RCCL 1u
+/* ---- tuning: everything a DEPLOYMENT decides about how the library schedules its work, as one struct (none of it changes a
+ *      result -- tests/test_gpu_profiles.py proves every field and every environment name below leaves proof bytes unchanged).
+ *      Reference counterpart: `ProvingContext` carries no tuning at all (manta-crypto/src/arkworks/groth16.rs:216-245): the
+ *      arkworks prover has one schedule; this struct is what the GPU path adds next to it. A Rust host fills it once
+ *      (rust/mantagpu-sys mirrors it) instead of exporting environment variables. Process-wide values: mg_get_tuning /
+ *      mg_set_tuning (contexts copy them when they are created); per context: mg_ctx_opts.tuning.
+ *      The shipped library reads the environment in ONE place, once, as the initial process-wide values -- the 14 variables of
+ *      mg_tuning_env_names() (plus MANTA_RCCL_LIB, the path of librccl.so): MANTA_GRAPH (single | split | off),
+ *      MANTA_GRAPH_BATCH, MANTA_PROVE_STREAMS, MANTA_Z3_LINEAR, MANTA_COALESCE, MANTA_COALESCE_GATHER_US, MANTA_BATCH_INFLIGHT,
+ *      MANTA_QUEUE_AWARE, MANTA_MSM_DEDICATED_QUEUES, MANTA_PROVE_C / _CW / _CH / _CG2, MANTA_FULL_TABLE_GB. Every other knob of
+ *      the measurement campaigns is compiled in at its measured optimum (a unit rebuilt with -DMG_DIAG reads it again).
+ *   struct_size           sizeof(mg_tuning), written by mg_tuning_init / mg_get_tuning
+ *   graph_mode            replay of a pass's GPU side as hipGraphs: 1 = two graphs per pass (default), 2 = six single-stream graphs,
+ *                         0 = eager launches
+ *   graph_mode_batch      the same for passes of >= 4 proofs; -1 = as graph_mode
+ *   prove_streams         streams of a forked pass: 3, 4, 5 or 6 (default)
+ *   linear_chains         single proofs as three linear graphs on three hardware queues: 0 never, 1 a lone proof only, 2 also
+ *                         beside other passes, 3 (default) the same with the yielding chain chosen by what the proof runs beside
+ *   coalesce_inflight     passes of coalesced concurrent mg_groth16_prove calls on the GPU: 0 = no coalescing, default 2, <= 4
+ *   coalesce_gather_us    how long the leader of such a pass waits for the callers of the pass that has just ended (default 100)
+ *   batch_inflight        passes of one mg_groth16_prove_batch call in flight (default 3)
+ *   queue_aware           1 (default): single-proof slots get streams on measured hardware queues; 0: plain pooled streams
+ *   msm_dedicated_queues  1 (default): a stand-alone MSM (mg_msm_launch) runs on a stream with a hardware queue of its own, which
+ *                         makes its pipelined rate independent of the streams the rest of the process created; such streams
+ *                         are BLOCKING streams (they order themselves against the host's NULL-stream work). 0: ordinary streams
+ *   window_bits_*         window widths of a context's key tables, 0 = the library's choice: narrow = the latency tables of
+ *                         a / b_g1 / l (setting it forces ONE width for every bucket table and leaves the full and wide tables
+ *                         out), wide = the batched-pass tables, h = the h query, g2 = b_g2
+ *   full_table_bytes      default HBM budget of a context's full tables (mg_ctx_opts.full_table_bytes >= 0 takes precedence);
+ *                         -1 = a tenth of the device's HBM, 0 = none */
+typedef struct mg_tuning {
+    uint32_t struct_size;
+    int32_t graph_mode;
+    int32_t graph_mode_batch;
+    int32_t prove_streams;
+    int32_t linear_chains;
+    int32_t coalesce_inflight;
+    int32_t coalesce_gather_us;
+    int32_t batch_inflight;
+    int32_t queue_aware;
+    int32_t msm_dedicated_queues;
+    int32_t window_bits_narrow;
+    int32_t window_bits_wide;
+    int32_t window_bits_h;
+    int32_t window_bits_g2;
+    int64_t full_table_bytes;
+} mg_tuning;
+int mg_tuning_init(mg_tuning *t);      /* the compiled-in defaults (no environment) */
+int mg_get_tuning(mg_tuning *t);       /* the process-wide values in force */
+int mg_set_tuning(const mg_tuning *t); /* validated as a whole (MG_ERROR_INVALID_ARGUMENT leaves everything as it was); contexts
+                                          created afterwards use it, the environment no longer applies */
+/* NULL-terminated list of the environment variables the shipped library reads (the tuning table + MANTA_RCCL_LIB) */
+const char *const *mg_tuning_env_names(void);
+
 typedef struct mg_ctx_opts {
     uint32_t struct_size;
     uint32_t exchange;
@@ -276,6 +330,7 @@ typedef struct mg_ctx_opts {
     int32_t n_devices;
     int32_t shard, n_shards;
     uint32_t task_mask;
+    const mg_tuning *tuning; /* this context's tuning (read during the call); NULL = the process-wide values */
 } mg_ctx_opts;
 int mg_ctx_opts_init(mg_ctx_opts *opts); /* defaults: host exchange, default table budget, current device, whole key */
 int mg_ctx_create_ex(mg_curve_t curve, const mg_pk_view *pk, const mg_ctx_opts *opts /* NULL = defaults */, mg_ctx **out);

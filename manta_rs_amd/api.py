@@ -70,6 +70,7 @@ EXPORTS = [
     "mg_groth16_partials_launch", "mg_groth16_partials_finish", "mg_groth16_assemble", "mg_blake3", "mg_ctx_create_from_bytes_checked",
     "mg_last_ntt_ms", "mg_hw_queues", "mg_last_prove_phases_ms", "mg_clock_probe", "mg_last_accumulate_mhz", "mg_ctx_create_task",
     "mg_ctx_opts_init", "mg_ctx_create_ex", "mg_ctx_create_from_bytes_ex", "mg_last_pass_host_ms",
+    "mg_tuning_init", "mg_get_tuning", "mg_set_tuning", "mg_tuning_env_names",
 ]
 
 
@@ -526,14 +527,67 @@ def groth16_setup(r1cs: "R1CS", n_vars, toxic_mont, g1_generator, g2_generator) 
 EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1
 
 
+class Tuning(ctypes.Structure):
+    """`mg_tuning` (include/mantagpu.h): what a deployment decides about the library's scheduling -- process-wide through
+    get_tuning / set_tuning, per context through ProvingContext(tuning=...). No field changes a result."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("graph_mode", ctypes.c_int32), ("graph_mode_batch", ctypes.c_int32),
+                ("prove_streams", ctypes.c_int32), ("linear_chains", ctypes.c_int32), ("coalesce_inflight", ctypes.c_int32),
+                ("coalesce_gather_us", ctypes.c_int32), ("batch_inflight", ctypes.c_int32), ("queue_aware", ctypes.c_int32),
+                ("msm_dedicated_queues", ctypes.c_int32), ("window_bits_narrow", ctypes.c_int32), ("window_bits_wide", ctypes.c_int32),
+                ("window_bits_h", ctypes.c_int32), ("window_bits_g2", ctypes.c_int32), ("full_table_bytes", ctypes.c_int64)]
+
+    def replace(self, **kw):
+        t = Tuning.from_buffer_copy(bytes(self))
+        for k, v in kw.items():
+            if k not in dict(Tuning._fields_) or k == "struct_size":
+                raise ValueError("mg_tuning has no field %r" % k)
+            setattr(t, k, int(v))
+        return t
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in Tuning._fields_ if k != "struct_size"}
+
+
+GRAPH_OFF, GRAPH_SINGLE, GRAPH_SPLIT = 0, 1, 2
+
+
+def tuning_defaults() -> Tuning:
+    t = Tuning()
+    _chk(LIB.mg_tuning_init(ctypes.byref(t)), "mg_tuning_init")
+    assert t.struct_size == ctypes.sizeof(Tuning), "mg_tuning: the Python mirror is out of date"
+    return t
+
+
+def get_tuning() -> Tuning:
+    t = Tuning()
+    _chk(LIB.mg_get_tuning(ctypes.byref(t)), "mg_get_tuning")
+    return t
+
+
+def set_tuning(t: Tuning = None, **kw):
+    """process-wide tuning for contexts created from now on: a whole struct, or keyword changes to the values in force"""
+    t = (t if t is not None else get_tuning()).replace(**kw)
+    _chk(LIB.mg_set_tuning(ctypes.byref(t)), "mg_set_tuning")
+
+
+def tuning_env_names() -> list:
+    """the environment variables the shipped library reads (mg_tuning_env_names)"""
+    LIB.mg_tuning_env_names.restype = ctypes.POINTER(ctypes.c_char_p)
+    arr, out, i = LIB.mg_tuning_env_names(), [], 0
+    while arr[i]:
+        out.append(arr[i].decode())
+        i += 1
+    return out
+
+
 class _CtxOpts(ctypes.Structure):
     """`mg_ctx_opts` (include/mantagpu.h)"""
     _fields_ = [("struct_size", ctypes.c_uint32), ("exchange", ctypes.c_uint32), ("full_table_bytes", ctypes.c_int64),
                 ("devices", ctypes.POINTER(ctypes.c_int)), ("n_devices", ctypes.c_int32), ("shard", ctypes.c_int32),
-                ("n_shards", ctypes.c_int32), ("task_mask", ctypes.c_uint32)]
+                ("n_shards", ctypes.c_int32), ("task_mask", ctypes.c_uint32), ("tuning", ctypes.POINTER(Tuning))]
 
 
-def _ctx_opts(devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None):
+def _ctx_opts(devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None, tuning=None):
     """-> (mg_ctx_opts, keep-alive) from the keyword arguments of ProvingContext"""
     o = _CtxOpts()
     _chk(LIB.mg_ctx_opts_init(ctypes.byref(o)), "mg_ctx_opts_init")
@@ -550,6 +604,11 @@ def _ctx_opts(devices=None, shard=None, task_mask=None, full_table_bytes=None, e
         o.full_table_bytes = int(full_table_bytes)
     if exchange is not None:
         o.exchange = int(exchange)
+    if tuning is not None:
+        if isinstance(tuning, dict):
+            tuning = get_tuning().replace(**tuning)
+        o.tuning = ctypes.pointer(tuning)
+        keep = (keep, tuning)
     return o, keep
 
 
@@ -557,7 +616,7 @@ class ProvingContext:
     """Mirror of groth16::ProvingContext<E> (manta-crypto/src/arkworks/groth16.rs:216-245): owns the
     device-resident proving key; created once, shared by every proof of the shape."""
 
-    def __init__(self, curve, pk, devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None):
+    def __init__(self, curve, pk, devices=None, shard=None, task_mask=None, full_table_bytes=None, exchange=None, tuning=None):
         """pk: object with numpy arrays alpha_g1, beta_g1, delta_g1, beta_g2, delta_g2, a_query,
         b_g1_query, b_g2_query, h_query, l_query (affine Montgomery limbs) and ints V, P.
         devices: list of HIP device indices -> every MSM of a proof is range-sharded over them
@@ -565,7 +624,8 @@ class ProvingContext:
         shard = (g, G): this PROCESS holds slice g of G of every query on the current device (`mg_ctx_create_shard`,
         one process per GPU; see distributed.ShardedProver).
         full_table_bytes: HBM budget of the context's full tables (None = the library's default, a tenth of the device's
-        HBM; 0 = bucket tables only); exchange: EXCHANGE_HOST / EXCHANGE_RCCL for a `devices` list (`mg_ctx_opts`)."""
+        HBM; 0 = bucket tables only); exchange: EXCHANGE_HOST / EXCHANGE_RCCL for a `devices` list (`mg_ctx_opts`);
+        tuning: this context's `Tuning` (or a dict of field changes to the process-wide values), `mg_ctx_opts.tuning`."""
         self.curve = curve
         self._keep = [_u64(getattr(pk, k)) for k in ("alpha_g1", "beta_g1", "delta_g1", "beta_g2", "delta_g2",
                                                      "a_query", "b_g1_query", "b_g2_query", "h_query", "l_query")]
@@ -573,11 +633,11 @@ class ProvingContext:
         h = _vp()
         if task_mask is not None and int(task_mask) == 0:  # a rank beyond the fifth owns no MSM: the struct reads 0 as "all five"
             _chk(LIB.mg_ctx_create_task(curve, ctypes.byref(v), ctypes.c_uint(0), ctypes.byref(h)), "mg_ctx_create_task")
-        elif shard is not None and int(shard[1]) == 1 and devices is None and task_mask is None and full_table_bytes is None:
+        elif shard is not None and int(shard[1]) == 1 and devices is None and task_mask is None and full_table_bytes is None and tuning is None:
             # a world of one driven through the partials interface: the entry point that says so (no combined a | b_g1 | l table)
             _chk(LIB.mg_ctx_create_shard(curve, ctypes.byref(v), 0, 1, ctypes.byref(h)), "mg_ctx_create_shard")
         else:
-            o, keep = _ctx_opts(devices, shard, task_mask, full_table_bytes, exchange)
+            o, keep = _ctx_opts(devices, shard, task_mask, full_table_bytes, exchange, tuning)
             _chk(LIB.mg_ctx_create_ex(curve, ctypes.byref(v), ctypes.byref(o), ctypes.byref(h)), "mg_ctx_create_ex")
             del keep
         self._keep = None  # the library copied everything
@@ -585,7 +645,7 @@ class ProvingContext:
         self._r1cs_ref = None
 
     @classmethod
-    def decode(cls, curve, data: bytes, devices=None, checksum: bytes = None, full_table_bytes=None, exchange=None):
+    def decode(cls, curve, data: bytes, devices=None, checksum: bytes = None, full_table_bytes=None, exchange=None, tuning=None):
         """Mirror of `impl Decode for ProvingContext` (groth16.rs:268-288): arkworks `deserialize_unchecked`
         bytes of the ProvingKey -- the format of manta-parameters' proving-key files. checksum: the file's BLAKE3 digest as
         manta-parameters' data.checkfile lists it (32 bytes); a mismatch raises before anything is uploaded, whatever the
@@ -597,7 +657,7 @@ class ProvingContext:
         h = _vp()
         if checksum is not None and len(checksum) != 32:
             raise ValueError("a BLAKE3 digest is 32 bytes")
-        o, keep = _ctx_opts(devices, None, None, full_table_bytes, exchange)
+        o, keep = _ctx_opts(devices, None, None, full_table_bytes, exchange, tuning)
         _chk(LIB.mg_ctx_create_from_bytes_ex(curve, bytes(data), _sz(len(data)), None if checksum is None else bytes(checksum),
                                              ctypes.byref(o), ctypes.byref(h)), "mg_ctx_create_from_bytes_ex")
         del keep

@@ -1,6 +1,8 @@
 // C ABI of libmantagpu.so (include/mantagpu.h): thin, exception-free wrappers over the engines.
 #include "../../include/mantagpu.h"
 #include "engine.h"
+#include "tuning.h"
+#include <cstddef>
 #include "prover.h"
 #include "verify.h"
 #include <cstring>
@@ -497,7 +499,41 @@ MG_API int mg_ctx_create_task(mg_curve_t curve, const mg_pk_view *pk, unsigned t
     MG_CATCH
 }
 // mg_ctx_opts -> ProverOptions; a struct shorter than ours (an older caller) is read up to its own size
-static int opts_from_abi(const mg_ctx_opts *in, ProverOptions &o) {
+static_assert(sizeof(mg_tuning) == sizeof(Tuning) && offsetof(mg_tuning, full_table_bytes) == offsetof(Tuning, full_table_bytes) &&
+                  offsetof(mg_tuning, window_bits_g2) == offsetof(Tuning, window_bits_g2),
+              "mg_tuning (mantagpu.h) and mg::Tuning (tuning.h) are the same struct");
+// a caller's mg_tuning -> Tuning: a shorter struct (an older caller) is read up to its own size over the process-wide values
+static int tuning_from_abi(const mg_tuning *in, Tuning &t) {
+    if (!in || in->struct_size < 8 || in->struct_size > 4096) return MG_ERROR_INVALID_ARGUMENT;
+    t = tuning();
+    std::memcpy(&t, in, std::min<size_t>(in->struct_size, sizeof(t)));
+    return normalize_tuning(t) == MG_OK ? MG_SUCCESS : MG_ERROR_INVALID_ARGUMENT;
+}
+MG_API int mg_tuning_init(mg_tuning *t) {
+    if (!t) return MG_ERROR_INVALID_ARGUMENT;
+    const Tuning d = tuning_defaults();
+    std::memcpy(t, &d, sizeof(d));
+    return MG_SUCCESS;
+}
+MG_API int mg_get_tuning(mg_tuning *t) {
+    MG_TRY
+    if (!t) return MG_ERROR_INVALID_ARGUMENT;
+    const Tuning d = tuning();
+    std::memcpy(t, &d, sizeof(d));
+    return MG_SUCCESS;
+    MG_CATCH
+}
+MG_API int mg_set_tuning(const mg_tuning *t) {
+    MG_TRY
+    Tuning v;
+    const int rc = tuning_from_abi(t, v);
+    if (rc) return rc;
+    return set_tuning(v) == MG_OK ? MG_SUCCESS : MG_ERROR_INVALID_ARGUMENT;
+    MG_CATCH
+}
+MG_API const char *const *mg_tuning_env_names(void) { return tuning_env_names(); }
+// (the Tuning a context's options point at lives in the caller's frame until prover_create_ex returns)
+static int opts_from_abi(const mg_ctx_opts *in, ProverOptions &o, Tuning &tn) {
     if (!in) return MG_SUCCESS;
     mg_ctx_opts t;
     mg_ctx_opts_init(&t);
@@ -511,6 +547,11 @@ static int opts_from_abi(const mg_ctx_opts *in, ProverOptions &o) {
     o.task_mask = t.task_mask ? t.task_mask : 0x1f;
     o.full_table_bytes = t.full_table_bytes;
     o.exchange = (int)t.exchange;
+    if (t.tuning) {
+        const int rc = tuning_from_abi(t.tuning, tn);
+        if (rc) return rc;
+        o.tuning = &tn;
+    }
     return MG_SUCCESS;
 }
 MG_API int mg_ctx_opts_init(mg_ctx_opts *o) {
@@ -527,7 +568,8 @@ MG_API int mg_ctx_create_ex(mg_curve_t curve, const mg_pk_view *pk, const mg_ctx
     MG_TRY
     if (!pk || !out) return MG_ERROR_INVALID_ARGUMENT;
     ProverOptions o;
-    int rc = opts_from_abi(opts, o);
+    Tuning tn;
+    int rc = opts_from_abi(opts, o, tn);
     if (rc) return rc;
     Prover *p = nullptr;
     rc = prover_create_ex((int)curve, pk, o, &p);
@@ -545,7 +587,8 @@ MG_API int mg_ctx_create_from_bytes_ex(mg_curve_t curve, const uint8_t *bytes, s
     HeavyOp no_capture_meanwhile;
     if (!bytes || !out) return MG_ERROR_INVALID_ARGUMENT;
     ProverOptions o;
-    int rc = opts_from_abi(opts, o);
+    Tuning tn;
+    int rc = opts_from_abi(opts, o, tn);
     if (rc) return rc;
     if (checksum32) { // manta_parameters::verify in front of the loader, whatever the placement
         uint8_t h[32];

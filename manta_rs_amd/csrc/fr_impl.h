@@ -9,6 +9,7 @@
 // generator; natural order in and out.
 #pragma once
 #include "fp_dev.h"
+#include "tuning.h"
 #include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
@@ -816,16 +817,14 @@ template <class FrC> class FrEngineT : public FrEngine {
     // registers cost occupancy) and three stages per round trip lose everywhere (215-256 VGPRs). MANTA_NTT_R = 0 / 2 / 3 forces one.
     static int ntt_reg_bits(bool dif) {
         static const int v = [] {
-            const char *e = getenv("MANTA_NTT_R");
-            const int x = e ? atoi(e) : -1;
+            const int x = ab_knob("MANTA_NTT_R", -1);
             return x == 0 || x == 2 || x == 3 ? x : -1;
         }();
         return v >= 0 ? v : (dif ? 0 : 2);
     }
     static u32 ntt_threads() {
         static const u32 v = [] {
-            const char *e = getenv("MANTA_NTT_THREADS");
-            return (u32)(e ? atoi(e) : 0);
+            return (u32)ab_knob("MANTA_NTT_THREADS", 0);
         }();
         return v;
     }
@@ -858,8 +857,7 @@ template <class FrC> class FrEngineT : public FrEngine {
             // tiles a pass is 32-96 workgroups on 256 CUs. Narrower column groups = more, smaller workgroups (the vectors live in
             // L2: the coalescing the wide groups buy is worth nothing here). MANTA_NTT_MIN_WGS = workgroups a pass should have.
             static const u32 min_wgs = [] {
-                const char *e = getenv("MANTA_NTT_MIN_WGS");
-                const int v = e ? atoi(e) : 512;
+                const int v = ab_knob("MANTA_NTT_MIN_WGS", 512);
                 return (u32)(v >= 1 ? v : 1);
             }();
             while (cb > 0 && ((((size_t)1 << lg) >> (ns + cb)) * (size_t)nvec * batch) < min_wgs && (1u << (ns + cb - 1)) >= 128u) --cb;
@@ -873,8 +871,7 @@ template <class FrC> class FrEngineT : public FrEngine {
             // public transform (arkworks format in and out, d0 = a scratch vector): the passes hand the vector on in the packed form
             const bool pack = io.in_std && io.out_std && npass > 1 && !DIF;
             static const bool twl_on = [] {
-                const char *e = getenv("MANTA_NTT_TWL");
-                return !(e && atoi(e) == 0);
+                return ab_knob("MANTA_NTT_TWL", 1) != 0;
             }();
             // single-column tiles of a LATENCY-bound launch (one proof's witness map: <= 2 workgroups per CU): twiddles staged in LDS
             // (E entries of 36 B more). A 2^20 transform is 1 024 workgroups per pass and throughput-bound: there the larger LDS
@@ -975,8 +972,7 @@ template <class FrC> class FrEngineT : public FrEngine {
         }
         // single proofs (single-column tiles, two passes per transform): four fused launches instead of seven (MANTA_NTT_FUSE=0: A/B)
         static const int fuse_on = [] { // bit 0: the low passes (ntt_fused_low), bit 1: high pass + pointwise + high pass
-            const char *e = getenv("MANTA_NTT_FUSE");
-            return e ? atoi(e) & 3 : 3;
+            return ab_knob("MANTA_NTT_FUSE", 3) & 3;
         }();
         const unsigned L = lg / 2, H = lg - L; // low / high stages of every transform
         if (fuse_on && lg >= 12 && lg <= 18 && (size_t)batch * 3 * ((size_t)n >> (H + 1)) < 512) {

@@ -26,6 +26,7 @@
 #include "fpr_dev.h"
 #include "host_ec.h"
 #include "params_gen.h"
+#include "tuning.h"
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
@@ -1510,7 +1511,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             const size_t rounds = (M + round * lmax - 1) / (round * lmax);
             L = (M + round * rounds - 1) / (round * rounds);
         }
-        if (const char *e = getenv("MANTA_MSM_L")) L = (size_t)atoi(e) > 0 ? (size_t)atoi(e) : L;
+        if (const int l = ab_knob("MANTA_MSM_L", 0); l > 0) L = (size_t)l;
         p.L = (u32)L;
         return p;
     }
@@ -1520,8 +1521,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // partials to merge). MANTA_ACC_ROUND_WAVES = wavefronts per SIMD, 0 = off (host-side chunk length only).
     u32 acc_round_lanes(u32 batch, bool single = false) {
         static const int knob = [] {
-            const char *e = getenv("MANTA_ACC_ROUND_WAVES");
-            return e ? atoi(e) : -1;
+            return ab_knob("MANTA_ACC_ROUND_WAVES", -1);
         }();
         if (knob == 0) return 0;
         const int dev = current_device();
@@ -1561,15 +1561,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // few tiles = a pure latency chain: spread each addition over the workgroup's four wavefronts
     static bool coop_tiles(u32 tiles) {
         static const int lim = [] {
-            const char *e = getenv("MANTA_COOP_TILES");
-            return e ? atoi(e) : 64;
+            return ab_knob("MANTA_COOP_TILES", 64);
         }();
         return (int)tiles <= lim;
     }
     static u32 coop_waves() { // merge levels with at most this many 64-entry waves use the cooperative kernel
         static const u32 lim = [] {
-            const char *e = getenv("MANTA_COOP_WAVES");
-            return (u32)(e ? atoi(e) : 512);
+            return (u32)ab_knob("MANTA_COOP_WAVES", 512);
         }();
         return lim;
     }
@@ -1579,8 +1577,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // (PrivateTransfer: G = 4 / 8 / 16 / 32 -> 865 / 927 / 955 / 832 proofs/s).
     static u32 merge_g1(size_t M) {
         static const u32 g = [] {
-            const char *e = getenv("MANTA_MERGE_G");
-            const int v = e ? atoi(e) : 0;
+            const int v = ab_knob("MANTA_MERGE_G", 0);
             return (u32)(v >= 1 && v <= 64 ? v : 0);
         }();
         if (g) return g;
@@ -1603,9 +1600,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         static const RedKnobs k = [] {
             RedKnobs r{2, -1, 3, 16384u, true}; // lgS = -1: automatic (below)
             auto env = [](const char *n, int lo, int hi, int dflt) {
-                const char *e = getenv(n);
-                if (!e) return dflt;
-                const int v = atoi(e);
+                const int v = ab_knob(n, dflt);
                 return v < lo ? lo : (v > hi ? hi : v);
             };
             r.lgS0 = env("MANTA_RED_S0", 1, 8, r.lgS0);
@@ -1683,8 +1678,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // (sort.hip sort_key). MANTA_SORT_LOW=0: the full key (A/B).
         u32 sort_mask = 0xffffffffu, sort_inv = 0xffffffffu;
         static const bool sort_low = [] {
-            const char *e = getenv("MANTA_SORT_LOW");
-            return !(e && atoi(e) == 0);
+            return ab_knob("MANTA_SORT_LOW", 1) != 0;
         }();
         if (sort_low && !sparse && batch > 1 && nsets == 1 && (seg_keys & (seg_keys - 1)) == 0) {
             int eb = 1;
@@ -1729,8 +1723,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // alternations on one box: off 0.770 / 0.859 / 1.258 ms, G1 0.755 / 0.852 / 1.270, G2 0.749 / 0.853 / 1.286, both 0.739 /
         // 0.863 / 1.314 -- over Fp2 the cooperative additions are ~20 us each and the dense G2 chain gets longer)
         static const bool acc_single_on = [] {
-            const char *e = getenv("MANTA_ACC_SINGLE");
-            const int v = e ? atoi(e) : 1;
+            const int v = ab_knob("MANTA_ACC_SINGLE", 1);
             return ((v >> (GROUP - 1)) & 1) != 0;
         }();
         const int dev_now = current_device();
@@ -1749,8 +1742,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             if (adapt && Lk > 6) Lk = 6;
         }
         static const u32 dthreads_sparse = [] {
-            const char *e = getenv("MANTA_DIGITS_THREADS");
-            const int v = e ? atoi(e) : 0;
+            const int v = ab_knob("MANTA_DIGITS_THREADS", 0);
             return (u32)(v == 256 || v == 512 || v == 1024 ? v : 256); // measured: 256 beats 512 and 1024 on the same box
         }();
         const u32 dthreads = d_count ? dthreads_sparse : 256u; // compacting path: fewer, larger workgroups = fewer atomics on the counter
@@ -1759,8 +1751,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         // and the radix pass over them (histogram, two scans, scatter: 135-150 us on the chain that ends a W or dense proof) is
         // not run. MANTA_Z3_SORT=1 restores the single launch + sort (A/B).
         static const bool z3_sort = [] {
-            const char *e = getenv("MANTA_Z3_SORT");
-            return e && atoi(e) != 0;
+            return ab_knob("MANTA_Z3_SORT", 0) != 0;
         }();
         const bool per_query = pl.full && nsets > 1 && nsets <= BaseSet::MAX_SETS && batch == 1 && d_count && !z3_sort &&
                                bs->set_first[nsets] == (u32)bs->n;
@@ -1789,7 +1780,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         u32 *const std_final = direct ? ws->redS.as<u32>() : (u32 *)nullptr;
         if (ws->timed) MG_HIP(hipEventRecord(ws->t0, s));
 #ifdef MG_CALIBRATION
-        static const bool gather_only = getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // calibration build only (wrong results)
+        static const bool gather_only = std::getenv("MANTA_ACC_GATHER_ONLY") != nullptr; // -DMG_CALIBRATION build only (wrong results)
         if (gather_only)
             hipLaunchKernelGGL((gather_only_chunks<F>), dim3(cdiv(T, 256)), dim3(256), 0, s, ws->keys_out.as<u32>(),
                                ws->vals_out.as<u32>(), (u32)M, pl.L, invalid, bs->d_pts, (u32)AWS, ws->pkeys[0].as<u32>(), T,
@@ -2143,8 +2134,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipMemcpyAsync(d_base, base_affine_host, AW_IO * 4, hipMemcpyHostToDevice, s);
         constexpr int KB = 16;
         static const size_t table_min = [] {
-            const char *e = getenv("MANTA_FIXED_BASE_TABLE_MIN");
-            return (size_t)(e ? atol(e) : 16384);
+            return (size_t)ab_knob("MANTA_FIXED_BASE_TABLE_MIN", 16384);
         }();
         u32 *t_xyzz = nullptr, *t_aff = nullptr;
         if (n >= table_min) { // many multiples of one base: 32 table additions each instead of ~380 group operations

@@ -13,6 +13,7 @@
 // An unsatisfied witness is not an error (ark-groth16 only debug_asserts it): a non-verifying proof
 // comes back, exactly like the reference in release builds.
 #include "prover.h"
+#include "tuning.h"
 // The six RCCL entry points this file calls, declared here from NCCL's stable C ABI (ncclResult_t 0 = success, ncclUint64 = 5):
 // librccl.so is loaded on demand (Rccl::get) and never linked, and its header is not a build dependency of a single-GPU host
 // (advisor r4). Only decltype() of the prototypes is used: nothing below references the symbols themselves.
@@ -133,7 +134,6 @@ struct ProveWs {
     bool linear3 = false;
     int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 / 3 linear3 beside other passes (combined / G2 MSM on the normal-priority stream)
     StreamSet sset; // linear3 slots: three streams on three different hardware queues (runtime.cpp); id < 0: plain pooled streams
-    bool dedicated = false; // the slot's three streams have hardware queues of their own (stream_pool_get_dedicated)
     bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
     std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
     int device = 0;
@@ -197,8 +197,6 @@ struct ProveWs {
         if (sset.id >= 0) {
             if (poisoned) sset.main = sset.g2 = sset.z3 = nullptr; // (abandoned, the set id is free again)
             stream_set_release(sset);
-        } else if (dedicated) {
-            if (!poisoned) stream_pool_put_dedicated(stream), stream_pool_put_dedicated(side[0]), stream_pool_put_dedicated(side[1]);
         } else if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
             stream_pool_put(stream);
             stream_pool_put(side[0]);
@@ -216,49 +214,27 @@ static inline void cpu_relax() {
 #endif
 }
 
-static int prove_streams() {
-    static const int n = [] {
-        const char *e = std::getenv("MANTA_PROVE_STREAMS");
-        const int v = e ? std::atoi(e) : 6;
-#ifdef MG_DIAG
-        if (v == 1) return 1; // part A as ONE linear chain: the topology of the round-4 wrong-C defect, diagnosis builds only
-#endif
-        return v == 3 || v == 4 || v == 5 ? v : 6; // (1 is ignored by the shipped library: DESIGN section 8)
-    }();
-    return n;
-}
-
-// MANTA_GRAPH = single (default): one captured graph for the whole proof (fork/join over all streams);
-//               split: six single-stream graphs (witness map + one per MSM) with eager event fork/join;
-//               off (or MANTA_NO_GRAPH): plain stream launches
-enum GraphMode { GRAPH_OFF = 0, GRAPH_SINGLE = 1, GRAPH_SPLIT = 2 };
-static GraphMode graph_mode() {
-    static const GraphMode m = [] {
-        if (std::getenv("MANTA_NO_GRAPH")) return GRAPH_OFF;
-        const char *e = std::getenv("MANTA_GRAPH");
-        if (!e) return GRAPH_SINGLE;
-        if (!std::strcmp(e, "off")) return GRAPH_OFF;
-        return std::strcmp(e, "split") ? GRAPH_SINGLE : GRAPH_SPLIT;
-    }();
-    return m;
-}
-static bool graphs_enabled() { return graph_mode() != GRAPH_OFF; }
-// Batched passes (k >= 4 proofs) may take another topology than single proofs: their launch cost is spread over the batch, and a
-// pass replayed from SINGLE-STREAM graphs (split) or launched eagerly (off) can run the work-efficient front levels of the bucket
-// reduce, which the multi-branch graph of the "single" mode cannot (msm_impl.h, in_graph_slot). MANTA_GRAPH_BATCH = single | split |
-// off; MANTA_GRAPH, when set, rules every pass.
-static GraphMode graph_mode_for(u32 k) {
-    static const GraphMode batch = [] {
-        const char *e = std::getenv("MANTA_GRAPH_BATCH");
-        if (std::getenv("MANTA_GRAPH") || std::getenv("MANTA_NO_GRAPH") || !e) return graph_mode();
-        if (!std::strcmp(e, "off")) return GRAPH_OFF;
-        return std::strcmp(e, "split") ? GRAPH_SINGLE : GRAPH_SPLIT;
-    }();
-    return k >= 4 ? batch : graph_mode();
-}
+enum GraphMode { GRAPH_OFF = GRAPH_MODE_OFF, GRAPH_SINGLE = GRAPH_MODE_SINGLE, GRAPH_SPLIT = GRAPH_MODE_SPLIT };
 
 class ProverImpl : public Prover {
   public:
+    // what the deployment decided for THIS context (mg_ctx_opts.tuning, else the process-wide values when it was created): tuning.h
+    Tuning tn_ = tuning();
+    // streams of a forked pass. (1 = part A as ONE linear chain, the topology of the round-4 wrong-C defect: diagnosis builds only)
+    int prove_streams() const {
+#ifdef MG_DIAG
+        if (ab_knob("MANTA_PROVE_STREAMS", 0) == 1) return 1;
+#endif
+        return tn_.prove_streams;
+    }
+    // Replay the GPU side of a pass as hipGraphs: 0 off, 1 single (default; two graphs, the G2 chain alone so the host can assemble A
+    // and C while it still runs), 2 split (six single-stream graphs, eager event fork / join). Batched passes (k >= 4 proofs) may take
+    // another topology than single proofs (graph_mode_batch; measured within noise: profiles/r05_batched_ab.txt).
+    GraphMode graph_mode() const { return (GraphMode)tn_.graph_mode; }
+    GraphMode graph_mode_for(u32 k) const { return k >= 4 && tn_.graph_mode_batch >= 0 ? (GraphMode)tn_.graph_mode_batch : graph_mode(); }
+    int coalesce_gather_us() const { return tn_.coalesce_gather_us; }
+    int coalesce_inflight() const { return tn_.coalesce_inflight; }
+    int batch_inflight() const { return tn_.batch_inflight < (int)MAX_IDLE_SLOTS ? tn_.batch_inflight : (int)MAX_IDLE_SLOTS; }
     int curve_ = 0;
     int dev_ = 0;                      // the HIP device this (shard of the) context lives on
     u32 shard_ = 0, n_shards_ = 1;     // range shard g of G: every MSM of a proof covers the g-th contiguous slice of its query
@@ -361,9 +337,8 @@ class ProverImpl : public Prover {
 
     // window bits for precomputed tables, by MSM length (HBM is plentiful: trade table size for fewer
     // buckets to fold and no doubling chain -- tuned on MI355X)
-    static int pre_c_for(u64 n) {
-        if (const char *e = std::getenv("MANTA_PROVE_C")) // tuning override (window bits of the pk tables)
-            if (std::atoi(e) > 0) return std::atoi(e);
+    int pre_c_for(u64 n) const {
+        if (tn_.window_bits_narrow > 0) return tn_.window_bits_narrow; // tuning override: ONE width for every bucket table of the key
         // Measured on MI355X for the PrivateTransfer shape (n = 35k / 65k): c = 6..8 -> 2.0 ms per proof,
         // c = 9..13 -> 2.5-2.7 ms, c = 14 -> 3.0 ms. Few buckets keep the latency-bound bucket reduce short
         // (B = 128: two tiles); the extra windows only add perfectly parallel mixed additions.
@@ -389,8 +364,7 @@ class ProverImpl : public Prover {
     void plan_full_tables(const u64 n[5], int64_t budget, int out[5], bool tie_abl = false) const {
         for (int i = 0; i < 5; ++i) out[i] = 0;
         static const int fixed = [] {
-            const char *e = std::getenv("MANTA_FULL_C");
-            const int v = e ? std::atoi(e) : 0;
+            const int v = ab_knob("MANTA_FULL_C", 0);
             return v >= 2 && v <= 12 ? v : 0;
         }();
         if (budget <= 0) return;
@@ -438,13 +412,13 @@ class ProverImpl : public Prover {
         }
         for (int i = 0; i < 5; ++i) out[i] = n[i] ? c[i] : 0;
     }
-    // the budget of this shard: the option (or its default, a tenth of the device's HBM), the environment override, never more
+    // the budget of this shard: the context option, else the tuning (MANTA_FULL_TABLE_GB / mg_set_tuning), else a tenth of the HBM; never more
     // than 40 % of what is free on the device right now, split between the shards of this context that share the device
-    static int64_t resolve_full_budget(int64_t opt_bytes, int shards_on_this_device) {
+    int64_t resolve_full_budget(int64_t opt_bytes, int shards_on_this_device) const {
         size_t free_b = 0, total_b = 0;
         const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-        double b = opt_bytes >= 0 ? (double)opt_bytes : (have ? (double)total_b / 10.0 : 24e9);
-        if (const char *e = std::getenv("MANTA_FULL_TABLE_GB")) b = std::atof(e) * 1e9;
+        // (the context's own option first, then the tuning's budget -- MANTA_FULL_TABLE_GB lands there --, then a tenth of the device)
+        double b = opt_bytes >= 0 ? (double)opt_bytes : (tn_.full_table_bytes >= 0 ? (double)tn_.full_table_bytes : (have ? (double)total_b / 10.0 : 24e9));
         if (have && b > 0.4 * (double)free_b) b = 0.4 * (double)free_b;
         if (shards_on_this_device > 1) b /= shards_on_this_device;
         return b > 0 ? (int64_t)b : 0;
@@ -500,14 +474,13 @@ class ProverImpl : public Prover {
         const u32 *aq = (const u32 *)pk->a_query + (1 + zlo) * w1, *b1q = (const u32 *)pk->b_g1_query + (1 + zlo) * w1;
         const u32 *b2q = (const u32 *)pk->b_g2_query + (1 + zlo) * w2, *lq = (const u32 *)pk->l_query + llo * w1;
         const int c_z = pre_c_for(V_ - 1);
-        const bool proof_sized = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
+        const bool proof_sized = V_ - 1 <= (1u << 17) && tn_.window_bits_narrow == 0;
         if (proof_sized) {
             full_budget_ = resolve_full_budget(full_table_bytes, shards_on_this_device);
             u64 D = 1; // the domain the h query was made for: len(h_query) = D - 1 (ark setup) or D (MPC keys)
             while (D < h_len_) D <<= 1;
             const u64 nq[5] = {zn, zn, zn, ln, (u64)(D * (shard_ + 1) / n_shards_ - D * shard_ / n_shards_)};
-            const char *z3e = std::getenv("MANTA_Z3");
-            plan_full_tables(nq, full_budget_, full_c_plan_, allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && !(z3e && std::atoi(z3e) == 0));
+            plan_full_tables(nq, full_budget_, full_c_plan_, allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && ab_knob("MANTA_Z3", 1) != 0);
         }
         const int f_z1a = -full_c_plan_[0], f_z1b = -full_c_plan_[1], f_z2 = -full_c_plan_[2], f_l = -full_c_plan_[3];
         if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
@@ -515,13 +488,12 @@ class ProverImpl : public Prover {
         // The G2 MSM is the latency-critical chain of a single proof: 6-bit windows (32 buckets: one tile, no second
         // reduce level) shorten it by four dependent additions (measured +4 % proofs/s); the extra windows only
         // add parallel mixed additions.
-        const bool small = V_ - 1 <= (1u << 17) && !std::getenv("MANTA_PROVE_C");
+        const bool small = V_ - 1 <= (1u << 17) && tn_.window_bits_narrow == 0;
         // large keys (2^20 variables, BASELINE configs[2]): the 2^16 Fp2 buckets of a 17-bit window made the G2 bucket reduce a
         // 4.4 ms chain of latency-bound kernels next to a 0.7 ms accumulate (profiles/r04_config2_timeline.txt); 13-bit windows
         // -- 4 096 buckets, 20 windows instead of 15 -- trade a third more mixed additions for a sixteenth of the buckets
         int c_g2 = small ? 6 : (c_z > 13 ? 13 : c_z);
-        if (const char *e = std::getenv("MANTA_PROVE_CG2"))
-            if (std::atoi(e) >= 4 && std::atoi(e) <= 18) c_g2 = std::atoi(e);
+        if (tn_.window_bits_g2) c_g2 = tn_.window_bits_g2;
         if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
         if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
         // (an optimisation: a table that does not fit any more is left out, the bucket tables above serve its MSM)
@@ -536,10 +508,7 @@ class ProverImpl : public Prover {
             return r;
         };
         if ((rc = try_full(g2_, b2q, zn, f_z2, &b2_bs_full_))) return rc; // the G2 chain first: the longest of a proof
-        static const bool z3_on = [] {
-            const char *e = std::getenv("MANTA_Z3");
-            return !(e && std::atoi(e) == 0);
-        }();
+        static const bool z3_on = ab_knob("MANTA_Z3", 1) != 0;
         const int c_z3 = std::min(full_c_plan_[0], std::min(full_c_plan_[1], full_c_plan_[3]));
         if (z3_on && allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && c_z3 >= 2 && 3 * (u64)zn * ((u64)((g1_->scalar_bits() + c_z3 - 1) / c_z3) << (c_z3 - 1)) < ((u64)1 << 31)) {
             // a | b_g1 | l as one table over the scalars z[1 .. V): l_query[i] belongs to z[P + i] = scalar P - 1 + i of that range
@@ -562,7 +531,7 @@ class ProverImpl : public Prover {
         }
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
             int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
-            if (const char *e = std::getenv("MANTA_PROVE_CW")) cw = std::atoi(e) >= 6 && std::atoi(e) <= 16 ? std::atoi(e) : cw; // tuning override
+            if (tn_.window_bits_wide) cw = tn_.window_bits_wide; // tuning override
             if ((rc = g1_->bases_create(aq, zn, false, cw, &a_bs_wide_, true))) return rc;
             if ((rc = g1_->bases_create(b1q, zn, false, cw, &b1_bs_wide_, true))) return rc;
             if ((rc = g2_->bases_create(b2q, zn, false, cw, &b2_bs_wide_, true))) return rc;
@@ -681,11 +650,11 @@ class ProverImpl : public Prover {
             int ch = pre_c_for(D), ch_wide = ch;
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
             if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
-            if (const char *e = std::getenv("MANTA_PROVE_CH")) ch = ch_wide = std::atoi(e) > 0 ? std::atoi(e) : ch;
+            if (tn_.window_bits_h) ch = ch_wide = tn_.window_bits_h;
             // the h table gets what the budget has left after the four z / l tables: the planned width when the domain is the
             // one the key was made for, else the widest that still fits
             int f_h = 0;
-            if (lg <= 17 && !std::getenv("MANTA_PROVE_CH") && full_budget_ > 0) {
+            if (lg <= 17 && !tn_.window_bits_h && full_budget_ > 0) {
                 int64_t left = full_budget_;
                 for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, z3_bs_full_}) // (z3 replaces a / b_g1 / l: advisor r4)
                     if (b) left -= (int64_t)b->bytes;
@@ -740,10 +709,7 @@ class ProverImpl : public Prover {
     // coalesced passes) 1 794-1 898 against 1 624-1 700.
     // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 no flavour 3, 3 (default) all of the above.
     int lin_flavour(u32 k, bool z3, int company) const {
-        static const int z3_linear = [] {
-            const char *e = std::getenv("MANTA_Z3_LINEAR");
-            return e ? std::atoi(e) : 3;
-        }();
+        const int z3_linear = tn_.linear_chains;
         if (!(z3 && k == 1 && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE)) return 0;
         if (company == 0) return z3_linear >= 1 ? 1 : 0;
         if (!(z3_linear >= 2 && sets_ok_)) return 0; // (linear graphs beside others need queues of their own: -18 % without)
@@ -774,28 +740,12 @@ class ProverImpl : public Prover {
             std::lock_guard<std::mutex> g(mu_);
             w->no_graph = no_graph_keys_.count(slot_key(k, z3, lin_flavour(k, z3, company))) != 0; // (a capture of this kind failed for good)
         }
-        static const int z3_high = [] { // A/B: the combined MSM's stream of every linear3 slot normal (0) / high (1) priority
-            const char *e = std::getenv("MANTA_Z3_HIGH");
-            return e ? std::atoi(e) : -1;
-        }();
+        static const int z3_high = ab_knob("MANTA_Z3_HIGH", -1); // A/B: the combined MSM's stream of every linear3 slot normal (0) / high (1) priority
         w->flavour = lin_flavour(k, z3, company);
-        static const int slot_dedicated = [] { // EXPERIMENT (round 6): linear3 slots on three dedicated hardware queues
-            const char *e = std::getenv("MANTA_SLOT_DEDICATED");
-            return e ? std::atoi(e) : 0;
-        }();
-        if (w->flavour && slot_dedicated) {
-            w->stream = stream_pool_get_dedicated(), w->side[0] = stream_pool_get_dedicated(), w->side[1] = stream_pool_get_dedicated();
-            w->dedicated = w->stream && w->side[0] && w->side[1];
-            if (!w->dedicated) {
-                stream_pool_put_dedicated(w->stream), stream_pool_put_dedicated(w->side[0]), stream_pool_put_dedicated(w->side[1]);
-                w->stream = w->side[0] = w->side[1] = nullptr;
-            }
-        }
-        if (!w->dedicated)
         if (w->flavour && stream_set_acquire(w->sset, z3_high >= 0 ? z3_high != 0 : w->flavour == 1))
             w->stream = w->sset.main, w->side[0] = w->sset.g2, w->side[1] = w->sset.z3;
         if (w->sset.id >= 0 && w->flavour == 3 && !w->sset.z3_high) std::swap(w->side[0], w->side[1]); // the G2 chain takes the normal-priority stream
-        if ((w->sset.id < 0 && !w->dedicated && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
+        if ((w->sset.id < 0 && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
                                 !(w->side[1] = stream_pool_get()))) ||
             hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
@@ -816,10 +766,7 @@ class ProverImpl : public Prover {
         // z3 slots: the combined a | b_g1 | l MSM announces its end through a pinned flag (MsmWorkspace::notify), so that the host
         // can fold its three results into s A + r B1 -- the one long piece of host work of a proof, ~0.1 ms -- while the h chain is
         // still running (finish_pass_body). MANTA_Z3_EARLY=0: wait for all of part A first, as before (A/B).
-        static const bool z3_early = [] {
-            const char *e = std::getenv("MANTA_Z3_EARLY");
-            return !(e && std::atoi(e) == 0);
-        }();
+        static const bool z3_early = ab_knob("MANTA_Z3_EARLY", 1) != 0;
         w->mw[0]->notify = z3 && z3_early;
         // Three streams per proof, not six: the G2 MSM is the critical path (~3x a G1 MSM), so the three
         // z-MSMs over G1 run back to back beside it and the h MSM follows the witness map on the main stream.
@@ -900,8 +847,8 @@ class ProverImpl : public Prover {
 #ifdef MG_DIAG
         // diagnosis builds: MG_DIAG_MEMSET=1 puts the round-4 memset node back in front of the SpMV (the negative control of
         // test_captured_graphs_survive_other_contexts: with it a LINEAR part A must go wrong); MG_DIAG_WM_STOP cuts the witness map
-        static const int diag_memset = std::getenv("MG_DIAG_MEMSET") ? std::atoi(std::getenv("MG_DIAG_MEMSET")) : 0;
-        static const int diag_stop = std::getenv("MG_DIAG_WM_STOP") ? std::atoi(std::getenv("MG_DIAG_WM_STOP")) : 0;
+        static const int diag_memset = ab_knob("MG_DIAG_MEMSET", 0);
+        static const int diag_stop = ab_knob("MG_DIAG_WM_STOP", 0);
         if (diag_memset) MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s));
         if (diag_stop == 1) return MG_OK;
 #endif
@@ -992,8 +939,7 @@ class ProverImpl : public Prover {
         // batched passes switch to the wide-window tables (fewer mixed additions, longer bucket reduce) from this many proofs
         // on: a pass of a few coalesced single calls is still a latency chain and keeps the narrow ones (MANTA_WIDE_MIN)
         static const u32 wide_min = [] {
-            const char *e = std::getenv("MANTA_WIDE_MIN");
-            const int v = e ? std::atoi(e) : 4;
+            const int v = ab_knob("MANTA_WIDE_MIN", 4);
             return (u32)(v >= 1 && v <= 64 ? v : 4);
         }();
         const bool wide = w->k >= wide_min;
@@ -1004,8 +950,7 @@ class ProverImpl : public Prover {
         // passes of up to this many proofs run on the full tables where the key has them (MANTA_FULL_MAX_K; a batch sorts its
         // pairs by proof -- one radix pass -- and needs 32 additions per scalar where the wide bucket tables need 24)
         static const u32 full_max_k = [] {
-            const char *e = std::getenv("MANTA_FULL_MAX_K");
-            const int v = e ? std::atoi(e) : 1;
+            const int v = ab_knob("MANTA_FULL_MAX_K", 1);
             return (u32)(v >= 0 ? v : 1);
         }();
         const bool one = w->k <= full_max_k;
@@ -1020,8 +965,7 @@ class ProverImpl : public Prover {
     bool runs(const ProveWs *w, int i) const { return does(i) && !(w->z3 && (i == 1 || i == 3)); }
     bool wants_z3(u32 k) const {
         static const u32 full_max_k = [] {
-            const char *e = std::getenv("MANTA_FULL_MAX_K");
-            const int v = e ? std::atoi(e) : 1;
+            const int v = ab_knob("MANTA_FULL_MAX_K", 1);
             return (u32)(v >= 0 ? v : 1);
         }();
         // (passes of one proof only: on full tables passes of 2-8 proofs are SLOWER than on the narrow bucket tables -- 2.65 against 1.9 ms
@@ -1094,8 +1038,8 @@ class ProverImpl : public Prover {
             // launch order (MANTA_Z3_ORDER, three letters of a = witness map + h, b = G2, z = combined): the chain that bounds the
             // proof first -- each hipGraphLaunch is 10-20 us of host time, which the chains launched later start behind
             static const char *order = [] {
-                const char *e = std::getenv("MANTA_Z3_ORDER");
-                return e && std::strlen(e) == 3 ? e : "abz";
+                const char *e = ab_knob_str("MANTA_Z3_ORDER", "abz");
+                return std::strlen(e) == 3 ? e : "abz";
             }();
             for (int t = 0; t < 3; ++t) {
                 if (order[t] == 'a') {
@@ -1273,22 +1217,6 @@ class ProverImpl : public Prover {
     int cq_inflight_ = 0, cq_batched_inflight_ = 0; // passes of this context's coalescing queue on the GPU; those of more than one proof
     bool cq_gathering_ = false; // a leader is waiting for the callers of the pass that has just finished
     size_t cq_last_k_ = 1;      // size of the most recently finished pass
-    static int coalesce_gather_us() {
-        static const int n = [] {
-            const char *e = std::getenv("MANTA_COALESCE_GATHER_US");
-            const int v = e ? std::atoi(e) : 100; // (0 / 40 / 80 / 150 / 300 us -> six threads 1 609 / 1 621 / 1 784 / 1 850 / 1 620 proofs/s)
-            return v >= 0 && v <= 2000 ? v : 100;
-        }();
-        return n;
-    }
-    static int coalesce_inflight() {
-        static const int n = [] {
-            const char *e = std::getenv("MANTA_COALESCE");
-            const int v = e ? std::atoi(e) : 2;
-            return v >= 0 && v <= 4 ? v : 2;
-        }();
-        return n;
-    }
     int prove(const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proof_out) override {
         if (!z || !r || !s || !proof_out) return MG_ERR_ARG;
         if (task_mask_ != 0x1f) return MG_ERR_STATE; // holds some of the MSMs only: partials_launch / assemble
@@ -1356,9 +1284,8 @@ class ProverImpl : public Prover {
         // coalesced calls to four wastes a sixth of the pass; six signer threads produce passes of two to four), then multiples of
         // four: slots and their captured graphs exist per size, so the set of sizes stays small
         size_t kp = k <= 8 ? k : (k + 3) / 4 * 4;
-        if (const char *e = std::getenv("MANTA_COALESCE_POW2"))
-            if (std::atoi(e) > 0) // round up to a power of two (the round-2 rule)
-                for (kp = 1; kp < k;) kp <<= 1;
+        if (ab_knob("MANTA_COALESCE_POW2", 0) > 0) // round up to a power of two (the round-2 rule)
+            for (kp = 1; kp < k;) kp <<= 1;
         const size_t pbytes = 2 * (size_t)g1_->point_bytes(true) + (size_t)g2_->point_bytes(true);
         std::vector<const uint64_t *> zl(kp);
         std::vector<uint64_t> rr(kp * 4), ss(kp * 4);
@@ -1384,14 +1311,6 @@ class ProverImpl : public Prover {
     // two, 3 820 with three, 3 680 with four; passes of 16 or 64 are no better. (Splitting ONE pass of 32 into two
     // halves in flight was measured too and gains nothing: the smaller passes lose what the overlap wins.)
     static constexpr u64 BATCH_CHUNK = 32;
-    static int batch_inflight() {
-        static const int n = [] {
-            const char *e = std::getenv("MANTA_BATCH_INFLIGHT");
-            const int v = e ? std::atoi(e) : 3;
-            return v >= 1 && v <= (int)MAX_IDLE_SLOTS ? v : 3;
-        }();
-        return n;
-    }
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
         if (task_mask_ != 0x1f || lone_range_shard()) return MG_ERR_STATE;
@@ -2248,6 +2167,7 @@ int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Pr
     if (!listed) {
         if (o.exchange != 0) return MG_ERR_ARG; // a collective needs a device list
         ProverImpl *p = new ProverImpl();
+        if (o.tuning) p->tn_ = *o.tuning;
         p->task_mask_ = o.task_mask;
         const int rc = p->init(curve, pk, prev, o.shard, o.n_shards, o.full_table_bytes, 1, !o.partials_interface);
         if (rc) {
@@ -2263,6 +2183,7 @@ int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Pr
     int rc = MG_OK;
     for (int g = o.n_devices - 1; g >= 0 && !rc; --g) { // shard 0 last: it ends up the current device's context
         ProverImpl *p = g == 0 ? p0 : new ProverImpl();
+        if (o.tuning) p->tn_ = *o.tuning;
         if (g) p0->peers_.insert(p0->peers_.begin(), p), p->shard_owner_ = p0;
         int same = 0;
         for (int t = 0; t < o.n_devices; ++t) same += o.devices[t] == o.devices[g];

@@ -1,6 +1,7 @@
 // Scalar-field (Fr) device engine -- NTT, sparse matrix-vector product, QAP pointwise kernel -- and the
 // Groth16 prover that strings them together with the MSM engines.
 #pragma once
+#include "tuning.h"
 #include "../../include/mantagpu.h"
 #include "engine.h"
 #include <vector>
@@ -80,6 +81,7 @@ struct ProverOptions {
     int64_t full_table_bytes = -1; // HBM budget of the full tables; < 0: the default (a tenth of the device's HBM)
     int exchange = 0;             // in-process sharding: 0 = partial points summed through pinned host memory, 1 = RCCL all_gather
     bool partials_interface = false; // the context will be driven through partials_launch / assemble (mg_ctx_create_shard)
+    const Tuning *tuning = nullptr;  // per-context tuning (validated by the caller); nullptr: the process-wide values
 };
 int prover_create_ex(int curve, const mg_pk_view *pk, const ProverOptions &o, Prover **out);
 int prover_create(int curve, const mg_pk_view *pk, Prover **out);

@@ -1,6 +1,9 @@
 // Common host runtime of the MI355X Groth16 hot path: error reporting, grow-only device buffers,
 // the per-engine MSM workspace pool and the (curve, group) engine registry.
 #include "engine.h"
+#include "tuning.h"
+#include <cstddef>
+#include <cstring>
 #include <hip/hip_ext.h>
 #include <cstdio>
 #include <cstdlib>
@@ -143,16 +146,118 @@ hipStream_t stream_pool_get_normal() {
     g_nstream_dev[s] = dev;
     return s;
 }
+// ---- tuning (tuning.h): compiled-in defaults, the environment applied ONCE through one table, then mg_set_tuning --------------
+Tuning tuning_defaults() {
+    Tuning t{};
+    t.struct_size = (uint32_t)sizeof(Tuning);
+    t.graph_mode = GRAPH_MODE_SINGLE;
+    t.graph_mode_batch = -1;
+    t.prove_streams = 6;
+    t.linear_chains = 3;
+    t.coalesce_inflight = 2;
+    t.coalesce_gather_us = 100; // (0 / 40 / 80 / 150 / 300 us -> six threads 1 609 / 1 621 / 1 784 / 1 850 / 1 620 proofs/s)
+    t.batch_inflight = 3;
+    t.queue_aware = 1;
+    t.msm_dedicated_queues = 1;
+    t.window_bits_narrow = t.window_bits_wide = t.window_bits_h = t.window_bits_g2 = 0;
+    t.full_table_bytes = -1;
+    return t;
+}
+int normalize_tuning(Tuning &t) {
+    auto in = [](int v, int lo, int hi) { return v >= lo && v <= hi; };
+    if (!in(t.graph_mode, 0, 2) || !in(t.graph_mode_batch, -1, 2)) return MG_ERR_ARG;
+    if (!(t.prove_streams >= 3 && t.prove_streams <= 6)) return MG_ERR_ARG; // (1 = the linear part A of the round-4 defect: -DMG_DIAG only)
+    if (!in(t.linear_chains, 0, 3) || !in(t.coalesce_inflight, 0, 4) || !in(t.coalesce_gather_us, 0, 2000)) return MG_ERR_ARG;
+    if (!in(t.batch_inflight, 1, 16) || !in(t.queue_aware, 0, 1) || !in(t.msm_dedicated_queues, 0, 1)) return MG_ERR_ARG;
+    if (t.window_bits_narrow && !in(t.window_bits_narrow, 2, 20)) return MG_ERR_ARG;
+    if (t.window_bits_wide && !in(t.window_bits_wide, 6, 16)) return MG_ERR_ARG;
+    if (t.window_bits_h && !in(t.window_bits_h, 2, 20)) return MG_ERR_ARG;
+    if (t.window_bits_g2 && !in(t.window_bits_g2, 4, 18)) return MG_ERR_ARG;
+    if (t.full_table_bytes < -1) return MG_ERR_ARG;
+    t.struct_size = (uint32_t)sizeof(Tuning);
+    return MG_OK;
+}
+namespace {
+enum EnvKind { ENV_INT, ENV_GRAPH, ENV_GB };
+struct EnvField {
+    const char *name;
+    EnvKind kind;
+    size_t off;
+};
+#define MG_TF(f) offsetof(Tuning, f)
+const EnvField ENV_TABLE[] = {
+    {"MANTA_GRAPH", ENV_GRAPH, MG_TF(graph_mode)},
+    {"MANTA_GRAPH_BATCH", ENV_GRAPH, MG_TF(graph_mode_batch)},
+    {"MANTA_PROVE_STREAMS", ENV_INT, MG_TF(prove_streams)},
+    {"MANTA_Z3_LINEAR", ENV_INT, MG_TF(linear_chains)},
+    {"MANTA_COALESCE", ENV_INT, MG_TF(coalesce_inflight)},
+    {"MANTA_COALESCE_GATHER_US", ENV_INT, MG_TF(coalesce_gather_us)},
+    {"MANTA_BATCH_INFLIGHT", ENV_INT, MG_TF(batch_inflight)},
+    {"MANTA_QUEUE_AWARE", ENV_INT, MG_TF(queue_aware)},
+    {"MANTA_MSM_DEDICATED_QUEUES", ENV_INT, MG_TF(msm_dedicated_queues)},
+    {"MANTA_PROVE_C", ENV_INT, MG_TF(window_bits_narrow)},
+    {"MANTA_PROVE_CW", ENV_INT, MG_TF(window_bits_wide)},
+    {"MANTA_PROVE_CH", ENV_INT, MG_TF(window_bits_h)},
+    {"MANTA_PROVE_CG2", ENV_INT, MG_TF(window_bits_g2)},
+    {"MANTA_FULL_TABLE_GB", ENV_GB, MG_TF(full_table_bytes)},
+};
+#undef MG_TF
+const char *const ENV_NAMES[] = {"MANTA_GRAPH", "MANTA_GRAPH_BATCH", "MANTA_PROVE_STREAMS", "MANTA_Z3_LINEAR", "MANTA_COALESCE",
+                                 "MANTA_COALESCE_GATHER_US", "MANTA_BATCH_INFLIGHT", "MANTA_QUEUE_AWARE", "MANTA_MSM_DEDICATED_QUEUES",
+                                 "MANTA_PROVE_C", "MANTA_PROVE_CW", "MANTA_PROVE_CH", "MANTA_PROVE_CG2", "MANTA_FULL_TABLE_GB",
+                                 "MANTA_RCCL_LIB" /* prover.cpp: where librccl.so is */, nullptr};
+std::mutex g_tuning_mu;
+Tuning g_tuning;
+bool g_tuning_init = false;
+// the ONE place the shipped library reads MANTA_* tuning variables; a value the field's range refuses is ignored (the default stays)
+void tuning_from_env_locked() {
+    g_tuning = tuning_defaults();
+    for (const EnvField &f : ENV_TABLE) {
+        const char *e = std::getenv(f.name);
+        if (!e || !*e) continue;
+        Tuning t = g_tuning;
+        char *p = (char *)&t + f.off;
+        if (f.kind == ENV_GB) {
+            const double gb = std::atof(e);
+            *(int64_t *)p = gb >= 0 ? (int64_t)(gb * 1e9) : -1;
+        } else if (f.kind == ENV_GRAPH) {
+            int v = GRAPH_MODE_SINGLE;
+            if (!std::strcmp(e, "off") || !std::strcmp(e, "0")) v = GRAPH_MODE_OFF;
+            else if (!std::strcmp(e, "split") || !std::strcmp(e, "2")) v = GRAPH_MODE_SPLIT;
+            *(int32_t *)p = v;
+        } else {
+            *(int32_t *)p = (int32_t)std::atoi(e);
+        }
+        if (normalize_tuning(t) == MG_OK) g_tuning = t;
+    }
+    g_tuning_init = true;
+}
+} // namespace
+const Tuning &tuning() {
+    // (a snapshot per thread: contexts copy it when they are created; set_tuning may run beside readers)
+    static thread_local Tuning snap;
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    if (!g_tuning_init) tuning_from_env_locked();
+    snap = g_tuning;
+    return snap;
+}
+int set_tuning(const Tuning &t_in) {
+    Tuning t = t_in;
+    const int rc = normalize_tuning(t);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    g_tuning = t;
+    g_tuning_init = true; // (the environment no longer applies: the host has spoken)
+    return MG_OK;
+}
+const char *const *tuning_env_names() { return ENV_NAMES; }
+
 // ---- streams on hardware queues of their own (engine.h MsmWorkspace::solo)
 static std::vector<hipStream_t> g_dstream_pools[MAX_DEVICES];
 static std::map<hipStream_t, int> g_dstream_dev;
 static bool g_dstream_refused[MAX_DEVICES] = {};
 hipStream_t stream_pool_get_dedicated() {
-    static const bool on = [] { // MANTA_MSM_DEDICATED_QUEUES=0: the workspace's ordinary pooled stream (A/B, and for hosts that need
-        const char *e = std::getenv("MANTA_MSM_DEDICATED_QUEUES"); // non-blocking semantics against their own NULL-stream work)
-        return !(e && std::atoi(e) == 0);
-    }();
-    if (!on) return nullptr;
+    if (!tuning().msm_dedicated_queues) return nullptr; // (hosts that need non-blocking semantics against their own NULL-stream work)
     const int dev = current_device();
     {
         std::lock_guard<std::mutex> g(g_stream_mu);
@@ -165,9 +270,9 @@ hipStream_t stream_pool_get_dedicated() {
         }
     }
     // The runtime's pool of shared normal-priority hardware queues must be FULL before the first dedicated queue exists: a process
-    // that has created fewer ordinary streams than the pool holds (GPU_MAX_HW_QUEUES, default 4) otherwise finds the dedicated queue
+    // that has created fewer ordinary streams than the pool holds (the runtime's GPU_MAX_HW_QUEUES, default 4) otherwise finds the dedicated queue
     // counted as a pool member, and later ordinary streams -- the NULL stream included -- are multiplexed onto it (measured: 316
-    // Mscalar/s in a process with no foreign stream, 379-387 with two or more: profiles/r06_pipeline_phase.txt). Four ordinary
+    // Mscalar/s in a process with no foreign stream, 379-387 with two or more: profiles/r06_pipeline_phase.txt). Eight ordinary
     // streams are created once per device and kept in the library's normal-priority pool.
     {
         static std::mutex prime_mu;
@@ -175,9 +280,7 @@ hipStream_t stream_pool_get_dedicated() {
         std::lock_guard<std::mutex> g(prime_mu);
         if (!primed[dev]) {
             primed[dev] = true;
-            const char *e = std::getenv("GPU_MAX_HW_QUEUES");
-            int nq = e ? std::atoi(e) : 4;
-            nq = nq < 1 ? 4 : (nq > 16 ? 16 : nq);
+            const int nq = 8; // (GPU_MAX_HW_QUEUES is 4 by default; a host that raised it to 8 is covered too)
             std::vector<hipStream_t> fill;
             for (int i = 0; i < nq; ++i) {
                 hipStream_t f = nullptr;
@@ -228,13 +331,7 @@ struct DevQueues {
 constexpr int PROBE_RETRIES = 4;
 DevQueues g_q[MAX_DEVICES];
 std::mutex g_q_mu;
-bool queue_aware_on() {
-    static const bool on = [] {
-        const char *e = std::getenv("MANTA_QUEUE_AWARE");
-        return !(e && std::atoi(e) == 0);
-    }();
-    return on;
-}
+bool queue_aware_on() { return tuning().queue_aware != 0; }
 hipStream_t new_stream(int pr) {
     hipStream_t s = nullptr;
     int lo = 0, hi = 0;

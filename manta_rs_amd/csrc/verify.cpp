@@ -13,6 +13,7 @@
 //     prod_i ML(r_i A_i, B_i) . ML(sum_i r_i PI_i, -gamma) . ML(sum_i r_i C_i, -delta) . ML(-(sum_i r_i) alpha, beta)  -> 1
 // i.e. k + 3 Miller loops (one wavefront each, pairing_coop.h), two small MSMs and ONE final exponentiation for k proofs.
 #include "verify.h"
+#include "tuning.h"
 #include "host_ec.h"
 #include "params_gen.h"
 #include "prover.h"
@@ -261,8 +262,7 @@ template <class Curve, class K> class VerifierT : public Verifier {
         // -- the third Miller loop, which waits for it, no longer ends after the other two (tools/abc_sweep_r4.sh;
         // MANTA_VERIFY_ABC_C = 0: plain bases as in round 3, c > 0: window tables, c < 0: full tables of |c|-bit windows)
         static const int abc_c = [] {
-            const char *e = getenv("MANTA_VERIFY_ABC_C");
-            return e ? atoi(e) : -6;
+            return ab_knob("MANTA_VERIFY_ABC_C", -6);
         }();
         int rc = g1_->bases_create((const u32 *)abc_.data(), P_, false, abc_c, &abc_bs_);
         if (rc) return rc;

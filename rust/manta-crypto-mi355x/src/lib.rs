@@ -222,6 +222,23 @@ pub struct ContextOptions<'d> {
     /// HBM the context may spend on full tables (single proofs run on them); `None` = a tenth of the device's HBM,
     /// `Some(0)` = bucket tables only
     pub full_table_bytes: Option<u64>,
+    /// this context's scheduling (`mg_ctx_opts.tuning`); `None` = the process-wide values ([`tuning`] / [`set_tuning`])
+    pub tuning: Option<sys::mg_tuning>,
+}
+
+/// The process-wide tuning in force (`mg_get_tuning`): the compiled-in defaults, the `MANTA_*` variables of
+/// `mg_tuning_env_names` applied once, then whatever [`set_tuning`] stated. No field changes a proof's bytes.
+pub fn tuning() -> Result<sys::mg_tuning, Error> {
+    let mut t = core::mem::MaybeUninit::<sys::mg_tuning>::zeroed();
+    // SAFETY: mg_get_tuning writes every field
+    check(unsafe { sys::mg_get_tuning(t.as_mut_ptr()) })?;
+    Ok(unsafe { t.assume_init() })
+}
+
+/// States the process-wide tuning for contexts created from now on (`mg_set_tuning`): validated as a whole, an
+/// out-of-range field is an `Err` and leaves everything as it was.
+pub fn set_tuning(t: &sys::mg_tuning) -> Result<(), Error> {
+    check(unsafe { sys::mg_set_tuning(t) })
 }
 
 impl<E: Mi355xCurve> GpuProvingContext<E> {
@@ -245,6 +262,9 @@ impl<E: Mi355xCurve> GpuProvingContext<E> {
         }
         if let Some(b) = options.full_table_bytes {
             o.full_table_bytes = b.min(i64::MAX as u64) as i64;
+        }
+        if let Some(t) = options.tuning.as_ref() {
+            o.tuning = t; // (read during mg_ctx_create_ex: `options` outlives the call)
         }
         Ok(o)
     }

@@ -83,6 +83,33 @@ pub struct mg_pk_view {
 }
 
 /// One matrix of `ConstraintSystemRef::to_matrices()` in CSR form.
+/// `mg_tuning`: what a deployment decides about the library's scheduling (graph topology, streams per proof, coalescing window,
+/// passes in flight, window widths of the key tables, table budget, queue placement). Fill it with `mg_tuning_init` (compiled-in
+/// defaults) or `mg_get_tuning` (the process-wide values), change fields, hand it to `mg_set_tuning` or to one context through
+/// `mg_ctx_opts::tuning`. No field changes a proof's bytes.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub struct mg_tuning {
+    pub struct_size: u32,
+    pub graph_mode: i32,
+    pub graph_mode_batch: i32,
+    pub prove_streams: i32,
+    pub linear_chains: i32,
+    pub coalesce_inflight: i32,
+    pub coalesce_gather_us: i32,
+    pub batch_inflight: i32,
+    pub queue_aware: i32,
+    pub msm_dedicated_queues: i32,
+    pub window_bits_narrow: i32,
+    pub window_bits_wide: i32,
+    pub window_bits_h: i32,
+    pub window_bits_g2: i32,
+    pub full_table_bytes: i64,
+}
+pub const MG_GRAPH_OFF: i32 = 0;
+pub const MG_GRAPH_SINGLE: i32 = 1;
+pub const MG_GRAPH_SPLIT: i32 = 2;
+
 /// `mg_ctx_opts`: what a deployment decides per context (placement, exchange, HBM budget of the full tables). Fill it with
 /// `mg_ctx_opts_init`, then change fields; `struct_size` lets the C side accept an older, shorter struct.
 #[repr(C)]
@@ -96,6 +123,7 @@ pub struct mg_ctx_opts {
     pub shard: i32,
     pub n_shards: i32,
     pub task_mask: u32,
+    pub tuning: *const mg_tuning,
 }
 pub const MG_EXCHANGE_HOST: u32 = 0;
 pub const MG_EXCHANGE_RCCL: u32 = 1;
@@ -248,6 +276,10 @@ extern "C" {
         out: *const mg_pk_out,
     ) -> c_int;
     pub fn mg_ctx_create(curve: mg_curve_t, pk: *const mg_pk_view, out: *mut *mut mg_ctx) -> c_int;
+    pub fn mg_tuning_init(t: *mut mg_tuning) -> c_int;
+    pub fn mg_get_tuning(t: *mut mg_tuning) -> c_int;
+    pub fn mg_set_tuning(t: *const mg_tuning) -> c_int;
+    pub fn mg_tuning_env_names() -> *const *const c_char;
     pub fn mg_ctx_opts_init(opts: *mut mg_ctx_opts) -> c_int;
     pub fn mg_ctx_create_ex(curve: mg_curve_t, pk: *const mg_pk_view, opts: *const mg_ctx_opts, out: *mut *mut mg_ctx) -> c_int;
     pub fn mg_ctx_create_from_bytes_ex(

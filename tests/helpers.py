@@ -1,4 +1,6 @@
 """Shared test helpers: seeded inputs for the parity tests (oracle = checker, HIP library = product)."""
+import os
+
 import numpy as np
 
 import oracle_lib as O
@@ -23,3 +25,21 @@ def rand_fr_mont(curve, n, seed=11):
     rng = synth.XorShift(seed)
     p = synth.FR_MODULUS[curve]
     return synth.to_mont([rng.field(p) for _ in range(n)], p, 4)
+
+
+def knob_env(knobs, base=None, strip_prefix=None):
+    """Environment of a child process that runs under `knobs`. The names of the tuning table (mg_tuning_env_names) act on the SHIPPED
+    library; every other MANTA_* / MG_DIAG_* knob is an A/B switch of a measurement campaign that the shipped library has compiled in
+    at its default -- it exists in the diagnosis twin (every unit built with -DMG_DIAG), which the child then loads through MANTA_LIB.
+    strip_prefix: drop inherited variables with this prefix first."""
+    from manta_rs_amd import api
+    env = dict(os.environ if base is None else base)
+    if strip_prefix:
+        env = {k: v for k, v in env.items() if not k.startswith(strip_prefix)}
+    env.update(knobs)
+    shipped = set(api.tuning_env_names())
+    if any(k not in shipped for k in knobs if k.startswith(("MANTA_", "MG_DIAG_")) and k != "MANTA_LIB"):
+        diag = os.path.join(os.path.dirname(api.LIB_PATH), "libmantagpu_diag.so")
+        assert os.path.exists(diag), "manta_rs_amd/csrc/Makefile builds the diagnosis twin next to the library"
+        env.setdefault("MANTA_LIB", diag)
+    return env

@@ -250,7 +250,7 @@ def test_msm_reduce_front_levels(gpu, curve, group, pres, env):
     import subprocess
     import sys
     code = _FRONT_SCRIPT.format(root=ROOT, curve=curve, group=group, pres=pres)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, "-c", code], env=H.knob_env(env), capture_output=True, text=True, timeout=900)  # (the diagnosis twin)
     assert out.returncode == 0 and "front levels ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 

@@ -166,8 +166,7 @@ def test_single_proof_host_fold_variants(gpu):
     two = [O.groth16_prove(c, pk, rs[0], rs[1]).hex(), O.groth16_prove(c, pk, rs[2], rs[3]).hex()]
     want = [two[i & 1] for i in range(5)]
     for knobs in ({}, {"MANTA_Z3_EARLY": "0"}, {"MANTA_Z3_SORT": "1"}, {"MANTA_Z3_EARLY": "0", "MANTA_Z3_SORT": "1"}, {"MANTA_Z3": "0"}):
-        env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_Z3")}
-        env.update(knobs)
+        env = H.knob_env(knobs, strip_prefix="MANTA_Z3")  # (A/B switches: the diagnosis twin)
         out = subprocess.run([sys.executable, "-c", _Z3_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
         assert [ln.split()[1] for ln in out.stdout.split("\n") if ln.startswith("PROOF")] == want, knobs
@@ -230,8 +229,7 @@ def test_round5_knobs_do_not_change_results(gpu):
                 {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"}, {"MANTA_QUEUE_AWARE": "0"},
                 {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_LINEAR": "2"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
     for knobs in variants:
-        env = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_")}
-        env.update(knobs)
+        env = H.knob_env(knobs, strip_prefix="MANTA_")  # tuning-table names: the shipped library; A/B switches: the diagnosis twin
         out = subprocess.run([sys.executable, "-c", _R5_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, (knobs, out.stdout[-2000:] + out.stderr[-2000:])
         lines = out.stdout.split("\n")

@@ -132,3 +132,129 @@ def test_bls12_381_2_15_circuit(gpu, prof):
     for q in (1, 2):
         assert got[q] == O.groth16_prove(cs[q], pk, rs[2 * q], rs[2 * q + 1])
     ctx.close()
+
+
+# ---- tuning: every field of mg_tuning and every environment variable the shipped library reads ---------------
+_TUNING_CASES = {  # one non-default value per variable of mg_tuning_env_names (MANTA_RCCL_LIB is a path, not a schedule)
+    "MANTA_GRAPH": ("split", "off"), "MANTA_GRAPH_BATCH": ("off",), "MANTA_PROVE_STREAMS": ("3",), "MANTA_Z3_LINEAR": ("0",),
+    "MANTA_COALESCE": ("0",), "MANTA_COALESCE_GATHER_US": ("0",), "MANTA_BATCH_INFLIGHT": ("1",), "MANTA_QUEUE_AWARE": ("0",),
+    "MANTA_MSM_DEDICATED_QUEUES": ("0",), "MANTA_PROVE_C": ("7",), "MANTA_PROVE_CW": ("9",), "MANTA_PROVE_CH": ("10",),
+    "MANTA_PROVE_CG2": ("8",), "MANTA_FULL_TABLE_GB": ("0.5",),
+}
+_TUNING_SCRIPT = '''
+import os, sys, threading
+sys.path.insert(0, r"{root}"); sys.path.insert(0, os.path.join(r"{root}", "tests"))
+import numpy as np
+import helpers as H
+from manta_rs_amd import api as gpu, synth, keygen
+gpu.init(0)
+assert gpu.LIB_PATH.endswith("libmantagpu.so"), gpu.LIB_PATH     # the SHIPPED library
+print("TUNING", sorted(gpu.get_tuning().as_dict().items()))
+c = synth.make_shape(0, "to_public", profile="W")
+pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+ctx = gpu.ProvingContext(0, pk)
+ctx.set_r1cs(gpu.R1CS.from_circuit(c))
+rs = H.rand_fr_mont(0, 4, seed=98)
+rs[2][:] = 0
+z2 = synth.Reassigner(c).assign(0x5EED).z
+for i in range(5):
+    print("PROOF", gpu.Groth16.prove_with_randomness(ctx, z2 if i & 1 else c.z, rs[2 * (i & 1)], rs[2 * (i & 1) + 1]).hex())
+for rep in range(4):
+    got = gpu.Groth16.prove_batch(ctx, np.stack([c.z, z2] * 4), np.stack([rs[0], rs[2]] * 4), np.stack([rs[1], rs[3]] * 4))
+    print("BATCH", " ".join(g.hex() for g in got))
+big = gpu.Groth16.prove_batch(ctx, np.stack([c.z, z2] * 40), np.stack([rs[0], rs[2]] * 40), np.stack([rs[1], rs[3]] * 40))  # three passes
+print("BIG", len(big), len(set(big[0::2])), len(set(big[1::2])), big[0].hex(), big[1].hex())
+def worker(t):
+    for i in range(10):
+        j = (i + t) & 1
+        print("CONC %d %s" % (j, gpu.Groth16.prove_with_randomness(ctx, z2 if j else c.z, rs[2 * j], rs[2 * j + 1]).hex()), flush=True)
+ts = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+# a stand-alone MSM, three in flight (MANTA_MSM_DEDICATED_QUEUES)
+pts = H.random_points(0, 1, 1500, seed=3)
+pts = np.concatenate([pts] * 4)
+sc = synth.msm_scalars(0, pts.shape[0], "U", seed=4)
+b = gpu.Bases(0, 1, pts, precompute_window_bits=11)
+d = gpu.DeviceBuffer.from_numpy(sc)
+jobs = [gpu.VariableBaseMSM.launch(b, d, pts.shape[0]) for _ in range(3)]
+print("MSM", " ".join(bytes(j.finish()).hex() for j in jobs))
+'''
+
+
+def _tuning_truth():
+    c = synth.make_shape(0, "to_public", profile="W")
+    pk = keygen.generate(c, synth.from_mont(H.toxic(0, seed=6), synth.FR_MODULUS[0]))
+    rs = H.rand_fr_mont(0, 4, seed=98)
+    rs[2][:] = 0
+    z2 = synth.Reassigner(c).assign(0x5EED).z
+    _fast_oracle()
+    two = [O.groth16_prove(c, pk, rs[0], rs[1]).hex(), O.groth16_prove(c, pk, rs[2], rs[3], z=z2).hex()]
+    pts = np.concatenate([H.random_points(0, 1, 1500, seed=3)] * 4)
+    msm = bytes(O.msm(0, 1, pts, synth.msm_scalars(0, pts.shape[0], "U", seed=4), algo=1)).hex()
+    return c, pk, rs, z2, two, msm
+
+
+def _check_tuning_child(out, two, msm, what):
+    assert out.returncode == 0, (what, out.stdout[-2000:] + out.stderr[-2000:])
+    lines = out.stdout.split("\n")
+    assert [ln.split()[1] for ln in lines if ln.startswith("PROOF")] == [two[i & 1] for i in range(5)], what
+    batches = [ln[6:] for ln in lines if ln.startswith("BATCH")]
+    assert len(batches) == 4 and all(b == " ".join(two * 4) for b in batches), what
+    big = [ln.split() for ln in lines if ln.startswith("BIG")]
+    assert big == [["BIG", "80", "1", "1", two[0], two[1]]], what
+    conc = [ln.split() for ln in lines if ln.startswith("CONC")]
+    assert len(conc) == 30 and all(two[int(j)] == h for _, j, h in conc), what
+    assert [ln for ln in lines if ln.startswith("MSM")] == ["MSM " + " ".join([msm] * 3)], what
+    return [ln for ln in lines if ln.startswith("TUNING")][0]
+
+
+def test_every_environment_variable_of_the_shipped_library_leaves_results_unchanged(gpu):
+    """VERDICT r5 item 7: the shipped library reads the variables mg_tuning_env_names() lists and no other (tests/test_host.py checks
+    the binary). Each one, set to a non-default value in a process of its own (the table is read once), must leave every result what
+    the oracle says: single proofs (eager, captured, replayed; r = 0; two assignments), passes of 8, a batch of 80 streamed as three
+    passes, single calls from three host threads at once (coalesced), and three stand-alone MSMs in flight. The child also prints
+    the tuning in force, so a variable that the table silently ignored fails here."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = [n for n in gpu.tuning_env_names() if n != "MANTA_RCCL_LIB"]
+    assert sorted(names) == sorted(_TUNING_CASES), "a variable was added to the library's table without a case here"
+    c, pk, rs, z2, two, msm = _tuning_truth()
+    base = {k: v for k, v in os.environ.items() if not k.startswith("MANTA_")}
+    default = _check_tuning_child(subprocess.run([sys.executable, "-c", _TUNING_SCRIPT.format(root=root)], env=base, capture_output=True, text=True,
+                                                 timeout=900), two, msm, "defaults")
+    for name in names:
+        for value in _TUNING_CASES[name]:
+            out = subprocess.run([sys.executable, "-c", _TUNING_SCRIPT.format(root=root)], env=dict(base, **{name: value}), capture_output=True,
+                                 text=True, timeout=900)
+            assert _check_tuning_child(out, two, msm, (name, value)) != default, (name, value, "the variable did not reach the tuning")
+
+
+def test_per_context_tuning_through_the_abi_leaves_results_unchanged(gpu):
+    """mg_ctx_opts.tuning: contexts of ONE process under different tuning structs (what a Rust host does instead of exporting
+    variables) -- every field at a non-default value, the process-wide values untouched -- give the oracle's bytes; a struct with
+    an out-of-range field is refused and creates nothing."""
+    c, pk, rs, z2, two, _ = _tuning_truth()
+    before = gpu.get_tuning().as_dict()
+    cases = [dict(graph_mode=gpu.GRAPH_SPLIT), dict(graph_mode=gpu.GRAPH_OFF), dict(graph_mode_batch=gpu.GRAPH_OFF), dict(prove_streams=3),
+             dict(prove_streams=4, linear_chains=0), dict(linear_chains=1), dict(coalesce_inflight=0), dict(coalesce_inflight=4, coalesce_gather_us=0),
+             dict(batch_inflight=1), dict(queue_aware=0), dict(window_bits_narrow=7), dict(window_bits_wide=9, window_bits_h=10, window_bits_g2=8),
+             dict(full_table_bytes=500_000_000), dict(full_table_bytes=0)]
+    assert set(k for cs in cases for k in cs) | {"msm_dedicated_queues"} == set(before), "a field of mg_tuning has no case here"
+    r1cs = gpu.R1CS.from_circuit(c)
+    for cs in cases:
+        ctx = gpu.ProvingContext(0, pk, tuning=cs)
+        ctx.set_r1cs(r1cs)
+        for i in range(5):
+            assert gpu.Groth16.prove_with_randomness(ctx, z2 if i & 1 else c.z, rs[2 * (i & 1)], rs[2 * (i & 1) + 1]).hex() == two[i & 1], (cs, i)
+        for rep in range(3):
+            got = gpu.Groth16.prove_batch(ctx, np.stack([c.z, z2] * 4), np.stack([rs[0], rs[2]] * 4), np.stack([rs[1], rs[3]] * 4))
+            assert [g.hex() for g in got] == two * 4, (cs, rep)
+        if cs.get("full_table_bytes") == 0:
+            assert ctx.table_bytes()[1] == 0
+        ctx.close()
+    assert gpu.get_tuning().as_dict() == before  # per-context tuning does not leak into the process
+    with pytest.raises(gpu.MantaGpuError):
+        gpu.ProvingContext(0, pk, tuning=gpu.get_tuning().replace(prove_streams=2))

@@ -245,13 +245,13 @@ def test_shard_ranges_tile_the_index_space():
 
 def test_rust_sys_crate_declares_exactly_the_header():
     """rust/mantagpu-sys/src/lib.rs (source only: no Rust toolchain here) must bind every entry point of mantagpu.h
-    and nothing else, and mirror the three structs that cross the ABI field for field."""
+    and nothing else, and mirror the structs that cross the ABI field for field (mg_tuning and mg_ctx_opts since round 6)."""
     hdr = open(os.path.join(ROOT, "include", "mantagpu.h")).read()
     rs = open(os.path.join(ROOT, "rust", "mantagpu-sys", "src", "lib.rs")).read()
     declared = set(re.findall(r"\b(mg_[a-z0-9_]+)\s*\(", hdr))
     bound = set(re.findall(r"pub fn (mg_[a-z0-9_]+)\s*\(", rs))
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
-    for struct, n_fields in (("mg_pk_view", 13), ("mg_csr", 4), ("mg_pk_out", 12)):
+    for struct, n_fields in (("mg_pk_view", 13), ("mg_csr", 4), ("mg_pk_out", 12), ("mg_tuning", 15), ("mg_ctx_opts", 9)):
         body = re.search(r"pub struct %s \{(.*?)\n\}" % struct, rs, re.S).group(1)
         assert len(re.findall(r"pub \w+:", body)) == n_fields, struct
         end = hdr.index("} %s;" % struct)
@@ -351,3 +351,39 @@ def test_bench_rank_refuses_a_launcher_that_disagrees(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert out.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in out.stderr and "AssertionError" not in out.stderr
+
+
+def test_tuning_crosses_the_abi_and_the_library_reads_fifteen_variables():
+    """VERDICT r5 item 7: what a deployment decides lives in `mg_tuning` (C header == Python mirror == Rust mirror, checked above);
+    the shipped library reads the environment in ONE place -- the table behind mg_tuning_env_names (<= 15 names) -- and every
+    other knob of the measurement campaigns is compiled in: the shipped binary holds no other MANTA_* name, the diagnosis twin
+    (every unit built with -DMG_DIAG) does. mg_set_tuning validates as a whole."""
+    import ctypes
+    import subprocess
+    from manta_rs_amd import api
+    names = api.tuning_env_names()
+    assert len(names) == len(set(names)) <= 15 and "MANTA_RCCL_LIB" in names and "MANTA_GRAPH" in names
+    blob = open(api.LIB_PATH, "rb").read()
+    found = set(m.decode() for m in re.findall(rb"MANTA_[A-Z0-9_]{2,}", blob))
+    assert found <= set(names) | {"MANTA_"}, sorted(found - set(names))  # nothing else is even a string of the release library
+    src = ""
+    for f in os.listdir(os.path.join(ROOT, "manta_rs_amd", "csrc")):
+        if f.endswith((".cpp", ".h", ".hip")) and f != "tuning.h":
+            src += open(os.path.join(ROOT, "manta_rs_amd", "csrc", f)).read()
+    sites = [ln for ln in src.splitlines() if re.search(r"\bgetenv\(", ln) and "MG_CALIBRATION" not in ln]
+    assert len(sites) <= 3, sites  # the tuning table's loop, MANTA_RCCL_LIB, and nothing that is not named above
+    diag = os.path.join(os.path.dirname(api.LIB_PATH), "libmantagpu_diag.so")
+    assert b"MANTA_RED_MIN" in open(diag, "rb").read()  # the A/B knobs live on in the diagnosis twin
+    # defaults, get, set (in a child: process-wide state), refusal of an out-of-range field
+    d = api.tuning_defaults()
+    assert d.as_dict() == dict(graph_mode=1, graph_mode_batch=-1, prove_streams=6, linear_chains=3, coalesce_inflight=2, coalesce_gather_us=100,
+                               batch_inflight=3, queue_aware=1, msm_dedicated_queues=1, window_bits_narrow=0, window_bits_wide=0, window_bits_h=0,
+                               window_bits_g2=0, full_table_bytes=-1)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom manta_rs_amd import api\n"
+            "t = api.get_tuning(); assert t.graph_mode == 2 and t.coalesce_inflight == 0 and t.full_table_bytes == 3500000000 and t.prove_streams == 6, t.as_dict()\n"
+            "api.set_tuning(graph_mode=0, batch_inflight=2); t = api.get_tuning(); assert t.graph_mode == 0 and t.batch_inflight == 2 and t.coalesce_inflight == 0\n"
+            "try:\n    api.set_tuning(prove_streams=7); raise SystemExit('accepted prove_streams=7')\nexcept api.MantaGpuError: pass\n"
+            "assert api.get_tuning().prove_streams == 6\nprint('tuning ok')\n" % ROOT)
+    env = dict(os.environ, MANTA_GRAPH="split", MANTA_COALESCE="0", MANTA_FULL_TABLE_GB="3.5", MANTA_PROVE_STREAMS="9")  # 9: out of range, ignored
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "tuning ok" in out.stdout, out.stdout + out.stderr
