@@ -1840,8 +1840,18 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // (profiles/r03_front_levels_ab.txt). The plain sums ride on ONE high-priority side stream per engine: a side stream per
             // workspace aliased the runtime's four normal-priority hardware queues and cost the pipelined rate 10-15 % by itself.
             const int lgS_eff = rk.lgS >= 0 ? rk.lgS : 3;
-            if (lgS_eff > 0 && rn >= rk.min_items && !ws->in_graph_slot) {
-                if (!ws->capturing && !ws->run_on && rk.side) {
+            // (MANTA_FRONT_IN_GRAPH, diagnosis builds only: the front levels inside a proof slot's captures -- DESIGN section 6)
+            static const bool front_in_graph = ab_knob("MANTA_FRONT_IN_GRAPH", 0) != 0;
+            if (lgS_eff > 0 && rn >= rk.min_items && (!ws->in_graph_slot || front_in_graph)) {
+                // The side stream is for STAND-ALONE launches only, and never for a stream that is being captured. Round 6 root cause
+                // (profiles/r06_front_levels_in_graph.txt): inside the forked capture of a proof slot the four G1 MSMs are four
+                // branches, and the ONE side stream of the engine was forked from and joined into each of them in turn -- the
+                // runtime's per-stream lists of "parallel capture streams" became cyclic (branch a <-> side <-> branch b) and
+                // hipStreamEndCapture recursed over them until the stack was gone (SIGSEGV in hip::Stream::EndCapture, 25+ frames
+                // of itself). That was the "pass fails" of profiles/r05_batched_ab.txt (3) and the reason behind in_graph_slot.
+                hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+                const bool being_captured = hipStreamIsCapturing(s, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
+                if (!ws->capturing && !ws->run_on && !ws->in_graph_slot && !being_captured && rk.side) {
                     // ONE side stream per engine, high priority (= the runtime's other pool of hardware queues): a stream per
                     // workspace put six streams on the four normal-priority queues and cost the pipelined rate 15 % through
                     // aliasing alone, whether or not the side stream was used (measured: 308 against 365 Mscalar/s)

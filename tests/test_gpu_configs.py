@@ -43,14 +43,15 @@ def test_config2_g2_msm_2_20_closed_form(gpu, pre):
     assert (gpu.VariableBaseMSM.launch(b, gpu.DeviceBuffer.from_numpy(sc), m).finish() == O.msm(curve, 2, host, sc)).all()
 
 
-@pytest.mark.parametrize("profile", ["sparse", "W"])
-def test_config2_bls12_381_proof_at_2_20(gpu, profile):
+@pytest.mark.parametrize("curve,profile", [(1, "sparse"), (1, "W"), (0, "W")])
+def test_config2_proof_at_2_20(gpu, curve, profile):
     """configs[2] end to end: D = V = 2^20, P = 16 synthetic circuit over BLS12-381 -- 7 NTTs of 2^20, 3 SpMVs, four G1
     MSMs and one G2 MSM of ~2^20 terms each. The proof bytes equal the CPU oracle's (all host cores: tens of seconds) and the
     proof satisfies the pairing equation; replayed through the captured hipGraphs it stays the same bytes. `W` is the witness
     bench.py's config2 leg proves (same seeds: 40 / 25 / 10 / 25 split -- the zero-digit compaction, the pair-count-dependent chunk
-    length and the 13-bit G2 windows at full size: VERDICT r4 item 5); `sparse` the generator of rounds 1-3."""
-    curve, lg, P = 1, 20, 16
+    length and the 13-bit G2 windows at full size: VERDICT r4 item 5); `sparse` the generator of rounds 1-3. Round 6: the same
+    proof over BN254, manta-pay's own curve (SURVEY.md 8(d) config 3 names both; manta-pay/src/config/mod.rs:40,79)."""
+    lg, P = 20, 16
     D = 1 << lg
     c = synth.make_circuit(curve, D - P, D, P, seed=0x4D414E5441_0301, profile=profile)
     assert (c.D, c.V) == (D, D)

@@ -242,6 +242,9 @@ print("front levels ok")
     (1, 1, (14, 18), {"MANTA_RED_S": "2", "MANTA_RED_MIN": "1024", "MANTA_RED_SIDE": "0", "MANTA_RED_SP": "2"}),  # many levels, inline
     (0, 1, (16,), {"MANTA_RED_S": "3", "MANTA_RED_S0": "3"}),
     (0, 2, (15,), {"MANTA_RED_S": "3", "MANTA_RED_MIN": "2048"}),                        # G2: the additions are calls
+    (0, 1, (9, 13), {"MANTA_RED_MIN": "128"}),                                            # the lowest threshold the knob takes
+    (1, 1, (12, 16), {"MANTA_RED_MIN": "1024"}),
+    (0, 1, (13, 16), {"MANTA_RED_MIN": "16384"}),                                         # the default threshold, stated
 ])
 def test_msm_reduce_front_levels(gpu, curve, group, pres, env):
     """The optional work-efficient front levels of the bucket reduce (serial_reduce / serial_reduce_coop, msm_impl.h; off by
@@ -276,3 +279,23 @@ def test_msm_result_folded_on_the_device(gpu, curve, group, n, pre):
     with pytest.raises(gpu.MantaGpuError):
         plain.result_to_device(out.ptr)
     assert (plain.finish() == want).all()
+
+
+@pytest.mark.parametrize("min_items", [128, 1024, 16384])
+def test_front_levels_inside_captured_passes(gpu, min_items):
+    """VERDICT r5 item 5. Round 5 saw "the pass fails" with the front levels inside the captured graphs of a batched pass and
+    MANTA_RED_MIN=1024, deleted the knob and kept the restriction. Root cause (round 6, profiles/r06_front_levels_in_graph.txt): the
+    engine's ONE side stream joined the forked capture from several branches, the runtime's per-stream lists of parallel capture
+    streams became cyclic, and hipStreamEndCapture recursed until the stack was gone. The side stream no longer joins any capture;
+    with that, passes of 8 proofs whose MSMs run their front levels INSIDE the slot's graphs (diagnosis twin, MANTA_FRONT_IN_GRAPH=1)
+    are the oracle's -- eager, eager, capture, replay, replay -- for thresholds 128 / 1 024 (front levels in every MSM of the
+    pass) and 16 384 (the default: none qualifies), in the forked topology and in the split one."""
+    import subprocess
+    import sys
+    for extra in ({}, {"MANTA_GRAPH_BATCH": "split"}):
+        env = H.knob_env(dict({"MANTA_FRONT_IN_GRAPH": "1", "MANTA_RED_MIN": str(min_items)}, **extra), strip_prefix="MANTA_")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_front_in_graph.py"), "8", "to_public"], env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        ok = [ln for ln in out.stdout.splitlines() if ln.endswith("8 proofs == oracle")]
+        assert len(ok) == 5 and "libmantagpu_diag.so" in out.stdout, out.stdout[-2000:]
