@@ -71,7 +71,10 @@ def pmc_traffic():
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mg_pmc_", dir="/tmp")
-        env = dict(os.environ, TMPDIR="/tmp", MANTA_BENCH_NO_PMC="1")
+        # one MSM at a time on an ordinary stream: the counters of a dispatch are then that kernel's alone (with three MSMs in flight on
+        # hardware queues of their own, the neighbours' digit / sort kernels run beside the accumulate kernel and their bytes land in
+        # its sample: 3.0 GB instead of 1.95 GB per launch, round 6)
+        env = dict(os.environ, TMPDIR="/tmp", MANTA_BENCH_NO_PMC="1", MANTA_BENCH_DEPTH="1", MANTA_MSM_DEDICATED_QUEUES="0")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "m", "--", sys.executable, os.path.abspath(__file__), "--workload", "msm",
                "--quick", "--no-cpu-baseline", "--steps", "3", "--warmup", "1"]
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)

@@ -1107,7 +1107,8 @@ class ProverImpl : public Prover {
         // CAPTURE_TRIES such passes it waits.
         std::unique_lock<std::shared_mutex> no_heavy_ops_meanwhile(capture_mutex(), std::try_to_lock);
         if (!no_heavy_ops_meanwhile.owns_lock()) {
-            if (++w->capture_tries < CAPTURE_TRIES) return false;
+            static const int tries = ab_knob("MANTA_CAPTURE_TRIES", CAPTURE_TRIES);
+            if (++w->capture_tries < tries) return false;
             no_heavy_ops_meanwhile.lock();
         }
         w->capture_tries = 0;
