@@ -83,11 +83,11 @@ MG_API int mg_host_free(void *hptr) {
     return MG_SUCCESS;
 }
 MG_API int mg_memcpy_h2d(void *d, const void *h, size_t bytes) {
-    MG_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice));
+    MG_HIP(memcpy_sync(d, h, bytes, hipMemcpyHostToDevice)); // (the calling thread's setup stream, not the NULL stream: engine.h)
     return MG_SUCCESS;
 }
 MG_API int mg_memcpy_d2h(void *h, const void *d, size_t bytes) {
-    MG_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost));
+    MG_HIP(memcpy_sync(h, d, bytes, hipMemcpyDeviceToHost));
     return MG_SUCCESS;
 }
 MG_API int mg_device_synchronize(void) {
@@ -237,7 +237,7 @@ static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, co
         hipError_t he = hipSetDevice(s.device);
         if (he == hipSuccess && host_scalars) {
             he = hipMalloc(&d_tmp, n * 32);
-            if (he == hipSuccess) he = hipMemcpy(d_tmp, host_scalars + s.lo * 4, n * 32, hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = memcpy_sync(d_tmp, host_scalars + s.lo * 4, n * 32, hipMemcpyHostToDevice);
             d_sc = (const u32 *)d_tmp;
         }
         if (he != hipSuccess) {
@@ -433,9 +433,9 @@ MG_API int mg_ntt_device(mg_curve_t curve, uint64_t *d_data, unsigned log_n, int
     if (!d_data) return MG_ERROR_INVALID_ARGUMENT;
     NttEngine *n = get_ntt_engine((int)curve);
     if (!n) return MG_ERROR_INVALID_ARGUMENT;
-    int rc = n->transform((u32 *)d_data, log_n, inverse != 0, coset != 0, nullptr);
+    int rc = n->transform((u32 *)d_data, log_n, inverse != 0, coset != 0, setup_stream());
     if (rc) return rc;
-    MG_HIP(hipStreamSynchronize(nullptr));
+    MG_HIP(setup_sync());
     return MG_SUCCESS;
     MG_CATCH
 }
@@ -446,9 +446,9 @@ MG_API int mg_ntt(mg_curve_t curve, uint64_t *data, unsigned log_n, int inverse,
     void *d = nullptr;
     MG_HIP(hipMalloc(&d, bytes));
     int rc = MG_SUCCESS;
-    if (hipMemcpy(d, data, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = MG_ERROR_HIP;
+    if (memcpy_sync(d, data, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = MG_ERROR_HIP;
     if (!rc) rc = mg_ntt_device(curve, (uint64_t *)d, log_n, inverse, coset);
-    if (!rc && hipMemcpy(data, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = MG_ERROR_HIP;
+    if (!rc && memcpy_sync(data, d, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = MG_ERROR_HIP;
     hipFree(d);
     return rc;
     MG_CATCH

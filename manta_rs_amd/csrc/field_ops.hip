@@ -86,12 +86,12 @@ template <class C> static int run(int op, int repr, int lazy_a, int lazy_b, cons
     hipError_t e = hipMalloc((void **)&da, bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&dout, bytes);
     if (e == hipSuccess && b) e = hipMalloc((void **)&db, bytes);
-    if (e == hipSuccess) e = hipMemcpy(da, a, bytes, hipMemcpyHostToDevice);
-    if (e == hipSuccess && b) e = hipMemcpy(db, b, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = memcpy_sync(da, a, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b) e = memcpy_sync(db, b, bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL((field_op_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, repr, lazy_a, lazy_b, da, db,
+        hipLaunchKernelGGL((field_op_kernel<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, setup_stream(), op, repr, lazy_a, lazy_b, da, db,
                            dout, n);
-        e = hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost);
+        e = memcpy_sync(out, dout, bytes, hipMemcpyDeviceToHost);
     }
     hipFree(da);
     hipFree(db);
@@ -163,13 +163,13 @@ int clock_probe(u32 iters, double *memtime_mhz, double *mad_issue_per_us_per_sim
     hipEvent_t e0, e1;
     MG_HIP(hipEventCreate(&e0));
     MG_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, 0, 64u, 1u, d); // warm-up
-    MG_HIP(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, 0, iters, 2u, d);
-    MG_HIP(hipEventRecord(e1, 0));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, setup_stream(), 64u, 1u, d); // warm-up
+    MG_HIP(hipEventRecord(e0, setup_stream()));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(blocks), dim3(256), 0, setup_stream(), iters, 2u, d);
+    MG_HIP(hipEventRecord(e1, setup_stream()));
     hipError_t e = hipEventSynchronize(e1);
     std::vector<unsigned long long> h(waves * 3);
-    if (e == hipSuccess) e = hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = memcpy_sync(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
     float t = 0.f;
     hipEventElapsedTime(&t, e0, e1);
     hipFree(d);

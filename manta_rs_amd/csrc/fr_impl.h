@@ -755,35 +755,35 @@ template <class FrC> class FrEngineT : public FrEngine {
             }
         }
         n_inv.store_words(&hsq[4 * 33 * 8]);
-        MG_HIP(hipMemcpy(d_sq, hsq.data(), hsq.size() * 4, hipMemcpyHostToDevice));
+        MG_HIP(memcpy_sync(d_sq, hsq.data(), hsq.size() * 4, hipMemcpyHostToDevice));
         const int bits = (int)log_n;
         const u32 gh = (u32)((half + 255) / 256), gn = (u32)((n + 255) / 256);
-        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gh), dim3(256), 0, 0, d.tw_fwd, d_sq, (u32)half, bits,
+        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gh), dim3(256), 0, setup_stream(), d.tw_fwd, d_sq, (u32)half, bits,
                            (const u32 *)nullptr);
-        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gh), dim3(256), 0, 0, d.tw_inv, d_sq + 33 * 8, (u32)half, bits,
+        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gh), dim3(256), 0, setup_stream(), d.tw_inv, d_sq + 33 * 8, (u32)half, bits,
                            (const u32 *)nullptr);
-        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.coset_fwd, d_sq + 2 * 33 * 8, (u32)n,
+        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, setup_stream(), d.coset_fwd, d_sq + 2 * 33 * 8, (u32)n,
                            bits + 1, (const u32 *)nullptr);
-        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.coset_inv, d_sq + 3 * 33 * 8, (u32)n,
+        hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, setup_stream(), d.coset_inv, d_sq + 3 * 33 * 8, (u32)n,
                            bits + 1, (const u32 *)(d_sq + 4 * 33 * 8));
         u32 hc[16];
         n_inv.store_words(hc);
         zinv.store_words(hc + 8);
-        MG_HIP(hipMemcpy(d.consts, hc, 64, hipMemcpyHostToDevice));
+        MG_HIP(memcpy_sync(d.consts, hc, 64, hipMemcpyHostToDevice));
         // bit-reversed scale tables of the permutation-free witness-map pipeline
         MG_HIP(hipMalloc((void **)&d.t1_br, n * 32));
         MG_HIP(hipMalloc((void **)&d.t2_br, n * 32));
         {
             u32 *tmp = nullptr;
             MG_HIP(hipMalloc((void **)&tmp, n * 32));
-            hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, 0, tmp, d_sq + 2 * 33 * 8, (u32)n, bits + 1,
+            hipLaunchKernelGGL((powers_kernel<FrC>), dim3(gn), dim3(256), 0, setup_stream(), tmp, d_sq + 2 * 33 * 8, (u32)n, bits + 1,
                                (const u32 *)(d_sq + 4 * 33 * 8)); // n^-1 * g^i
-            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.t1_br, tmp, log_n);
-            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, 0, d.t2_br, d.coset_inv, log_n);
-            MG_HIP(hipDeviceSynchronize());
+            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, setup_stream(), d.t1_br, tmp, log_n);
+            hipLaunchKernelGGL((permute_bitrev_kernel<FrC>), dim3(gn), dim3(256), 0, setup_stream(), d.t2_br, d.coset_inv, log_n);
+            MG_HIP(setup_sync());
             hipFree(tmp);
         }
-        MG_HIP(hipDeviceSynchronize());
+        MG_HIP(setup_sync());
         hipFree(d_sq);
         { // reduced-radix copies
             struct T {
@@ -797,10 +797,10 @@ template <class FrC> class FrEngineT : public FrEngine {
                         {&d.t2_br_rr, d.t2_br, n, RK}};
             for (T &t : tabs) {
                 MG_HIP(hipMalloc((void **)t.dst, t.cnt * t.stride * 4));
-                hipLaunchKernelGGL((std_to_rr_table_kernel<FrC>), dim3((u32)((t.cnt + 255) / 256)), dim3(256), 0, 0, t.src, (u32)t.cnt,
+                hipLaunchKernelGGL((std_to_rr_table_kernel<FrC>), dim3((u32)((t.cnt + 255) / 256)), dim3(256), 0, setup_stream(), t.src, (u32)t.cnt,
                                    *t.dst, t.stride);
             }
-            MG_HIP(hipDeviceSynchronize());
+            MG_HIP(setup_sync());
             // the saturated copies the pipeline no longer reads are released (the public NTT keeps none of them either)
             // (tw_fwd / tw_inv stay: the group-domain NTT reads them)
             hipFree(d.t1_br), hipFree(d.t2_br), hipFree(d.coset_fwd), hipFree(d.coset_inv);

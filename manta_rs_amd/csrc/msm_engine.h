@@ -167,7 +167,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         }
         if (!map.empty()) {
             if (hipMalloc((void **)&bs->d_map, map.size() * 4) != hipSuccess ||
-                hipMemcpy(bs->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                memcpy_sync(bs->d_map, map.data(), map.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
                 bases_destroy(bs);
                 return MG_ERR_OOM;
             }
@@ -205,19 +205,19 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         } free_win{win_pts};
         u32 *const dst = full ? win_pts : bs->d_pts;
         if (SAME) {
-            e = hipMemcpy(dst, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+            e = memcpy_sync(dst, pts, n * AW * 4, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
         } else { // convert arkworks limbs -> internal representation on the device
             u32 *stage = nullptr;
             const u32 *src = pts;
             e = hipSuccess;
             if (!src_on_device) {
                 e = hipMalloc((void **)&stage, n * AW_IO * 4);
-                if (e == hipSuccess) e = hipMemcpy(stage, pts, n * AW_IO * 4, hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = memcpy_sync(stage, pts, n * AW_IO * 4, hipMemcpyHostToDevice);
                 src = stage;
             }
             if (e == hipSuccess) {
-                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, src, n, dst, (u32)AWS);
-                e = hipDeviceSynchronize();
+                hipLaunchKernelGGL((bases_to_internal<F>), dim3(cdiv(n, 256)), dim3(256), 0, setup_stream(), src, n, dst, (u32)AWS);
+                e = setup_sync();
             }
             if (stage) hipFree(stage);
         }
@@ -235,12 +235,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 set_last_hip_error(e, "hipMalloc(precompute tmp)", __FILE__, __LINE__);
                 return MG_ERR_OOM;
             }
-            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, dst, (u32)AWS, (u32)n,
+            hipLaunchKernelGGL((precompute_chain<F>), dim3(cdiv(n, 256)), dim3(256), 0, setup_stream(), dst, (u32)AWS, (u32)n,
                                pre_c, W, tmp);
             constexpr int KB = 16;
-            hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(cnt, KB), 256)), dim3(256), 0, 0, tmp,
+            hipLaunchKernelGGL((xyzz_to_affine_batch<F, KB>), dim3(cdiv(cdiv(cnt, KB), 256)), dim3(256), 0, setup_stream(), tmp,
                                cnt, dst + n * AWS, (u32)AWS);
-            e = hipDeviceSynchronize();
+            e = setup_sync();
             hipFree(tmp);
             if (e != hipSuccess) {
                 bases_destroy(bs);
@@ -259,14 +259,14 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             constexpr int KBF = 64; // one Fermat inversion per 64 points
             for (size_t j0 = 0; e == hipSuccess && j0 < pairs; j0 += slice) {
                 const size_t cntp = pairs - j0 < slice ? pairs - j0 : slice;
-                hipLaunchKernelGGL((full_table_chain<F>), dim3(cdiv(cntp, 256)), dim3(256), 0, 0, win_pts, (u32)AWS, j0, (u32)cntp, FB,
+                hipLaunchKernelGGL((full_table_chain<F>), dim3(cdiv(cntp, 256)), dim3(256), 0, setup_stream(), win_pts, (u32)AWS, j0, (u32)cntp, FB,
                                    tmp);
-                hipLaunchKernelGGL((xyzz_to_affine_batch<F, KBF>), dim3(cdiv(cdiv(cntp * FB, KBF), 256)), dim3(256), 0, 0, tmp,
+                hipLaunchKernelGGL((xyzz_to_affine_batch<F, KBF>), dim3(cdiv(cdiv(cntp * FB, KBF), 256)), dim3(256), 0, setup_stream(), tmp,
                                    cntp * FB, final_pts + j0 * FB * AWS, (u32)AWS);
                 e = hipGetLastError();
             }
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            else (void)hipDeviceSynchronize();
+            if (e == hipSuccess) e = setup_sync();
+            else (void)setup_sync();
             if (tmp) hipFree(tmp);
             if (e != hipSuccess) {
                 bases_destroy(bs);
@@ -949,6 +949,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // ---------------------------------------------------------------- fixed-base batch mul
     int fixed_base_mul(const u32 *base_affine_host, const u32 *d_scalars, size_t n, u32 *d_out_affine,
                        hipStream_t s) override {
+        if (!s) s = setup_stream(); // (never the NULL stream: engine.h)
         u32 *d_base = nullptr, *tmp = nullptr;
         MG_HIP(hipMalloc((void **)&d_base, AW_IO * 4));
         hipError_t e = hipMalloc((void **)&tmp, n * XW_IO * 4);
@@ -1118,16 +1119,16 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         if (e == hipSuccess) e = hipMalloc((void **)&d_std, n * XW_IO * 4);
         if (e == hipSuccess) e = hipMalloc((void **)&d_out, ab);
         if (e == hipSuccess && n_inv_canonical) e = hipMalloc((void **)&d_sc, 32);
-        if (e == hipSuccess) e = hipMemcpy(d_in, in_affine_host, ab, hipMemcpyHostToDevice);
-        if (e == hipSuccess && n_inv_canonical) e = hipMemcpy(d_sc, n_inv_canonical, 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = memcpy_sync(d_in, in_affine_host, ab, hipMemcpyHostToDevice);
+        if (e == hipSuccess && n_inv_canonical) e = memcpy_sync(d_sc, n_inv_canonical, 32, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((group_ntt_load_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, d_in, lg, d_pts);
+            hipLaunchKernelGGL((group_ntt_load_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, setup_stream(), d_in, lg, d_pts);
             for (unsigned s = 1; s <= lg; ++s)
-                hipLaunchKernelGGL((group_ntt_stage_kernel<F, FrC>), dim3(cdiv(n / 2, 256)), dim3(256), 0, 0, d_pts, d_twiddles_mont, lg, s);
-            hipLaunchKernelGGL((group_scale_store_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, 0, d_pts, (const u32 *)d_sc, n, d_std);
+                hipLaunchKernelGGL((group_ntt_stage_kernel<F, FrC>), dim3(cdiv(n / 2, 256)), dim3(256), 0, setup_stream(), d_pts, d_twiddles_mont, lg, s);
+            hipLaunchKernelGGL((group_scale_store_kernel<F>), dim3(cdiv(n, 256)), dim3(256), 0, setup_stream(), d_pts, (const u32 *)d_sc, n, d_std);
             constexpr int KB = 16;
-            hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, 0, d_std, n, d_out, (u32)AW_IO);
-            e = hipMemcpy(out_affine_host, d_out, ab, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL((xyzz_to_affine_batch<FIO, KB>), dim3(cdiv(cdiv(n, KB), 256)), dim3(256), 0, setup_stream(), d_std, n, d_out, (u32)AW_IO);
+            e = memcpy_sync(out_affine_host, d_out, ab, hipMemcpyDeviceToHost);
         }
         hipFree(d_in), hipFree(d_pts), hipFree(d_std), hipFree(d_out), hipFree(d_sc);
         if (e != hipSuccess) {
@@ -1141,9 +1142,9 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         const u32 T = n < 4096 ? (u32)(n ? n : 1) : 4096;
         u32 *tmp = nullptr;
         MG_HIP(hipMalloc((void **)&tmp, (size_t)T * XW_IO * 4));
-        hipLaunchKernelGGL((sum_affine_kernel<FIO>), dim3(cdiv(T, 256)), dim3(256), 0, 0, d_pts, n, T, tmp);
+        hipLaunchKernelGGL((sum_affine_kernel<FIO>), dim3(cdiv(T, 256)), dim3(256), 0, setup_stream(), d_pts, n, T, tmp);
         std::vector<u32> h((size_t)T * XW_IO);
-        hipError_t e = hipMemcpy(h.data(), tmp, h.size() * 4, hipMemcpyDeviceToHost);
+        hipError_t e = memcpy_sync(h.data(), tmp, h.size() * 4, hipMemcpyDeviceToHost);
         hipFree(tmp);
         if (e != hipSuccess) {
             set_last_hip_error(e, "sum_affine", __FILE__, __LINE__);

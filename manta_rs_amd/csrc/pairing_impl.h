@@ -120,10 +120,10 @@ template <class K> class PairingEngineT : public PairingEngine {
         const size_t qb = n * 2 * P::F2W * 4, cb = n * (size_t)P::NCOEFF * P::COEFFW * 4;
         hipError_t e = hipMalloc((void **)&dq, qb);
         if (e == hipSuccess) e = hipMalloc((void **)&dc, cb);
-        if (e == hipSuccess) e = hipMemcpy(dq, q_affine_host, qb, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = memcpy_sync(dq, q_affine_host, qb, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL((g2_prepare_kernel<K>), dim3((unsigned)n), dim3(64), PW::prep_lds_bytes(), 0, dq, n, dc);
-            e = hipDeviceSynchronize();
+            hipLaunchKernelGGL((g2_prepare_kernel<K>), dim3((unsigned)n), dim3(64), PW::prep_lds_bytes(), setup_stream(), dq, n, dc);
+            e = setup_sync();
         }
         hipFree(dq);
         if (e != hipSuccess) {

@@ -560,10 +560,10 @@ class ProverImpl : public Prover {
         MG_HIP(hipMalloc((void **)&dst.row_ptr, (m + 1) * 4));
         MG_HIP(hipMalloc((void **)&dst.col, (src->nnz ? src->nnz : 1) * 4));
         MG_HIP(hipMalloc((void **)&dst.val, (src->nnz ? src->nnz : 1) * 32));
-        MG_HIP(hipMemcpy(dst.row_ptr, src->row_ptr, (m + 1) * 4, hipMemcpyHostToDevice));
+        MG_HIP(memcpy_sync(dst.row_ptr, src->row_ptr, (m + 1) * 4, hipMemcpyHostToDevice));
         if (src->nnz) {
-            MG_HIP(hipMemcpy(dst.col, src->col, src->nnz * 4, hipMemcpyHostToDevice));
-            MG_HIP(hipMemcpy(dst.val, src->val, src->nnz * 32, hipMemcpyHostToDevice));
+            MG_HIP(memcpy_sync(dst.col, src->col, src->nnz * 4, hipMemcpyHostToDevice));
+            MG_HIP(memcpy_sync(dst.val, src->val, src->nnz * 32, hipMemcpyHostToDevice));
         }
         return MG_OK;
     }

@@ -146,6 +146,22 @@ hipStream_t stream_pool_get_normal() {
     g_nstream_dev[s] = dev;
     return s;
 }
+// ---- the calling thread's setup stream (engine.h): one pooled normal-priority non-blocking stream per device it has touched
+namespace {
+struct ThreadSetupStreams {
+    hipStream_t s[MAX_DEVICES] = {};
+    ~ThreadSetupStreams() {
+        for (hipStream_t x : s)
+            if (x) stream_pool_put_normal(x); // (idle: every user waits for its own work before it returns)
+    }
+};
+} // namespace
+hipStream_t setup_stream() {
+    static thread_local ThreadSetupStreams tl;
+    const int dev = current_device();
+    if (!tl.s[dev]) tl.s[dev] = stream_pool_get_normal();
+    return tl.s[dev];
+}
 // ---- tuning (tuning.h): compiled-in defaults, the environment applied ONCE through one table, then mg_set_tuning --------------
 Tuning tuning_defaults() {
     Tuning t{};

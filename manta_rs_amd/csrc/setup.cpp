@@ -15,11 +15,11 @@ static int mul_all(GroupEngine *e, const u64 *gen, const std::vector<u64> &scala
     u32 *d_s = nullptr, *d_o = nullptr;
     hipError_t er = hipMalloc((void **)&d_s, n * 32);
     if (er == hipSuccess) er = hipMalloc((void **)&d_o, n * aw * 4);
-    if (er == hipSuccess) er = hipMemcpy(d_s, scalars.data(), n * 32, hipMemcpyHostToDevice);
+    if (er == hipSuccess) er = memcpy_sync(d_s, scalars.data(), n * 32, hipMemcpyHostToDevice);
     int rc = MG_OK;
     if (er == hipSuccess) rc = e->fixed_base_mul((const u32 *)gen, d_s, n, d_o, nullptr);
     out.resize(n * aw);
-    if (er == hipSuccess && !rc) er = hipMemcpy(out.data(), d_o, n * aw * 4, hipMemcpyDeviceToHost);
+    if (er == hipSuccess && !rc) er = memcpy_sync(out.data(), d_o, n * aw * 4, hipMemcpyDeviceToHost);
     if (d_s) hipFree(d_s);
     if (d_o) hipFree(d_o);
     if (er != hipSuccess) {

@@ -285,8 +285,8 @@ template <class Curve, class K> class VerifierT : public Verifier {
         if ((rc = pe_->prepare((const u32 *)ng.data(), 2, &d2))) return rc;
         const size_t cw = (size_t)pe_->n_coeffs() * pe_->coeff_words();
         gneg_host_.resize(cw), dneg_host_.resize(cw);
-        hipError_t e = hipMemcpy(gneg_host_.data(), d2, cw * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(dneg_host_.data(), d2 + cw, cw * 4, hipMemcpyDeviceToHost);
+        hipError_t e = memcpy_sync(gneg_host_.data(), d2, cw * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = memcpy_sync(dneg_host_.data(), d2 + cw, cw * 4, hipMemcpyDeviceToHost);
         d_gneg_ = d2; // the two blocks stay in this one allocation
         d_dneg_ = nullptr;
         if (e != hipSuccess) {
@@ -355,8 +355,8 @@ template <class Curve, class K> class VerifierT : public Verifier {
         }
         if (off != len) return MG_ERR_ARG;
         MG_HIP(hipMalloc((void **)&d_gneg_, 2 * cw * 4));
-        MG_HIP(hipMemcpy(d_gneg_, gneg_host_.data(), cw * 4, hipMemcpyHostToDevice));
-        MG_HIP(hipMemcpy(d_gneg_ + cw, dneg_host_.data(), cw * 4, hipMemcpyHostToDevice));
+        MG_HIP(memcpy_sync(d_gneg_, gneg_host_.data(), cw * 4, hipMemcpyHostToDevice));
+        MG_HIP(memcpy_sync(d_gneg_ + cw, dneg_host_.data(), cw * 4, hipMemcpyHostToDevice));
         return MG_OK;
     }
 

@@ -66,10 +66,17 @@ class PartialPointExchange:
         self.on_gpu = self.collective and dist.get_backend(process_group) == "nccl"
         self.words = int(words) if words else api.xyzz_limbs(curve, group)  # device path: XYZZ points
         self.slots, self.next = [], 0
+        self.comm_stream = None
         if self.collective:
             if self.on_gpu:
                 dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
                 self.slots = [_Slot(torch, self.words, self.world, dev) for _ in range(ring)]
+                # The exchange has a NON-blocking stream of its own, never torch's default (= the NULL) stream: the stand-alone MSMs
+                # run on blocking streams (hardware queues of their own, csrc/engine.h MsmWorkspace::solo), and legacy-stream
+                # ordering would make MSM k+1 wait for the all_gather of MSM k behind the NULL stream -- the pipeline of MSMs in
+                # flight would run one at a time.
+                self.comm_stream = torch.cuda.Stream(device=dev)
+                torch.cuda.current_stream(dev).synchronize()  # (the buffers' zero fills ran on torch's current stream)
             # host path buffers (affine points)
             self.send = torch.zeros(self.limbs, dtype=torch.int64)
             self.recv = torch.zeros(self.world * self.limbs, dtype=torch.int64)
@@ -83,10 +90,11 @@ class PartialPointExchange:
         if self.on_gpu:  # nccl cannot gather host tensors: bounce through a device slot (plain bases only take this road)
             sl = self._acquire()
             try:
-                sl.send[:self.limbs].copy_(t, non_blocking=True)
-                self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)
-                # .cpu() waits for the gather on the current stream: the slot is ours until the copy below exists
-                out = sl.recv.cpu().numpy().view(np.uint64).reshape(self.world, self.words)[:, :self.limbs].copy()
+                with self.torch.cuda.stream(self.comm_stream):
+                    sl.send[:self.limbs].copy_(t, non_blocking=True)
+                    self.dist.all_gather_into_tensor(sl.recv, sl.send, group=self.pg)
+                    # .cpu() waits for the gather on the exchange stream: the slot is ours until the copy below exists
+                    out = sl.recv.cpu().numpy().view(np.uint64).reshape(self.world, self.words)[:, :self.limbs].copy()
             finally:
                 sl.busy = False
             return out
@@ -116,24 +124,25 @@ class PartialPointExchange:
                            "launching another (or build the exchange with a larger ring)" % len(self.slots))
 
     def stream_handle(self) -> int:
-        """the raw hipStream_t the collective will be enqueued on (torch's current stream)"""
-        return int(self.torch.cuda.current_stream().cuda_stream)
+        """the raw hipStream_t the collective will be enqueued on (the exchange's own non-blocking stream)"""
+        return int((self.comm_stream or self.torch.cuda.current_stream()).cuda_stream)
 
     def begin(self) -> _Slot:
         """a free buffer set; the producer writes `words` u64 to slot.send (device memory) and makes stream_handle() wait"""
         return self._acquire()
 
     def gather_async(self, sl: _Slot, words=None):
-        """all_gather_into_tensor from device memory on the current stream + asynchronous copy to pinned memory. `words` (<= the
+        """all_gather_into_tensor from device memory on the exchange stream + asynchronous copy to pinned memory. `words` (<= the
         buffer's) = u64 per rank the producer wrote: only those travel -- a pass of k proofs moves k * 5 points per rank over xGMI,
         not the max_batch-sized buffer -- and land packed as [world, words] at the front of recv / h_recv."""
         w = self.words if words is None else int(words)
         if w <= 0 or w > self.words:
             raise ValueError("PartialPointExchange.gather_async: words out of range")
         sl.sent = w
-        self.dist.all_gather_into_tensor(sl.recv[:self.world * w], sl.send[:w], group=self.pg)  # RCCL over xGMI
-        sl.h_recv[:self.world * w].copy_(sl.recv[:self.world * w], non_blocking=True)
-        sl.done.record()
+        with self.torch.cuda.stream(self.comm_stream):
+            self.dist.all_gather_into_tensor(sl.recv[:self.world * w], sl.send[:w], group=self.pg)  # RCCL over xGMI
+            sl.h_recv[:self.world * w].copy_(sl.recv[:self.world * w], non_blocking=True)
+            sl.done.record()
 
     def wait(self, sl: _Slot, words=None) -> np.ndarray:
         """-> [world, words] uint64, once the gather and the copy have completed (the only host wait of the step). `words`

@@ -45,10 +45,26 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
     O.set_threads(1)
     reg = threading.Lock()
     drained = threading.Condition(reg)
+    slock = threading.Lock()
+
+    # Round 6: the contexts that come and go are not all alike -- in rotation: a signer's budget of full tables;
+    # NO full tables (bucket tables, sort + bucket reduce on every chain); every MSM range-sharded over devices [0, 0] (two shards on
+    # one GPU, partial points through pinned host memory, no coalescing); a context with its own mg_tuning (split graphs, one pass of
+    # a batch in flight, narrow windows of 7 bits)
+    variants = (dict(full_table_bytes=12 << 30), dict(full_table_bytes=0), dict(devices=[0, 0], full_table_bytes=4 << 30),
+                dict(full_table_bytes=6 << 30, tuning=dict(graph_mode=api.GRAPH_SPLIT, batch_inflight=1, coalesce_inflight=1)))
+    only = os.environ.get("SOAK_VARIANTS")  # diagnosis: e.g. "0" or "0,1" restricts the rotation
+    if only:
+        variants = tuple(variants[int(x)] for x in only.split(","))
+    made = {"n": 0, "by_variant": [0] * len(variants)}
 
     def make_ctx(name):
         s = S[name]
-        ctx = api.ProvingContext(curve, s["pk"], full_table_bytes=12 << 30)  # a signer's budget: three (at times four) contexts alive
+        with slock:
+            v = made["n"] % len(variants)
+            made["n"] += 1
+            made["by_variant"][v] += 1
+        ctx = api.ProvingContext(curve, s["pk"], **variants[v])
         ctx.set_r1cs(s["r1cs"])
         return ctx
 
@@ -60,8 +76,7 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
         S[name]["box"] = Box(make_ctx(name))
     log("soak: %d shapes, %d oracle proofs each, setup %.1f s; running %.0f s with %d threads, a context recycled every %.1f s"
         % (len(shapes), pool, time.perf_counter() - t_setup, seconds, threads, recycle_every))
-    stats = {"proofs": 0, "single_calls": 0, "batch_calls": 0, "mismatches": 0, "errors": 0, "contexts_created": len(shapes), "first_bad": None}
-    slock = threading.Lock()
+    stats = {"proofs": 0, "single_calls": 0, "batch_calls": 0, "msms": 0, "mismatches": 0, "errors": 0, "contexts_created": len(shapes), "first_bad": None}
     deadline = time.perf_counter() + seconds
     stop = threading.Event()
 
@@ -115,6 +130,33 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
             finally:
                 release(box)
 
+    # stand-alone MSMs beside the proofs (round 6: they run on streams with hardware queues of their own -- blocking streams --
+    # next to captures, replays and context creation): three in flight, BN254 G1 and G2, every result against the oracle's
+    msm_sets = []
+    for group, n, pre in ((1, 1 << 14, 11), (2, 3000, 8)):
+        pts = H.random_points(curve, group, 1500, seed=900 + group)
+        pts = np.concatenate([pts] * (-(-n // 1500)))[:n]
+        sc = synth.msm_scalars(curve, n, "W", seed=910 + group)
+        msm_sets.append((api.Bases(curve, group, pts, precompute_window_bits=pre), api.DeviceBuffer.from_numpy(sc), n, O.msm(curve, group, pts, sc, algo=1)))
+
+    def msm_worker():
+        while time.perf_counter() < deadline and not stop.is_set() and not os.environ.get("SOAK_NO_MSM"):
+            for b, d, n, want in msm_sets:
+                try:
+                    jobs = [api.VariableBaseMSM.launch(b, d, n, sparse=True) for _ in range(3)]
+                    bad = sum(0 if (j.finish() == want).all() else 1 for j in jobs)
+                except Exception as e:  # noqa: BLE001
+                    with slock:
+                        stats["errors"] += 1
+                        stats["first_bad"] = stats["first_bad"] or {"msm": True, "error": repr(e)[:300]}
+                    continue
+                with slock:
+                    stats["msms"] += 3
+                    if bad:
+                        stats["mismatches"] += bad
+                        stats["first_bad"] = stats["first_bad"] or {"msm": True, "group": b.group, "bad": bad}
+            time.sleep(0.002)
+
     def recycler():
         rnd = random.Random(77)
         while not stop.wait(recycle_every) and time.perf_counter() < deadline:
@@ -136,7 +178,7 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
             with slock:
                 stats["contexts_created"] += 1
 
-    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)] + [threading.Thread(target=recycler)]
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)] + [threading.Thread(target=msm_worker), threading.Thread(target=recycler)]
     t0 = time.perf_counter()
     [t.start() for t in ts]
     [t.join() for t in ts[:-1]]
@@ -145,6 +187,7 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
     dt = time.perf_counter() - t0
     for name in shapes:
         S[name]["box"].ctx.close()
+    stats["contexts_by_variant"] = dict(zip(("full_tables", "no_full_tables", "sharded_0_0", "own_tuning"), made["by_variant"])) if not only else made["by_variant"]
     stats["seconds"] = round(dt, 1)
     stats["proofs_per_s"] = round(stats["proofs"] / dt, 1)
     return stats
