@@ -290,9 +290,12 @@ int mg_ctx_create(mg_curve_t curve, const mg_pk_view *pk, mg_ctx **out);
  *   coalesce_gather_us    how long the leader of such a pass waits for the callers of the pass that has just ended (default 100)
  *   batch_inflight        passes of one mg_groth16_prove_batch call in flight (default 3)
  *   queue_aware           1 (default): single-proof slots get streams on measured hardware queues; 0: plain pooled streams
- *   msm_dedicated_queues  1 (default): a stand-alone MSM (mg_msm_launch) runs on a stream with a hardware queue of its own, which
- *                         makes its pipelined rate independent of the streams the rest of the process created; such streams
- *                         are BLOCKING streams (they order themselves against the host's NULL-stream work). 0: ordinary streams
+ *   msm_dedicated_queues  a stand-alone MSM (mg_msm_launch) on a stream with a hardware queue of its own: its pipelined rate then no
+ *                         longer depends on the streams the rest of the process created (390-398 Mscalar/s at 2^20 for every
+ *                         creation order against 317-394). 1 (default) = only while NO proving / verifying context is alive in
+ *                         the process (beside proof passes the dedicated queues cost far more than they give), 2 = always,
+ *                         0 = never. Such streams are BLOCKING streams: they order themselves against the host's NULL-stream work
+ *                         (the library itself puts nothing on the NULL stream)
  *   window_bits_*         window widths of a context's key tables, 0 = the library's choice: narrow = the latency tables of
  *                         a / b_g1 / l (setting it forces ONE width for every bucket table and leaves the full and wide tables
  *                         out), wide = the batched-pass tables, h = the h query, g2 = b_g2

@@ -250,8 +250,11 @@ static int launch_shards(const mg_bases *b, const uint64_t *const *d_scalars, co
         if (!rc && !ws) rc = MG_ERROR_HIP;
         if (ws) {
             // a stand-alone MSM: on a stream with a hardware queue of its own (engine.h MsmWorkspace::solo)
-            if (!ws->solo) ws->solo = stream_pool_get_dedicated();
-            ws->use_solo = ws->solo != nullptr;
+            // (tuning msm_dedicated_queues: 1 = only while no proving / verifying context is alive in the process, 2 = always)
+            const int dq = tuning().msm_dedicated_queues;
+            const bool want = dq == 2 || (dq == 1 && graph_clients_alive() == 0);
+            if (want && !ws->solo) ws->solo = stream_pool_get_dedicated();
+            ws->use_solo = want && ws->solo != nullptr;
             job->sh.push_back(JobShard{s.eng, ws, s.device, d_tmp});
             rc = s.eng->msm_launch(s.bs, d_sc, n, (scalar_flags & MG_SCALARS_MONT) ? SCALARS_MONT : SCALARS_CANONICAL, window_bits, ws, 1, 0,
                                    (scalar_flags & MG_SCALARS_SPARSE) != 0);

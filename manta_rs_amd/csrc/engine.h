@@ -97,6 +97,19 @@ hipStream_t stream_pool_get();
 void stream_pool_put(hipStream_t s);
 hipStream_t stream_pool_get_normal(); // normal-priority streams: pooled and never destroyed either (runtime.cpp)
 void stream_pool_put_normal(hipStream_t s);
+// Proving / verifying contexts alive in this process. A stand-alone MSM takes its dedicated-queue stream only while there is NONE
+// (tuning msm_dedicated_queues = 1, the default; 2 = always, 0 = never): beside proof passes the dedicated queues cost far more than
+// they give -- tools/soak.py with stand-alone MSMs next to six proving threads: 3 380 proofs/s on ordinary streams, 640 with the MSMs
+// on dedicated queues, also with graphs off and with nothing on the NULL stream (profiles/r06_soak.txt; the runtime's handling of
+// CU-masked HSA queues next to the pooled ones -- not identified further). The pipeline of MSMs of a process that only does MSMs
+// (BASELINE configs[1]) is where they pay: 390-398 Mscalar/s for every stream-creation order against 317-394.
+struct GraphClient { // a member of every proving / verifying context
+    GraphClient();
+    ~GraphClient();
+    GraphClient(const GraphClient &) = delete;
+    GraphClient &operator=(const GraphClient &) = delete;
+};
+int graph_clients_alive();
 hipStream_t stream_pool_get_dedicated(); // a stream on a hardware queue of its own (MsmWorkspace::solo); nullptr: off / refused
 void stream_pool_put_dedicated(hipStream_t s);
 // Queue-aware streams of a single-proof slot (queues.hip, runtime.cpp): three streams on three DIFFERENT hardware queues, chosen so

@@ -220,6 +220,7 @@ class ProverImpl : public Prover {
   public:
     // what the deployment decided for THIS context (mg_ctx_opts.tuning, else the process-wide values when it was created): tuning.h
     Tuning tn_ = tuning();
+    GraphClient counted_; // (stand-alone MSMs leave their dedicated queues alone while this context lives: engine.h)
     // streams of a forked pass. (1 = part A as ONE linear chain, the topology of the round-4 wrong-C defect: diagnosis builds only)
     int prove_streams() const {
 #ifdef MG_DIAG

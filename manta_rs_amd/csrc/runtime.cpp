@@ -184,7 +184,7 @@ int normalize_tuning(Tuning &t) {
     if (!in(t.graph_mode, 0, 2) || !in(t.graph_mode_batch, -1, 2)) return MG_ERR_ARG;
     if (!(t.prove_streams >= 3 && t.prove_streams <= 6)) return MG_ERR_ARG; // (1 = the linear part A of the round-4 defect: -DMG_DIAG only)
     if (!in(t.linear_chains, 0, 3) || !in(t.coalesce_inflight, 0, 4) || !in(t.coalesce_gather_us, 0, 2000)) return MG_ERR_ARG;
-    if (!in(t.batch_inflight, 1, 16) || !in(t.queue_aware, 0, 1) || !in(t.msm_dedicated_queues, 0, 1)) return MG_ERR_ARG;
+    if (!in(t.batch_inflight, 1, 16) || !in(t.queue_aware, 0, 1) || !in(t.msm_dedicated_queues, 0, 2)) return MG_ERR_ARG;
     if (t.window_bits_narrow && !in(t.window_bits_narrow, 2, 20)) return MG_ERR_ARG;
     if (t.window_bits_wide && !in(t.window_bits_wide, 6, 16)) return MG_ERR_ARG;
     if (t.window_bits_h && !in(t.window_bits_h, 2, 20)) return MG_ERR_ARG;
@@ -268,12 +268,16 @@ int set_tuning(const Tuning &t_in) {
 }
 const char *const *tuning_env_names() { return ENV_NAMES; }
 
+static std::atomic<int> g_graph_clients{0};
+GraphClient::GraphClient() { g_graph_clients.fetch_add(1, std::memory_order_relaxed); }
+GraphClient::~GraphClient() { g_graph_clients.fetch_sub(1, std::memory_order_relaxed); }
+int graph_clients_alive() { return g_graph_clients.load(std::memory_order_relaxed); }
 // ---- streams on hardware queues of their own (engine.h MsmWorkspace::solo)
 static std::vector<hipStream_t> g_dstream_pools[MAX_DEVICES];
 static std::map<hipStream_t, int> g_dstream_dev;
 static bool g_dstream_refused[MAX_DEVICES] = {};
 hipStream_t stream_pool_get_dedicated() {
-    if (!tuning().msm_dedicated_queues) return nullptr; // (hosts that need non-blocking semantics against their own NULL-stream work)
+    if (!tuning().msm_dedicated_queues) return nullptr; // (0: never -- e.g. hosts that need non-blocking semantics against their own NULL-stream work)
     const int dev = current_device();
     {
         std::lock_guard<std::mutex> g(g_stream_mu);

@@ -25,7 +25,7 @@ struct Tuning { // field for field `mg_tuning`
     int32_t coalesce_gather_us;   // how long the leader of a coalesced pass waits for the callers of the pass that just ended (default 100)
     int32_t batch_inflight;       // passes of one mg_groth16_prove_batch call in flight (default 3)
     int32_t queue_aware;          // 1 (default): single-proof slots get streams on measured hardware queues (queues.hip)
-    int32_t msm_dedicated_queues; // 1 (default): stand-alone MSMs run on streams with a hardware queue of their own (blocking streams)
+    int32_t msm_dedicated_queues; // stand-alone MSMs on streams with a hardware queue of their own: 1 (default) while no context is alive, 2 always, 0 never
     int32_t window_bits_narrow;   // key tables, 0 = the library's choice: latency tables of a / b_g1 / l (default 8 at manta-pay sizes)
     int32_t window_bits_wide;     //   batched-pass tables (default 11)
     int32_t window_bits_h;        //   the h query (default 12 / log2(D) - 2)

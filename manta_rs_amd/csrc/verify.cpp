@@ -107,6 +107,7 @@ template <class C> bool read_fq(const uint8_t *in, unsigned char mask_top, HFp<C
 
 template <class Curve, class K> class VerifierT : public Verifier {
   public:
+    GraphClient counted_; // (engine.h: stand-alone MSMs keep to ordinary streams while a context lives)
     typedef typename Curve::Fq C;
     typedef typename Curve::Fr CR;
     typedef HFp<C> HF;

@@ -138,7 +138,7 @@ def test_bls12_381_2_15_circuit(gpu, prof):
 _TUNING_CASES = {  # one non-default value per variable of mg_tuning_env_names (MANTA_RCCL_LIB is a path, not a schedule)
     "MANTA_GRAPH": ("split", "off"), "MANTA_GRAPH_BATCH": ("off",), "MANTA_PROVE_STREAMS": ("3",), "MANTA_Z3_LINEAR": ("0",),
     "MANTA_COALESCE": ("0",), "MANTA_COALESCE_GATHER_US": ("0",), "MANTA_BATCH_INFLIGHT": ("1",), "MANTA_QUEUE_AWARE": ("0",),
-    "MANTA_MSM_DEDICATED_QUEUES": ("0",), "MANTA_PROVE_C": ("7",), "MANTA_PROVE_CW": ("9",), "MANTA_PROVE_CH": ("10",),
+    "MANTA_MSM_DEDICATED_QUEUES": ("0", "2"), "MANTA_PROVE_C": ("7",), "MANTA_PROVE_CW": ("9",), "MANTA_PROVE_CH": ("10",),
     "MANTA_PROVE_CG2": ("8",), "MANTA_FULL_TABLE_GB": ("0.5",),
 }
 _TUNING_SCRIPT = '''

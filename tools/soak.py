@@ -155,7 +155,7 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
                     if bad:
                         stats["mismatches"] += bad
                         stats["first_bad"] = stats["first_bad"] or {"msm": True, "group": b.group, "bad": bad}
-            time.sleep(0.002)
+            time.sleep(float(os.environ.get("SOAK_MSM_SLEEP", "0.002")))
 
     def recycler():
         rnd = random.Random(77)
