@@ -57,1147 +57,26 @@ FrEngine *get_ntt_engine(int curve) { // one per (device, curve): twiddle and sc
     return tab[dev][curve];
 }
 
+// The prover is one class hierarchy split along its seams (round 6): prover_slot.h (slot), prover_key.h (ProverKey: key + circuit),
+// prover_assembly.h (ProverAssembly: host assembly), prover_passes.h (ProverSlots: slots, enqueue, graph capture); below: ProverImpl --
+// passes (launch / collect / finish), the coalescing queue, batches, the partials interface, the in-library RCCL exchange.
+} // namespace mg
+#include "prover_slot.h"
+#include "prover_key.h"
+#include "prover_assembly.h"
+#include "prover_passes.h"
+namespace mg {
 namespace {
 
-// RCCL behind the C ABI (mg_ctx_opts.exchange = MG_EXCHANGE_RCCL): the library is dlopen'ed the first time a context asks for
-// it -- a process that already holds one (PyTorch ships its own librccl.so.1) gets THAT copy, two RCCL runtimes in one
-// process would each claim the devices -- and only the six entry points below are used. MANTA_RCCL_LIB names another file.
-struct Rccl {
-    void *h = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    static Rccl *get() {
-        static Rccl *inst = [] () -> Rccl * {
-            Rccl *r = new Rccl();
-            const char *names[] = {std::getenv("MANTA_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-            for (const char *n : names)
-                if (n && !r->h) r->h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); // already in the process?
-            for (const char *n : names)
-                if (n && !r->h) r->h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (!r->h) {
-                delete r;
-                return nullptr;
-            }
-            r->CommInitAll = (decltype(r->CommInitAll))dlsym(r->h, "ncclCommInitAll");
-            r->CommDestroy = (decltype(r->CommDestroy))dlsym(r->h, "ncclCommDestroy");
-            r->AllGather = (decltype(r->AllGather))dlsym(r->h, "ncclAllGather");
-            r->GroupStart = (decltype(r->GroupStart))dlsym(r->h, "ncclGroupStart");
-            r->GroupEnd = (decltype(r->GroupEnd))dlsym(r->h, "ncclGroupEnd");
-            r->GetErrorString = (decltype(r->GetErrorString))dlsym(r->h, "ncclGetErrorString");
-            if (!r->CommInitAll || !r->CommDestroy || !r->AllGather || !r->GroupStart || !r->GroupEnd || !r->GetErrorString) {
-                delete r;
-                return nullptr;
-            }
-            return r;
-        }();
-        return inst;
-    }
-};
-
-// One in-flight proof (or batch of proofs): device scratch for the witness map, its five MSM workspaces (each
-// with its own stream), a pinned copy of z, and -- after two eager runs that size every buffer -- captured
-// hipGraphs of the GPU side (~90 launches: the prover is launch-bound at manta-pay circuit sizes, and
-// concurrent host threads stop contending on the runtime). Default ("single"): two graphs, the G2 MSM alone on
-// its stream and everything else (witness map, four G1 MSMs forked and joined) on the slot's main stream, so
-// that the host can take the G1 results and assemble A and C while the G2 MSM -- the longest chain -- is still
-// running. "split": six single-stream graphs with eager event fork/join (no multi-branch graph at all; 15 %
-// slower). The launch streams are high-priority pooled streams: see stream_pool_get() for the runtime defect
-// that makes this necessary for multi-branch graphs.
-struct ProveWs {
-    DevBuf z, a; // a holds the three work vectors a | b | c back to back (one allocation, one memset)
-    hipStream_t stream = nullptr;             // witness map (and the launch stream of the main graph); the G1 MSMs join back into it
-    hipStream_t side[2] = {nullptr, nullptr}; // [0]: the G2 MSM (the longest chain); [1]: a, b_g1, l in MANTA_PROVE_STREAMS=3 mode
-    hipEvent_t z_ready = nullptr, h_ready = nullptr, fork = nullptr;
-    MsmWorkspace *mw[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    GroupEngine *me[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    void *h_z = nullptr; // pinned staging of the assignment
-    size_t h_z_cap = 0;
-    hipGraphExec_t g_all = nullptr; // "single" mode: witness map + the four G1 MSMs, forked and joined on `stream`
-    hipGraphExec_t g_g2 = nullptr;  // "single" mode: the G2 MSM, alone on its own stream
-    hipGraphExec_t g_wm = nullptr;                                          // witness map body (main stream)
-    hipGraphExec_t g_msm[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // MSM i on its stream
-    bool graphs_ready = false;
-    u32 k = 1; // proofs per pass (the slot's buffers and its captured graph are sized for exactly this batch)
-    // this slot runs the three G1 MSMs over the assignment (a, b_g1, l) as ONE pass of the MSM pipeline over the concatenated
-    // query (ProverImpl::z3_bs_full_) on mw[0]; mw[1] and mw[3] stay idle. Fixed for the slot's lifetime (its graphs capture it).
-    bool z3 = false;
-    // round 5: a z3 slot replays THREE linear graphs -- (witness map + h MSM) on `stream`, the combined a | b_g1 | l MSM on side[1],
-    // the G2 MSM on side[0] -- instead of a forked part A: a captured multi-branch graph starts its branches one after the other
-    // (the combined MSM began 210-290 us into the proof) and its hipGraphLaunch costs ~110 us of host time against 15-30 us for a
-    // linear one. Round 4 built exactly this and withdrew it because C came out wrong next to other contexts: that was the memset
-    // node of the witness map in a packet-captured linear graph (profiles/r05_linear_graph_defect.txt), gone now. MANTA_Z3_LINEAR=0:
-    // the forked graph (A/B).
-    bool linear3 = false;
-    int flavour = 0; // lin_flavour(): 0 forked graph, 1 linear3 of a lone proof, 2 / 3 linear3 beside other passes (combined / G2 MSM on the normal-priority stream)
-    StreamSet sset; // linear3 slots: three streams on three different hardware queues (runtime.cpp); id < 0: plain pooled streams
-    bool poisoned = false; // a stream capture of this slot failed: its streams are not trusted again (dropped, never pooled)
-    std::vector<const uint64_t *> z_parts; // this pass's assignments as k separate host buffers (coalesced calls), else empty
-    int device = 0;
-    u64 gen = 0, last_use = 0; // circuit generation the slot belongs to; LRU stamp for the idle-slot cap
-    int eager_runs = 0, capture_tries = 0;
-    bool no_graph = false;
-    // kernel timing (bench.py's per-phase split of a single proof): timing events, created on first use; a timed pass is
-    // enqueued eagerly -- [0] before the upload of z, [1] after it, [2] witness map done, [3 + 2i], [4 + 2i] around MSM i on
-    // its stream, [13] part A joined, [14] G2 MSM done
-    hipEvent_t tev[15] = {};
-    bool timed = false;
-    void drop_graphs() {
-        if (g_all) hipGraphExecDestroy(g_all);
-        if (g_g2) hipGraphExecDestroy(g_g2);
-        g_all = g_g2 = nullptr;
-        if (g_wm) hipGraphExecDestroy(g_wm);
-        g_wm = nullptr;
-        for (int i = 0; i < 5; ++i) {
-            if (g_msm[i]) hipGraphExecDestroy(g_msm[i]);
-            g_msm[i] = nullptr;
-        }
-        graphs_ready = false;
-    }
-    ~ProveWs() {
-        // hipFree / hipHostFree / hipGraphExecDestroy / hipEventDestroy beside another thread's stream capture invalidate that
-        // capture (error 901): like every allocating path, a slot's destruction takes the shared side of the capture lock
-        // (evicted, stale-generation and poisoned slots are deleted from proving threads)
-        HeavyOp not_beside_a_capture;
-        int prev = 0;
-        hipGetDevice(&prev);
-        hipSetDevice(device);
-        // nothing of this slot may still be tracked by the runtime when its graph execs, events and buffers go (tools/soak.py,
-        // round 5: a heap corruption inside the process after ~5 minutes of contexts being recycled under load)
-        if (stream) (void)hipStreamSynchronize(stream);
-        for (hipStream_t sd : side)
-            if (sd) (void)hipStreamSynchronize(sd);
-        for (int i = 0; i < 5; ++i)
-            if (mw[i] && mw[i]->stream) (void)hipStreamSynchronize(mw[i]->stream);
-        (void)hipGetLastError();
-        drop_graphs();
-        for (int i = 0; i < 5; ++i)
-            if (mw[i]) {
-                mw[i]->run_on = nullptr;
-                mw[i]->in_graph_slot = false;
-                mw[i]->notify = false;
-                if (poisoned) { // its stream may have joined the invalidated capture: abandoned (leaked on purpose), never pooled
-                    mw[i]->stream = nullptr;
-                    delete mw[i];
-                } else {
-                    me[i]->ws_release(mw[i]);
-                }
-            }
-        z.release();
-        a.release();
-        if (h_z) hipHostFree(h_z);
-        if (z_ready) hipEventDestroy(z_ready);
-        if (h_ready) hipEventDestroy(h_ready);
-        if (fork) hipEventDestroy(fork);
-        for (auto &e : tev)
-            if (e) hipEventDestroy(e);
-        if (sset.id >= 0) {
-            if (poisoned) sset.main = sset.g2 = sset.z3 = nullptr; // (abandoned, the set id is free again)
-            stream_set_release(sset);
-        } else if (!poisoned) { // never destroyed: see stream_pool_get(); a poisoned slot's streams are abandoned (leaked on purpose)
-            stream_pool_put(stream);
-            stream_pool_put(side[0]);
-            stream_pool_put(side[1]);
-        }
-        hipSetDevice(prev);
-    }
-};
-
-static inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-    __builtin_ia32_pause();
-#elif defined(__aarch64__)
-    __asm__ __volatile__("yield");
-#endif
-}
-
-enum GraphMode { GRAPH_OFF = GRAPH_MODE_OFF, GRAPH_SINGLE = GRAPH_MODE_SINGLE, GRAPH_SPLIT = GRAPH_MODE_SPLIT };
-
-class ProverImpl : public Prover {
+class ProverImpl : public ProverSlots {
   public:
-    // what the deployment decided for THIS context (mg_ctx_opts.tuning, else the process-wide values when it was created): tuning.h
-    Tuning tn_ = tuning();
-    GraphClient counted_; // (stand-alone MSMs leave their dedicated queues alone while this context lives: engine.h)
-    // streams of a forked pass. (1 = part A as ONE linear chain, the topology of the round-4 wrong-C defect: diagnosis builds only)
-    int prove_streams() const {
-#ifdef MG_DIAG
-        if (ab_knob("MANTA_PROVE_STREAMS", 0) == 1) return 1;
-#endif
-        return tn_.prove_streams;
-    }
-    // Replay the GPU side of a pass as hipGraphs: 0 off, 1 single (default; two graphs, the G2 chain alone so the host can assemble A
-    // and C while it still runs), 2 split (six single-stream graphs, eager event fork / join). Batched passes (k >= 4 proofs) may take
-    // another topology than single proofs (graph_mode_batch; measured within noise: profiles/r05_batched_ab.txt).
-    GraphMode graph_mode() const { return (GraphMode)tn_.graph_mode; }
-    GraphMode graph_mode_for(u32 k) const { return k >= 4 && tn_.graph_mode_batch >= 0 ? (GraphMode)tn_.graph_mode_batch : graph_mode(); }
-    int coalesce_gather_us() const { return tn_.coalesce_gather_us; }
-    int coalesce_inflight() const { return tn_.coalesce_inflight; }
-    int batch_inflight() const { return tn_.batch_inflight < (int)MAX_IDLE_SLOTS ? tn_.batch_inflight : (int)MAX_IDLE_SLOTS; }
-    int curve_ = 0;
-    int dev_ = 0;                      // the HIP device this (shard of the) context lives on
-    u32 shard_ = 0, n_shards_ = 1;     // range shard g of G: every MSM of a proof covers the g-th contiguous slice of its query
-    // task placement (SURVEY.md 8(e) last row; prover_create_task): bit i set = this context computes MSM i (a, b_g1, b_g2, l, h)
-    // in full; the others are some other rank's. Only the partials interface works on such a context; it launches eagerly.
-    u32 task_mask_ = 0x1f;
-    bool does(int i) const { return (task_mask_ >> i) & 1u; }
-    // a context from prover_create_shard with more than one shard: it holds slice g of every query and nothing of the other
-    // slices (they are other processes'), so a whole proof cannot come out of it -- only partials_launch / assemble work
-    bool lone_range_shard() const { return n_shards_ > 1 && peers_.empty() && shard_owner_ == nullptr; }
-    ProverImpl *shard_owner_ = nullptr; // in-process peers: the shard-0 object that owns this one
-    std::vector<ProverImpl *> peers_;  // shard 0 only: shards 1 .. G-1 (owned); a pass runs on all of them, shard 0 assembles
-    FrEngine *fr_ = nullptr;
-    GroupEngine *g1_ = nullptr, *g2_ = nullptr;
-    u64 V_ = 0, P_ = 0, h_len_ = 0, m_ = 0;
-    unsigned log_d_ = 0;
-    bool have_r1cs_ = false;
-    bool sets_ok_ = false; // queue-aware stream sets available on this device (runtime.cpp)
-    BaseSet *a_bs_ = nullptr, *b1_bs_ = nullptr, *b2_bs_ = nullptr, *h_bs_ = nullptr, *l_bs_ = nullptr;
-    BaseSet *h_bs_wide_ = nullptr; // the h query again with wider windows, for batched passes (nullptr: same as h_bs_)
-    // the z queries again with 10-bit windows for batched passes (fewer mixed additions; single proofs want the
-    // short bucket reduce of narrow windows, above all on the G2 chain); nullptr: same as the narrow set
-    BaseSet *a_bs_wide_ = nullptr, *b1_bs_wide_ = nullptr, *b2_bs_wide_ = nullptr, *l_bs_wide_ = nullptr;
-    // the five queries once more as FULL tables (every multiple of every window: the MSM is one plain sum), for passes of ONE
-    // proof -- their latency chain loses the sort, the merge into buckets and the bucket reduce; nullptr: bucket tables
-    BaseSet *a_bs_full_ = nullptr, *b1_bs_full_ = nullptr, *b2_bs_full_ = nullptr, *l_bs_full_ = nullptr, *h_bs_full_ = nullptr;
-    // Round 4: a_query | b_g1_query | l_query (padded to the a query's indexing) as ONE full table (BaseSet::n_sets = 3). The three
-    // MSMs share the scalar vector z, so a single proof runs them as one digit kernel, one accumulate launch and one chain of
-    // merge levels with three bucket keys instead of three chains on three streams: a captured multi-branch graph starts its
-    // branches one after the other (tools/ubench_graph_branches.hip: 4 branches progress like 3, a fifth waits for a whole
-    // branch), which left the third of these MSMs starting 630 us into a 880 us proof (profiles/r04_proof_timeline_*). Replaces
-    // the three separate full tables of an unsharded context (same HBM); MANTA_Z3=0 keeps them apart.
-    BaseSet *z3_bs_full_ = nullptr;
-    HostPoint alpha_g1_, beta_g1_, delta_g1_, beta_g2_, delta_g2_, a0_, b1_0_, b2_0_;
-    HostPoint a0_alpha_, b10_beta_, b20_beta_; // constant terms of g_a, g1_b, g2_b folded once
-    void *delta1_tab_ = nullptr, *delta2_tab_ = nullptr; // fixed-base tables for r*delta, s*delta, rs*delta
-    DevCsr A_, B_, C_;
-    std::vector<u32> h_query_host_; // kept until the domain size is known (set_r1cs), then re-laid
-    std::mutex mu_;
-    // proofs hold it shared for the length of a pass, set_r1cs exclusively: replacing the circuit waits for the passes in
-    // flight and no pass ever sees a half-replaced one (mantagpu.h: prove is re-entrant on one context)
-    mutable std::shared_mutex shape_mu_;
-    u64 gen_ = 0; // bumped by every set_r1cs; a slot remembers the generation it was sized and captured for
-    std::map<u32, std::vector<ProveWs *>> ws_free_; // idle proof slots, by batch size
-    std::set<u32> no_graph_keys_; // slot kinds whose capture failed for a deterministic reason: their slots stay eager (mu_)
-    static constexpr int CAPTURE_TRIES = 8; // passes that run eagerly because the capture lock was busy before build_graphs waits for it
-    size_t idle_slots_ = 0;
-    u64 lru_tick_ = 0;
-    static constexpr size_t MAX_IDLE_SLOTS = 16; // (eight batch sizes of coalesced calls x two passes in flight) per context: beyond it the least recently used idle slot is destroyed
-
     ~ProverImpl() override {
         HeavyOp no_capture_meanwhile;
         exchange_destroy();
-        for (ProverImpl *q : peers_) delete q;
-        hipSetDevice(dev_);
-        // (h_bs_ is created by set_r1cs)
-        if (a_bs_) g1_->bases_destroy(a_bs_);
-        if (b1_bs_) g1_->bases_destroy(b1_bs_);
-        if (h_bs_) g1_->bases_destroy(h_bs_);
-        if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
-        if (l_bs_) g1_->bases_destroy(l_bs_);
-        if (b2_bs_) g2_->bases_destroy(b2_bs_);
-        if (z3_bs_full_) g1_->bases_destroy(z3_bs_full_);
-        if (a_bs_full_) g1_->bases_destroy(a_bs_full_);
-        if (b1_bs_full_) g1_->bases_destroy(b1_bs_full_);
-        if (l_bs_full_) g1_->bases_destroy(l_bs_full_);
-        if (h_bs_full_) g1_->bases_destroy(h_bs_full_);
-        if (b2_bs_full_) g2_->bases_destroy(b2_bs_full_);
-        if (a_bs_wide_) g1_->bases_destroy(a_bs_wide_);
-        if (b1_bs_wide_) g1_->bases_destroy(b1_bs_wide_);
-        if (l_bs_wide_) g1_->bases_destroy(l_bs_wide_);
-        if (b2_bs_wide_) g2_->bases_destroy(b2_bs_wide_);
-        if (delta1_tab_) g1_->hp_table_free(delta1_tab_);
-        if (delta2_tab_) g2_->hp_table_free(delta2_tab_);
-        free_csr(A_);
-        free_csr(B_);
-        free_csr(C_);
-        for (auto &kv : ws_free_)
-            for (ProveWs *w : kv.second) delete w;
+        for (ProverKey *q : peers_) delete q;
+        peers_.clear();
     }
-    static void free_csr(DevCsr &M) {
-        if (M.row_ptr) hipFree(M.row_ptr);
-        if (M.col) hipFree(M.col);
-        if (M.val) hipFree(M.val);
-        M = DevCsr();
-    }
-    u64 domain_size() const override { return have_r1cs_ ? (u64)1 << log_d_ : 0; }
-    void table_bytes(u64 out2[2]) const override {
-        out2[0] = out2[1] = 0;
-        for (const BaseSet *b : {a_bs_, b1_bs_, b2_bs_, l_bs_, h_bs_, a_bs_wide_, b1_bs_wide_, b2_bs_wide_, l_bs_wide_, h_bs_wide_})
-            if (b) out2[0] += b->bytes;
-        for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, h_bs_full_, z3_bs_full_})
-            if (b) out2[1] += b->bytes;
-        for (const ProverImpl *q : peers_) {
-            u64 t[2];
-            q->table_bytes(t);
-            out2[0] += t[0], out2[1] += t[1];
-        }
-    }
-
-    // window bits for precomputed tables, by MSM length (HBM is plentiful: trade table size for fewer
-    // buckets to fold and no doubling chain -- tuned on MI355X)
-    int pre_c_for(u64 n) const {
-        if (tn_.window_bits_narrow > 0) return tn_.window_bits_narrow; // tuning override: ONE width for every bucket table of the key
-        // Measured on MI355X for the PrivateTransfer shape (n = 35k / 65k): c = 6..8 -> 2.0 ms per proof,
-        // c = 9..13 -> 2.5-2.7 ms, c = 14 -> 3.0 ms. Few buckets keep the latency-bound bucket reduce short
-        // (B = 128: two tiles); the extra windows only add perfectly parallel mixed additions.
-        if (n <= (1u << 17)) return 8;
-        if (n <= (1u << 19)) return 12;
-        return 17; // 255 = 15 x 17, 254 < 15 x 17: fifteen windows on both curves (digits_kernel negates scalars above r / 2)
-    }
-
-    // FULL tables for the queries single proofs run on (mg_bases_create with a negative width: every multiple of every window
-    // tabulated, the MSM is one plain sum -- no sort, no merge into buckets, no bucket reduce on the latency chain of a proof).
-    // They are bought with HBM, and a signer holds three contexts (`MultiProvingContext`, manta-accounting/src/transfer/
-    // canonical.rs:561-588), so the budget is a property of the CONTEXT (mg_ctx_opts.full_table_bytes; default a tenth of the
-    // device's HBM; 0 = bucket tables only) and covers its five tables together. MANTA_FULL_TABLE_GB overrides it (GB per
-    // context), MANTA_FULL_C fixes the width. A context sharded over several entries of one device splits the budget.
-    int64_t full_budget_ = 0;   // bytes for this shard's five full tables
-    int full_c_plan_[5] = {0, 0, 0, 0, 0}; // planned widths: a, b_g1, b_g2, l, h (0 = none)
-    static u64 full_cost(GroupEngine *g, u64 n, int c) {
-        return ((u64)((g->scalar_bits() + c - 1) / c) << (c - 1)) * n * (u64)g->base_record_bytes();
-    }
-    static bool full_fits_index(GroupEngine *g, u64 n, int c) { return (((u64)((g->scalar_bits() + c - 1) / c) << (c - 1)) * n) < ((u64)1 << 31); }
-    // widths of the five tables under `budget`: the widest uniform width c in 4 .. 8 whose five tables fit together, then single
-    // queries one step wider while they fit, the longest chains first (b_g2, h, a, b_g1, l). n[i] = entries of query i on this shard.
-    void plan_full_tables(const u64 n[5], int64_t budget, int out[5], bool tie_abl = false) const {
-        for (int i = 0; i < 5; ++i) out[i] = 0;
-        static const int fixed = [] {
-            const int v = ab_knob("MANTA_FULL_C", 0);
-            return v >= 2 && v <= 12 ? v : 0;
-        }();
-        if (budget <= 0) return;
-        GroupEngine *ge[5] = {g1_, g1_, g2_, g1_, g1_};
-        auto total = [&](const int c[5]) {
-            u64 t = 0;
-            for (int i = 0; i < 5; ++i)
-                if (c[i] && n[i]) t += full_cost(ge[i], n[i], c[i]);
-            return t;
-        };
-        auto ok = [&](const int c[5]) {
-            for (int i = 0; i < 5; ++i)
-                if (c[i] && n[i] && !full_fits_index(ge[i], n[i], c[i])) return false;
-            return total(c) <= (u64)budget;
-        };
-        int c[5];
-        const int hi = fixed ? fixed : 8, lo = fixed ? fixed : 4;
-        int u = 0;
-        for (int w = hi; w >= lo && !u; --w) {
-            for (int i = 0; i < 5; ++i) c[i] = w;
-            if (ok(c)) u = w;
-        }
-        if (!u) return;
-        for (int i = 0; i < 5; ++i) c[i] = u;
-        if (!fixed) {
-            if (tie_abl) { // a, b_g1 and l share one concatenated table (z3_bs_full_): one width for the three
-                for (int i : {2, 4}) {
-                    if (c[i] >= 8) continue;
-                    ++c[i];
-                    if (!ok(c)) --c[i];
-                }
-                if (c[0] < 8) {
-                    ++c[0], ++c[1], ++c[3];
-                    if (!ok(c)) --c[0], --c[1], --c[3];
-                }
-            } else {
-                static const int order[5] = {2, 4, 0, 1, 3};
-                for (int step = 0; step < 5; ++step) {
-                    const int i = order[step];
-                    if (c[i] >= 8) continue;
-                    ++c[i];
-                    if (!ok(c)) --c[i];
-                }
-            }
-        }
-        for (int i = 0; i < 5; ++i) out[i] = n[i] ? c[i] : 0;
-    }
-    // the budget of this shard: the context option, else the tuning (MANTA_FULL_TABLE_GB / mg_set_tuning), else a tenth of the HBM; never more
-    // than 40 % of what is free on the device right now, split between the shards of this context that share the device
-    int64_t resolve_full_budget(int64_t opt_bytes, int shards_on_this_device) const {
-        size_t free_b = 0, total_b = 0;
-        const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
-        // (the context's own option first, then the tuning's budget -- MANTA_FULL_TABLE_GB lands there --, then a tenth of the device)
-        double b = opt_bytes >= 0 ? (double)opt_bytes : (tn_.full_table_bytes >= 0 ? (double)tn_.full_table_bytes : (have ? (double)total_b / 10.0 : 24e9));
-        if (have && b > 0.4 * (double)free_b) b = 0.4 * (double)free_b;
-        if (shards_on_this_device > 1) b /= shards_on_this_device;
-        return b > 0 ? (int64_t)b : 0;
-    }
-
-    // contiguous slice of an n-entry query owned by this shard
-    size_t shard_lo(size_t n) const { return n * shard_ / n_shards_; }
-    size_t shard_hi(size_t n) const { return n * (shard_ + 1) / n_shards_; }
-
-    // allow_z3 = false: the context is driven through the partials interface (mg_ctx_create_shard, an RCCL exchange) -- its passes
-    // fold every MSM by its own index, wants_z3() is false for them, and a combined table would only take the separate tables'
-    // HBM and leave a / b_g1 / l on the slower bucket tables (advisor r4)
-    int init(int curve, const mg_pk_view *pk, int device, u32 shard = 0, u32 n_shards = 1, int64_t full_table_bytes = -1,
-             int shards_on_this_device = 1, bool allow_z3 = true) {
-        curve_ = curve;
-        dev_ = device;
-        shard_ = shard;
-        n_shards_ = n_shards;
-        MG_HIP(hipSetDevice(dev_));
-        fr_ = get_ntt_engine(curve);
-        g1_ = get_engine(curve, 1);
-        g2_ = get_engine(curve, 2);
-        if (!fr_ || !g1_ || !g2_) return MG_ERR_ARG;
-        sets_ok_ = stream_sets_ready(); // (the caller holds HeavyOp; the first context of a device probes its hardware queues)
-        V_ = pk->n_vars;
-        P_ = pk->n_inputs;
-        h_len_ = pk->h_len;
-        if (V_ < 2 || P_ < 1 || P_ >= V_ || h_len_ < 1) return MG_ERR_ARG;
-        if (!pk->alpha_g1 || !pk->beta_g1 || !pk->delta_g1 || !pk->beta_g2 || !pk->delta_g2 || !pk->a_query ||
-            !pk->b_g1_query || !pk->b_g2_query || !pk->h_query || !pk->l_query)
-            return MG_ERR_ARG;
-        const size_t w1 = (size_t)g1_->affine_words(), w2 = (size_t)g2_->affine_words();
-        g1_->hp_from_affine(&alpha_g1_, (const u32 *)pk->alpha_g1);
-        g1_->hp_from_affine(&beta_g1_, (const u32 *)pk->beta_g1);
-        g1_->hp_from_affine(&delta_g1_, (const u32 *)pk->delta_g1);
-        g2_->hp_from_affine(&beta_g2_, (const u32 *)pk->beta_g2);
-        g2_->hp_from_affine(&delta_g2_, (const u32 *)pk->delta_g2);
-        g1_->hp_from_affine(&a0_, (const u32 *)pk->a_query);
-        g1_->hp_from_affine(&b1_0_, (const u32 *)pk->b_g1_query);
-        g2_->hp_from_affine(&b2_0_, (const u32 *)pk->b_g2_query);
-        a0_alpha_ = a0_;
-        g1_->hp_add(&a0_alpha_, &alpha_g1_);
-        b10_beta_ = b1_0_;
-        g1_->hp_add(&b10_beta_, &beta_g1_);
-        b20_beta_ = b2_0_;
-        g2_->hp_add(&b20_beta_, &beta_g2_);
-        delta1_tab_ = g1_->hp_table_create(&delta_g1_);
-        delta2_tab_ = g2_->hp_table_create(&delta_g2_);
-        int rc;
-        if (n_shards_ > 1 && (V_ - P_ < n_shards_ || V_ - 1 < n_shards_)) return MG_ERR_ARG; // every shard owns >= 1 entry
-        // this shard's slices of the z queries (entries 1 .. V-1 of a / b_g1 / b_g2) and of the l query
-        const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
-        const u32 *aq = (const u32 *)pk->a_query + (1 + zlo) * w1, *b1q = (const u32 *)pk->b_g1_query + (1 + zlo) * w1;
-        const u32 *b2q = (const u32 *)pk->b_g2_query + (1 + zlo) * w2, *lq = (const u32 *)pk->l_query + llo * w1;
-        const int c_z = pre_c_for(V_ - 1);
-        const bool proof_sized = V_ - 1 <= (1u << 17) && tn_.window_bits_narrow == 0;
-        if (proof_sized) {
-            full_budget_ = resolve_full_budget(full_table_bytes, shards_on_this_device);
-            u64 D = 1; // the domain the h query was made for: len(h_query) = D - 1 (ark setup) or D (MPC keys)
-            while (D < h_len_) D <<= 1;
-            const u64 nq[5] = {zn, zn, zn, ln, (u64)(D * (shard_ + 1) / n_shards_ - D * shard_ / n_shards_)};
-            plan_full_tables(nq, full_budget_, full_c_plan_, allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && ab_knob("MANTA_Z3", 1) != 0);
-        }
-        const int f_z1a = -full_c_plan_[0], f_z1b = -full_c_plan_[1], f_z2 = -full_c_plan_[2], f_l = -full_c_plan_[3];
-        if ((rc = g1_->bases_create(aq, zn, false, c_z, &a_bs_, true))) return rc;
-        if ((rc = g1_->bases_create(b1q, zn, false, c_z, &b1_bs_, true))) return rc;
-        // The G2 MSM is the latency-critical chain of a single proof: 6-bit windows (32 buckets: one tile, no second
-        // reduce level) shorten it by four dependent additions (measured +4 % proofs/s); the extra windows only
-        // add parallel mixed additions.
-        const bool small = V_ - 1 <= (1u << 17) && tn_.window_bits_narrow == 0;
-        // large keys (2^20 variables, BASELINE configs[2]): the 2^16 Fp2 buckets of a 17-bit window made the G2 bucket reduce a
-        // 4.4 ms chain of latency-bound kernels next to a 0.7 ms accumulate (profiles/r04_config2_timeline.txt); 13-bit windows
-        // -- 4 096 buckets, 20 windows instead of 15 -- trade a third more mixed additions for a sixteenth of the buckets
-        int c_g2 = small ? 6 : (c_z > 13 ? 13 : c_z);
-        if (tn_.window_bits_g2) c_g2 = tn_.window_bits_g2;
-        if ((rc = g2_->bases_create(b2q, zn, false, c_g2, &b2_bs_, true))) return rc;
-        if ((rc = g1_->bases_create(lq, ln, false, pre_c_for(V_ - P_), &l_bs_, true))) return rc;
-        // (an optimisation: a table that does not fit any more is left out, the bucket tables above serve its MSM)
-        auto try_full = [&](GroupEngine *g, const u32 *q, size_t cnt, int f, BaseSet **dst) -> int {
-            if (!f) return MG_OK;
-            const int r = g->bases_create(q, cnt, false, f, dst, true);
-            if (r == MG_ERR_OOM) {
-                *dst = nullptr;
-                (void)hipGetLastError();
-                return MG_OK;
-            }
-            return r;
-        };
-        if ((rc = try_full(g2_, b2q, zn, f_z2, &b2_bs_full_))) return rc; // the G2 chain first: the longest of a proof
-        static const bool z3_on = ab_knob("MANTA_Z3", 1) != 0;
-        const int c_z3 = std::min(full_c_plan_[0], std::min(full_c_plan_[1], full_c_plan_[3]));
-        if (z3_on && allow_z3 && n_shards_ == 1 && task_mask_ == 0x1f && c_z3 >= 2 && 3 * (u64)zn * ((u64)((g1_->scalar_bits() + c_z3 - 1) / c_z3) << (c_z3 - 1)) < ((u64)1 << 31)) {
-            // a | b_g1 | l as one table over the scalars z[1 .. V): l_query[i] belongs to z[P + i] = scalar P - 1 + i of that range
-            std::vector<u32> cat((size_t)3 * zn * w1, 0u);
-            std::memcpy(&cat[0], aq, zn * w1 * 4);
-            std::memcpy(&cat[zn * w1], b1q, zn * w1 * 4);
-            std::memcpy(&cat[(2 * zn + (size_t)(P_ - 1)) * w1], lq, ln * w1 * 4);
-            const int r = g1_->bases_create(cat.data(), 3 * zn, false, -c_z3, &z3_bs_full_, true, 3);
-            if (r == MG_ERR_OOM) {
-                z3_bs_full_ = nullptr;
-                (void)hipGetLastError();
-            } else if (r) {
-                return r;
-            }
-        }
-        if (!z3_bs_full_) {
-        if ((rc = try_full(g1_, aq, zn, f_z1a, &a_bs_full_))) return rc;
-        if ((rc = try_full(g1_, b1q, zn, f_z1b, &b1_bs_full_))) return rc;
-        if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
-        }
-        if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
-            int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
-            if (tn_.window_bits_wide) cw = tn_.window_bits_wide; // tuning override
-            if ((rc = g1_->bases_create(aq, zn, false, cw, &a_bs_wide_, true))) return rc;
-            if ((rc = g1_->bases_create(b1q, zn, false, cw, &b1_bs_wide_, true))) return rc;
-            if ((rc = g2_->bases_create(b2q, zn, false, cw, &b2_bs_wide_, true))) return rc;
-            if ((rc = g1_->bases_create(lq, ln, false, cw, &l_bs_wide_, true))) return rc;
-        }
-        // h_query is stored in the bit-reversed order the witness map leaves h in; that order depends on
-        // the domain size, known once the R1CS arrives (set_r1cs)
-        h_query_host_.assign((const u32 *)pk->h_query, (const u32 *)pk->h_query + (size_t)h_len_ * w1);
-        return MG_OK;
-    }
-
-    // Structural checks of one matrix as it arrives over the ABI (O(m + nnz) on the host): the device kernels loop
-    // k = row_ptr[i] .. row_ptr[i+1] and gather z[col[k]] without further checks, so nothing malformed may pass here.
-    static int validate_csr(const mg_csr *src, u64 m, u64 n_vars) {
-        if (!src || !src->row_ptr || (src->nnz && (!src->col || !src->val))) return MG_ERR_ARG;
-        if (src->nnz >= ((u64)1 << 32)) return MG_ERR_ARG;
-        if (src->row_ptr[0] != 0 || src->row_ptr[m] != src->nnz) return MG_ERR_ARG;
-        for (u64 i = 0; i < m; ++i)
-            if (src->row_ptr[i] > src->row_ptr[i + 1]) return MG_ERR_ARG; // monotone => every entry <= row_ptr[m] = nnz
-        for (u64 k = 0; k < src->nnz; ++k)
-            if (src->col[k] >= n_vars) return MG_ERR_ARG;
-        return MG_OK;
-    }
-    static int upload_csr(const mg_csr *src, u64 m, DevCsr &dst) { // dst is empty on entry; freed by the caller on failure
-        dst.nnz = src->nnz;
-        MG_HIP(hipMalloc((void **)&dst.row_ptr, (m + 1) * 4));
-        MG_HIP(hipMalloc((void **)&dst.col, (src->nnz ? src->nnz : 1) * 4));
-        MG_HIP(hipMalloc((void **)&dst.val, (src->nnz ? src->nnz : 1) * 32));
-        MG_HIP(memcpy_sync(dst.row_ptr, src->row_ptr, (m + 1) * 4, hipMemcpyHostToDevice));
-        if (src->nnz) {
-            MG_HIP(memcpy_sync(dst.col, src->col, src->nnz * 4, hipMemcpyHostToDevice));
-            MG_HIP(memcpy_sync(dst.val, src->val, src->nnz * 32, hipMemcpyHostToDevice));
-        }
-        return MG_OK;
-    }
-
-    // Replaces the circuit. All-or-nothing, on every shard at once: the exclusive locks of ALL shards are taken in the order in
-    // which a pass takes its shared ones (shard 0, then the peers) -- so no pass is in flight on any of them; then, in two
-    // phases, every shard first validates the three matrices, uploads them into temporaries and builds the h-query tables of
-    // a new domain size -- a failure on any shard (say, out of memory on one device) frees the temporaries everywhere and
-    // leaves the previous circuit, if any, fully usable -- and only when all of them have succeeded is every shard switched
-    // over: a proof never runs with some shards on the new matrices and others on the old.
-    struct StagedR1cs {
-        DevCsr A, B, C;
-        BaseSet *h = nullptr, *h_wide = nullptr, *h_full = nullptr;
-        bool new_domain = false;
-        unsigned lg = 0;
-        u64 m = 0;
-    };
-    std::mutex set_mu_; // one set_r1cs at a time per context (shard 0's)
-    int set_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m) override {
-        int rc = MG_OK, prev = 0;
-        MG_HIP(hipGetDevice(&prev));
-        std::lock_guard<std::mutex> one_at_a_time(set_mu_);
-        std::vector<ProverImpl *> all{this};
-        all.insert(all.end(), peers_.begin(), peers_.end());
-        // The exclusive locks are taken BEFORE staging as well: staging uploads with synchronous copies, builds window tables
-        // on the default stream and ends in hipDeviceSynchronize, and the HIP runtime fails the graph capture of a proof
-        // slot on another thread when that happens meanwhile (seen on MI355X: mg_groth16_prove returning a HIP error while a
-        // circuit was being staged). With every shard locked no pass is in flight, none starts, nothing is capturing.
-        std::vector<std::unique_lock<std::shared_mutex>> locks;
-        for (ProverImpl *q : all) locks.emplace_back(q->shape_mu_);
-        // (after the shape locks, never before: a pass that holds a shape lock shared may be waiting for the capture lock)
-        HeavyOp no_capture_meanwhile;
-        std::vector<StagedR1cs> st(all.size());
-        for (size_t g = 0; g < all.size() && !rc; ++g) rc = all[g]->stage_r1cs(a, b, c, m, st[g]);
-        if (rc) {
-            for (size_t g = 0; g < all.size(); ++g) all[g]->discard_staged(st[g]);
-            hipSetDevice(prev);
-            return rc;
-        }
-        for (size_t g = 0; g < all.size(); ++g) all[g]->commit_staged(st[g]);
-        hipSetDevice(prev);
-        return MG_OK;
-    }
-    u64 n_vars() const override { return V_; }
-    u64 n_inputs() const override { return P_; }
-    u32 n_shards() const override { return n_shards_; }
-    void discard_staged(StagedR1cs &st) {
-        hipSetDevice(dev_);
-        free_csr(st.A), free_csr(st.B), free_csr(st.C);
-        if (st.h) g1_->bases_destroy(st.h);
-        if (st.h_wide) g1_->bases_destroy(st.h_wide);
-        if (st.h_full) g1_->bases_destroy(st.h_full);
-        st.h = st.h_wide = st.h_full = nullptr;
-    }
-    // phase 1 on this shard: nothing visible to a proof is touched
-    int stage_r1cs(const mg_csr *a, const mg_csr *b, const mg_csr *c, u64 m, StagedR1cs &st) {
-        MG_HIP(hipSetDevice(dev_));
-        if (m == 0 || m + P_ > ((u64)1 << 32)) return MG_ERR_ARG;
-        unsigned lg = 0;
-        while (((u64)1 << lg) < m + P_) ++lg; // GeneralEvaluationDomain::new(m + P) -> next power of two
-        if ((int)lg > fr_->two_adicity()) return MG_ERR_DOMAIN;
-        int rc;
-        if ((rc = validate_csr(a, m, V_)) || (rc = validate_csr(b, m, V_)) || (rc = validate_csr(c, m, V_))) return rc;
-        st.lg = lg;
-        st.m = m;
-        if ((rc = upload_csr(a, m, st.A)) || (rc = upload_csr(b, m, st.B)) || (rc = upload_csr(c, m, st.C))) return rc;
-        st.new_domain = !h_bs_ || lg != log_d_; // (h_bs_ / log_d_ only change under set_mu_, which the caller holds)
-        if (st.new_domain) { // (re)build the h-query base set for this domain
-            const size_t D = (size_t)1 << lg, w1 = (size_t)g1_->affine_words();
-            // this shard's slice [h_lo, h_hi) of the bit-reversed positions; entries beyond len(h_query) stay
-            // infinity: h[D-1] = 0 anyway
-            const size_t lo = shard_lo(D), hi = shard_hi(D);
-            std::vector<u32> perm((hi - lo) * w1, 0u);
-            for (size_t p = lo; p < hi; ++p) {
-                size_t src = 0;
-                for (unsigned bb = 0; bb < lg; ++bb) src |= ((p >> bb) & 1) << (lg - 1 - bb);
-                if (src < h_len_) std::memcpy(&perm[(p - lo) * w1], &h_query_host_[src * w1], w1 * 4);
-            }
-            // The h MSM is the one with dense, uniform scalars -- half of all the mixed additions of a proof at
-            // c = 8. Wider windows halve them, but lengthen its bucket reduce: measured on PrivateTransfer,
-            // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32); for single proofs the
-            // reduce chain matters more (with the cooperative reduce: c_h = 8/10/12 -> 839 / 859 / 862 proofs/s).
-            // The tables are small (80 MB), so single proofs and batches each get their own width.
-            int ch = pre_c_for(D), ch_wide = ch;
-            if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)
-            if (lg <= 17) ch_wide = (int)lg - 2 < 8 ? 8 : ((int)lg - 2 > 14 ? 14 : (int)lg - 2);
-            if (tn_.window_bits_h) ch = ch_wide = tn_.window_bits_h;
-            // the h table gets what the budget has left after the four z / l tables: the planned width when the domain is the
-            // one the key was made for, else the widest that still fits
-            int f_h = 0;
-            if (lg <= 17 && !tn_.window_bits_h && full_budget_ > 0) {
-                int64_t left = full_budget_;
-                for (const BaseSet *b : {a_bs_full_, b1_bs_full_, b2_bs_full_, l_bs_full_, z3_bs_full_}) // (z3 replaces a / b_g1 / l: advisor r4)
-                    if (b) left -= (int64_t)b->bytes;
-                for (int cc = full_c_plan_[4] ? std::max(full_c_plan_[4], 4) : 0; cc >= 4 && !f_h; --cc)
-                    if (full_fits_index(g1_, hi - lo, cc) && (int64_t)full_cost(g1_, hi - lo, cc) <= left) f_h = -cc;
-            }
-            rc = g1_->bases_create(perm.data(), hi - lo, false, ch, &st.h);
-            if (!rc && ch_wide != ch) rc = g1_->bases_create(perm.data(), hi - lo, false, ch_wide, &st.h_wide);
-            if (!rc && f_h && g1_->bases_create(perm.data(), hi - lo, false, f_h, &st.h_full) != MG_OK) {
-                st.h_full = nullptr; // optional: the bucket tables serve
-                (void)hipGetLastError();
-            }
-            if (rc) return rc;
-        }
-        return MG_OK;
-    }
-    // phase 2 on this shard; the caller holds the exclusive shape lock of every shard
-    void commit_staged(StagedR1cs &st) {
-        hipSetDevice(dev_);
-        std::lock_guard<std::mutex> g(mu_);
-        free_csr(A_), free_csr(B_), free_csr(C_);
-        A_ = st.A, B_ = st.B, C_ = st.C;
-        st.A = st.B = st.C = DevCsr();
-        if (st.new_domain) {
-            if (h_bs_) g1_->bases_destroy(h_bs_);
-            if (h_bs_wide_) g1_->bases_destroy(h_bs_wide_);
-            if (h_bs_full_) g1_->bases_destroy(h_bs_full_);
-            h_bs_ = st.h, h_bs_wide_ = st.h_wide, h_bs_full_ = st.h_full;
-            st.h = st.h_wide = st.h_full = nullptr;
-        }
-        // pooled proof slots hold captured graphs and buffers sized for the previous shape: drop them (slots of
-        // another generation that are still in flight cannot exist -- the exclusive locks waited for them)
-        for (auto &kv : ws_free_)
-            for (ProveWs *w : kv.second) delete w;
-        ws_free_.clear();
-        idle_slots_ = 0;
-        ++gen_;
-        m_ = st.m;
-        log_d_ = st.lg;
-        have_r1cs_ = true;
-    }
-
-    // How a SINGLE proof's slot replays (ProveWs::linear3). 0: the forked graph. 1: three linear graphs -- witness map + h | a|b_g1|l
-    // | G2 -- on three high-priority streams: the shortest chain for a LONE proof (company 0: no other pass of this context in
-    // flight). 2 / 3: the same beside other passes, with ONE chain on a normal-priority stream -- the combined MSM beside a batched
-    // pass (company 2), the G2 MSM beside single proofs only (company 1: two host threads). The streams come from
-    // stream_set_acquire (runtime.cpp): three DIFFERENT hardware queues per slot, and the two slots that two host threads keep in
-    // flight share none -- before, which chains of the two proofs met on one queue was decided by the order in which the process
-    // had created its streams, and two threads ran at 976 or 1 364 proofs/s from process to process (profiles/r05_hw_queues.txt).
-    // A normal-priority chain costs a lone proof 18 %: flavour 1 keeps all three high. Which chain yields beside others is measured:
-    // two threads 1 412-1 435 proofs/s with the combined MSM normal, 1 511-1 531 with the G2 MSM normal; six threads (singles beside
-    // coalesced passes) 1 794-1 898 against 1 624-1 700.
-    // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 no flavour 3, 3 (default) all of the above.
-    int lin_flavour(u32 k, bool z3, int company) const {
-        const int z3_linear = tn_.linear_chains;
-        if (!(z3 && k == 1 && prove_streams() == 6 && graph_mode_for(k) == GRAPH_SINGLE)) return 0;
-        if (company == 0) return z3_linear >= 1 ? 1 : 0;
-        if (!(z3_linear >= 2 && sets_ok_)) return 0; // (linear graphs beside others need queues of their own: -18 % without)
-        return company == 1 && z3_linear >= 3 ? 3 : 2;
-    }
-    static u32 slot_key(u32 k, bool z3, int flavour = 0) { return k | (z3 ? 1u << 16 : 0u) | ((u32)flavour << 17); }
-    ProveWs *ws_acquire(u32 k = 1, bool z3 = false, int company = 0) {
-        u64 gen;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            gen = gen_;
-            auto it = ws_free_.find(slot_key(k, z3, lin_flavour(k, z3, company)));
-            while (it != ws_free_.end() && !it->second.empty()) {
-                ProveWs *w = it->second.back();
-                it->second.pop_back();
-                --idle_slots_;
-                if (w->gen == gen_) return w;
-                delete w; // sized / captured for a previous circuit
-            }
-        }
-        HeavyOp creates_streams_events_workspaces; // (not beside another thread's capture: ADVICE r5)
-        ProveWs *w = new ProveWs();
-        w->k = k;
-        w->z3 = z3;
-        w->gen = gen;
-        w->device = dev_;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            w->no_graph = no_graph_keys_.count(slot_key(k, z3, lin_flavour(k, z3, company))) != 0; // (a capture of this kind failed for good)
-        }
-        static const int z3_high = ab_knob("MANTA_Z3_HIGH", -1); // A/B: the combined MSM's stream of every linear3 slot normal (0) / high (1) priority
-        w->flavour = lin_flavour(k, z3, company);
-        if (w->flavour && stream_set_acquire(w->sset, z3_high >= 0 ? z3_high != 0 : w->flavour == 1))
-            w->stream = w->sset.main, w->side[0] = w->sset.g2, w->side[1] = w->sset.z3;
-        if (w->sset.id >= 0 && w->flavour == 3 && !w->sset.z3_high) std::swap(w->side[0], w->side[1]); // the G2 chain takes the normal-priority stream
-        if ((w->sset.id < 0 && (!(w->stream = stream_pool_get()) || !(w->side[0] = stream_pool_get()) ||
-                                !(w->side[1] = stream_pool_get()))) ||
-            hipEventCreateWithFlags(&w->z_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&w->h_ready, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&w->fork, hipEventDisableTiming) != hipSuccess) {
-            delete w;
-            return nullptr;
-        }
-        GroupEngine *me[5] = {g1_, g1_, g2_, g1_, g1_}; // a, b_g1, b_g2, l, h
-        for (int i = 0; i < 5; ++i) {
-            w->me[i] = me[i];
-            w->mw[i] = me[i]->ws_acquire();
-            if (!w->mw[i]) {
-                delete w;
-                return nullptr;
-            }
-            w->mw[i]->in_graph_slot = graph_mode_for(k) == GRAPH_SINGLE; // (multi-branch capture: no front levels)
-        }
-        // z3 slots: the combined a | b_g1 | l MSM announces its end through a pinned flag (MsmWorkspace::notify), so that the host
-        // can fold its three results into s A + r B1 -- the one long piece of host work of a proof, ~0.1 ms -- while the h chain is
-        // still running (finish_pass_body). MANTA_Z3_EARLY=0: wait for all of part A first, as before (A/B).
-        static const bool z3_early = ab_knob("MANTA_Z3_EARLY", 1) != 0;
-        w->mw[0]->notify = z3 && z3_early;
-        // Three streams per proof, not six: the G2 MSM is the critical path (~3x a G1 MSM), so the three
-        // z-MSMs over G1 run back to back beside it and the h MSM follows the witness map on the main stream.
-        // Fewer streams = fewer hardware queues per proof in flight (the runtime multiplexes streams onto
-        // GPU_MAX_HW_QUEUES queues; streams that share one serialise). MANTA_PROVE_STREAMS=6 restores one
-        // stream per MSM.
-        w->mw[2]->run_on = w->side[0]; // the G2 MSM (the critical path) gets a high-priority stream of its own
-        if (w->flavour) {
-            w->linear3 = true;
-            w->mw[0]->run_on = w->side[1]; // the combined MSM: a high-priority pooled stream of its own
-            w->mw[4]->run_on = w->stream;  // the h MSM follows the witness map on the main stream
-            for (int i = 0; i < 5; ++i) w->mw[i]->in_graph_slot = false; // (single-stream captures only: front levels allowed)
-        } else
-        if (prove_streams() == 3) {
-            w->mw[0]->run_on = w->side[1];
-            w->mw[1]->run_on = w->side[1];
-            w->mw[2]->run_on = w->side[0];
-            w->mw[3]->run_on = w->side[1];
-            w->mw[4]->run_on = w->stream;
-        } else if (prove_streams() == 1) {
-            for (int i = 0; i < 5; ++i) w->mw[i]->run_on = w->stream;
-        } else if (prove_streams() == 4) { // three branches beside the G2 chain: (a, b_g1) back to back | l | witness map + h
-            w->mw[0]->run_on = w->side[1];
-            w->mw[1]->run_on = w->side[1];
-            w->mw[4]->run_on = w->stream;
-        } else if (prove_streams() == 5) { // (a, l) back to back | b_g1 | witness map + h
-            w->mw[0]->run_on = w->side[1];
-            w->mw[3]->run_on = w->side[1];
-            w->mw[4]->run_on = w->stream;
-        }
-        return w;
-    }
-    // Idle slots are cached per exact batch size (their buffers and graphs are sized for it) but the cache is
-    // bounded: a slot of an outdated circuit generation is destroyed, and beyond MAX_IDLE_SLOTS the least recently
-    // used idle slot goes -- its MSM workspaces return to the engine pool, which is bounded too (runtime.cpp), so a
-    // service that varies k or creates and drops contexts does not accumulate HBM.
-    void ws_release(ProveWs *w) {
-        std::vector<ProveWs *> doomed;
-        {
-            std::lock_guard<std::mutex> g(mu_);
-            if (w->gen != gen_ || w->poisoned) {
-                doomed.push_back(w);
-            } else {
-                w->last_use = ++lru_tick_;
-                ws_free_[slot_key(w->k, w->z3, w->flavour)].push_back(w);
-                ++idle_slots_;
-                while (idle_slots_ > MAX_IDLE_SLOTS) {
-                    std::vector<ProveWs *> *from = nullptr;
-                    size_t at = 0;
-                    for (auto &kv : ws_free_)
-                        for (size_t i = 0; i < kv.second.size(); ++i)
-                            if (!from || kv.second[i]->last_use < (*from)[at]->last_use) from = &kv.second, at = i;
-                    if (!from) break;
-                    doomed.push_back((*from)[at]);
-                    from->erase(from->begin() + (long)at);
-                    --idle_slots_;
-                }
-            }
-        }
-        for (ProveWs *d : doomed) delete d;
-    }
-
-    // Witness map for the slot's w->k assignments (stored back to back, like the three work vectors: member q of
-    // a batch lives V resp. D elements after member q-1); h ends up in w->a.
-    int reserve_witness_map(ProveWs *w) {
-        const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words() * 4; // bytes per work element
-        int rc;
-        if ((rc = w->z.reserve(k * V_ * 32)) || (rc = w->a.reserve(3 * k * D * ww))) return rc;
-        return MG_OK;
-    }
-    // everything after the upload of z, on w->stream (this is what the witness-map graph captures)
-    int enqueue_witness_map_body(ProveWs *w) {
-        const size_t D = (size_t)1 << log_d_, k = w->k, ww = (size_t)fr_->work_words(); // u32 per work element
-        int rc;
-        hipStream_t s = w->stream;
-        u32 *a = w->a.as<u32>(), *b = a + k * D * ww, *c = b + k * D * ww, *zz = w->z.as<u32>();
-        const size_t zs = (size_t)V_ * 8, ds = D * ww;
-#ifdef MG_DIAG
-        // diagnosis builds: MG_DIAG_MEMSET=1 puts the round-4 memset node back in front of the SpMV (the negative control of
-        // test_captured_graphs_survive_other_contexts: with it a LINEAR part A must go wrong); MG_DIAG_WM_STOP cuts the witness map
-        static const int diag_memset = ab_knob("MG_DIAG_MEMSET", 0);
-        static const int diag_stop = ab_knob("MG_DIAG_WM_STOP", 0);
-        if (diag_memset) MG_HIP(hipMemsetAsync(w->a.p, 0, 3 * k * D * ww * 4, s));
-        if (diag_stop == 1) return MG_OK;
-#endif
-        // A z, B z, C z in the reduced-radix work form; the A vector also gets the input-consistency rows a[m + j] = z_j, and every
-        // vector its zero rows up to the domain size (the all-zero words are 0 in the work form too): no memset node in front of it
-#ifdef MG_DIAG
-        if (diag_memset) { // round 4 exactly: the memset node zeroes, the SpMV writes its m + P rows only
-            if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds, 0))) return rc;
-        } else
-#endif
-        if ((rc = fr_->spmv3(A_, B_, C_, zz, a, b, c, m_, P_, s, (u32)k, zs, ds, D))) return rc;
-#ifdef MG_DIAG
-        if (diag_stop == 2) return MG_OK;
-#endif
-        // ifft x3, coset fft x3, (ab - c)/Z, coset ifft -- fused; leaves h bit-reversed in `a`
-        if ((rc = fr_->qap_quotient(a, b, c, log_d_, s, (u32)k))) return rc;
-        return MG_OK;
-    }
-    // H2D(z), recording z_ready
-    int upload_z(ProveWs *w, const uint64_t *z) {
-        int rc = reserve_witness_map(w);
-        if (rc) return rc;
-        if (w->z_parts.size() == w->k) { // coalesced single calls: one copy per assignment, from where it lies
-            for (u32 q = 0; q < w->k; ++q)
-                MG_HIP(hipMemcpyAsync((char *)w->z.p + (size_t)q * V_ * 32, w->z_parts[q], (size_t)V_ * 32, hipMemcpyHostToDevice, w->stream));
-        } else
-            MG_HIP(hipMemcpyAsync(w->z.p, z, (size_t)w->k * V_ * 32, hipMemcpyHostToDevice, w->stream));
-        MG_HIP(hipEventRecord(w->z_ready, w->stream));
-        return MG_OK;
-    }
-    // witness map after upload_z; records h_ready at the end
-    int launch_witness_map(ProveWs *w, bool use_graph = false) {
-        int rc;
-        if (use_graph) {
-            MG_HIP(hipGraphLaunch(w->g_wm, w->stream));
-        } else if ((rc = enqueue_witness_map_body(w))) {
-            return rc;
-        }
-        MG_HIP(hipEventRecord(w->h_ready, w->stream));
-        return MG_OK;
-    }
-
-    int witness_map_host(const uint64_t *z, uint64_t *h_out) override {
-        DeviceGuard restore_callers_device;
-        MG_HIP(hipSetDevice(dev_));
-        std::shared_lock<std::shared_mutex> shape_lock(shape_mu_);
-        if (!have_r1cs_) return MG_ERR_STATE;
-        ProveWs *w = ws_acquire();
-        if (!w) return MG_ERR_HIP;
-        int rc = upload_z(w, z);
-        if (!rc) rc = launch_witness_map(w);
-        if (!rc) {
-            const size_t D = (size_t)1 << log_d_;
-            std::vector<uint64_t> tmp(D * 4);
-            u32 *d_std = nullptr; // h leaves the pipeline in the work form: convert for the host
-            hipError_t e = hipMalloc((void **)&d_std, D * 32);
-            if (e == hipSuccess && fr_->work_to_std(w->a.as<u32>(), D, d_std, w->stream)) e = hipErrorUnknown;
-            if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), d_std, D * 32, hipMemcpyDeviceToHost, w->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
-            if (d_std) hipFree(d_std);
-            if (e != hipSuccess) {
-                set_last_hip_error(e, "witness_map_host", __FILE__, __LINE__);
-                rc = MG_ERR_HIP;
-            } else { // the device keeps h bit-reversed; the API returns natural order like witness_map
-                for (size_t p = 0; p < D; ++p) {
-                    size_t src = 0;
-                    for (unsigned b = 0; b < log_d_; ++b) src |= ((p >> b) & 1) << (log_d_ - 1 - b);
-                    std::memcpy(h_out + src * 4, &tmp[p * 4], 32);
-                }
-            }
-        } else {
-            hipStreamSynchronize(w->stream);
-        }
-        ws_release(w);
-        return rc;
-    }
-
-    struct MsmArgs {
-        const BaseSet *bs[5];
-        const u32 *sc[5];
-        size_t cnt[5], stride[5];
-    };
-    MsmArgs msm_args(const ProveWs *w) const {
-        const size_t D = (size_t)1 << log_d_;
-        const u32 *dz = w->z.as<u32>();
-        // h and the h-query bases are both bit-reversed; bases beyond len(h_query) are infinity
-        // (multi_scalar_mul zips to the shorter; the dropped coefficient h[D-1] is zero)
-        // batched passes switch to the wide-window tables (fewer mixed additions, longer bucket reduce) from this many proofs
-        // on: a pass of a few coalesced single calls is still a latency chain and keeps the narrow ones (MANTA_WIDE_MIN)
-        static const u32 wide_min = [] {
-            const int v = ab_knob("MANTA_WIDE_MIN", 4);
-            return (u32)(v >= 1 && v <= 64 ? v : 4);
-        }();
-        const bool wide = w->k >= wide_min;
-        // a range shard multiplies its contiguous slice of every query by the matching slice of the scalars
-        const size_t zlo = shard_lo(V_ - 1), zn = shard_hi(V_ - 1) - zlo, llo = shard_lo(V_ - P_), ln = shard_hi(V_ - P_) - llo;
-        const size_t hlo = shard_lo(D), hn = shard_hi(D) - hlo;
-        const u32 *sz = dz + (1 + zlo) * 8;
-        // passes of up to this many proofs run on the full tables where the key has them (MANTA_FULL_MAX_K; a batch sorts its
-        // pairs by proof -- one radix pass -- and needs 32 additions per scalar where the wide bucket tables need 24)
-        static const u32 full_max_k = [] {
-            const int v = ab_knob("MANTA_FULL_MAX_K", 1);
-            return (u32)(v >= 0 ? v : 1);
-        }();
-        const bool one = w->k <= full_max_k;
-        auto pick = [&](BaseSet *full, BaseSet *wd, BaseSet *narrow) { return one && full ? full : (wide && wd ? wd : narrow); };
-        return MsmArgs{{w->z3 ? z3_bs_full_ : pick(a_bs_full_, a_bs_wide_, a_bs_), pick(b1_bs_full_, b1_bs_wide_, b1_bs_), pick(b2_bs_full_, b2_bs_wide_, b2_bs_),
-                        pick(l_bs_full_, l_bs_wide_, l_bs_), pick(h_bs_full_, h_bs_wide_, h_bs_)},
-                       {sz, sz, sz, dz + ((size_t)P_ + llo) * 8, w->a.as<u32>() + hlo * (size_t)fr_->work_words()},
-                       {zn, zn, zn, ln, hn},
-                       {(size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, (size_t)V_ * 8, D * (size_t)fr_->work_words()}};
-    }
-    // does this slot launch MSM i (a, b_g1, b_g2, l, h)? -- not another rank's (task placement), not folded into the combined one
-    bool runs(const ProveWs *w, int i) const { return does(i) && !(w->z3 && (i == 1 || i == 3)); }
-    bool wants_z3(u32 k) const {
-        static const u32 full_max_k = [] {
-            const int v = ab_knob("MANTA_FULL_MAX_K", 1);
-            return (u32)(v >= 0 ? v : 1);
-        }();
-        // (passes of one proof only: on full tables passes of 2-8 proofs are SLOWER than on the narrow bucket tables -- 2.65 against 1.9 ms
-        // for two, six signer threads 1 300 against 1 650 proofs/s -- measured with MANTA_FULL_MAX_K = 4 / 8, round 4)
-        return z3_bs_full_ && k == 1 && full_max_k >= 1 && peers_.empty() && !ex_;
-    }
-    static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
-
-    // The GPU side of a pass is two independent pieces that only share the uploaded assignment:
-    //   part A, on w->stream: witness map, then the four G1 MSMs (a, b_g1, l from z; h from the witness map)
-    //           forked onto their streams with events and joined back;
-    //   part B, on the G2 MSM's stream: the G2 MSM -- the longest chain of a proof.
-    // The host waits for part A first and does the G1 half of the assembly (s*A + r*B1 is ~0.15 ms of host work)
-    // while part B is still running. use_graphs replays the per-stream graphs of the "split" mode instead of
-    // enqueuing kernels; the event structure is identical.
-    static bool in_part_a(int i) { return i != 2; }
-    int enqueue_msm(ProveWs *w, const MsmArgs &a, int i, bool use_graphs) {
-        if (use_graphs) {
-            hipStream_t ms = msm_stream(w, i);
-            MG_HIP(hipGraphLaunch(w->g_msm[i], ms));
-            MG_HIP(hipEventRecord(w->mw[i]->done, ms));
-            w->mw[i]->pending = 1;
-            return MG_OK;
-        }
-        // the z MSMs see witness scalars (mostly 0 / 1 / small): compact their zero digits; h is dense
-        if (w->timed) MG_HIP(hipEventRecord(w->tev[3 + 2 * i], msm_stream(w, i)));
-        const int rc = w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
-        if (w->timed && !rc) MG_HIP(hipEventRecord(w->tev[4 + 2 * i], msm_stream(w, i)));
-        return rc;
-    }
-    int enqueue_part_a(ProveWs *w, bool use_graphs) {
-        int rc;
-        const MsmArgs a = msm_args(w);
-        MG_HIP(hipEventRecord(w->fork, w->stream)); // z is on the device (upload_z ran on this stream)
-        if (w->timed) MG_HIP(hipEventRecord(w->tev[1], w->stream));
-        if (does(4) && (rc = launch_witness_map(w, use_graphs))) return rc; // h is only needed by the h MSM
-        if (w->timed) MG_HIP(hipEventRecord(w->tev[2], w->stream));
-        for (int i = 0; i < 5; ++i) {
-            if (!in_part_a(i) || !runs(w, i)) continue;
-            hipStream_t ms = msm_stream(w, i);
-            // (round 5, measured and dropped: for LARGE proofs -- 2^20 variables -- the a / b_g1 / l MSMs launched BEHIND the witness
-            // map instead of beside it: the witness map falls from 5.9 to 3.8 ms and each of the three MSMs from 4-7 to 2-3 ms, but the
-            // proof goes from 10.5 to 11.0 ms -- the chip is busy either way: profiles/r05_config2_ab.txt)
-            if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
-            if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
-        }
-        for (int i = 0; i < 5; ++i) { // join (after every launch, so that no MSM on the main stream queues behind a wait)
-            hipStream_t ms = msm_stream(w, i);
-            if (in_part_a(i) && runs(w, i) && ms != w->stream) MG_HIP(hipStreamWaitEvent(w->stream, w->mw[i]->done, 0));
-        }
-        if (w->timed) MG_HIP(hipEventRecord(w->tev[13], w->stream));
-        return MG_OK;
-    }
-    int enqueue_part_b(ProveWs *w, bool use_graphs) { return does(2) ? enqueue_msm(w, msm_args(w), 2, use_graphs) : MG_OK; }
-
-    int enqueue_proof(ProveWs *w, const uint64_t *z_src, bool use_graphs) {
-        if (w->timed) MG_HIP(hipEventRecord(w->tev[0], w->stream));
-        int rc = upload_z(w, z_src);
-        if (rc) return rc;
-        hipStream_t g2s = msm_stream(w, 2);
-        if (w->timed) { // eager launches with events between the phases
-            if ((rc = enqueue_part_a(w, false))) return rc;
-            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
-            if ((rc = enqueue_part_b(w, false))) return rc;
-            MG_HIP(hipEventRecord(w->tev[14], g2s));
-            return MG_OK;
-        }
-        if (w->linear3 && w->g_all && w->g_g2 && w->g_msm[0]) { // three linear graphs, each behind the upload
-            hipStream_t z3s = msm_stream(w, 0);
-            // launch order (MANTA_Z3_ORDER, three letters of a = witness map + h, b = G2, z = combined): the chain that bounds the
-            // proof first -- each hipGraphLaunch is 10-20 us of host time, which the chains launched later start behind
-            static const char *order = [] {
-                const char *e = ab_knob_str("MANTA_Z3_ORDER", "abz");
-                return std::strlen(e) == 3 ? e : "abz";
-            }();
-            for (int t = 0; t < 3; ++t) {
-                if (order[t] == 'a') {
-                    MG_HIP(hipGraphLaunch(w->g_all, w->stream));
-                } else if (order[t] == 'b') {
-                    if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
-                    MG_HIP(hipGraphLaunch(w->g_g2, g2s));
-                } else {
-                    if (z3s != w->stream) MG_HIP(hipStreamWaitEvent(z3s, w->z_ready, 0));
-                    MG_HIP(hipGraphLaunch(w->g_msm[0], z3s));
-                }
-            }
-            for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
-            return MG_OK;
-        }
-        if (w->g_all && w->g_g2) { // "single" mode replay
-            // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
-            // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
-            if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
-            MG_HIP(hipGraphLaunch(w->g_g2, g2s));
-            MG_HIP(hipGraphLaunch(w->g_all, w->stream));
-            for (int i = 0; i < 5; ++i) w->mw[i]->pending = runs(w, i) ? 1 : 0;
-            return MG_OK;
-        }
-        if ((rc = enqueue_part_a(w, use_graphs))) return rc;
-        if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
-        return enqueue_part_b(w, use_graphs);
-    }
-
-    // capture one single-stream segment into an executable graph
-    // why the last failed capture_segment of this thread failed: true = the capture itself was invalidated / the stream cannot
-    // capture (streams that joined it are not trusted again), false = a deterministic failure (instantiation, out of memory)
-    static bool &capture_invalidated() {
-        static thread_local bool v = false;
-        return v;
-    }
-    template <class Fn> static bool capture_segment(hipStream_t s, hipGraphExec_t *out, Fn &&body) {
-        capture_invalidated() = false;
-        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-            capture_invalidated() = true; // (still capturing / invalidated from an earlier failure)
-            (void)hipGetLastError();
-            return false;
-        }
-        const int rc = body();
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusActive) capture_invalidated() = true;
-        hipGraph_t graph = nullptr;
-        const hipError_t e = hipStreamEndCapture(s, &graph);
-        if (e == hipErrorStreamCaptureInvalidated || e == hipErrorStreamCaptureUnjoined || e == hipErrorStreamCaptureUnmatched ||
-            e == hipErrorStreamCaptureWrongThread || e == hipErrorStreamCaptureImplicit)
-            capture_invalidated() = true;
-        bool ok = !rc && e == hipSuccess && graph && hipGraphInstantiate(out, graph, nullptr, nullptr, 0) == hipSuccess;
-        if (graph) hipGraphDestroy(graph);
-        if (!ok) {
-            *out = nullptr;
-            (void)hipGetLastError();
-        }
-        return ok;
-    }
-    // every buffer has its final size (two eager runs): capture the witness map and the five MSMs
-    bool build_graphs(ProveWs *w) {
-        // exclusive side of the capture lock, but never WAITED for at once: a context creation (seconds of table precompute on the
-        // shared side) or a stream of stand-alone MSM calls would stall this proving thread with its shape lock held (and libstdc++'s
-        // shared_mutex prefers readers). The pass runs eagerly instead and the capture is retried on a later pass; after
-        // CAPTURE_TRIES such passes it waits.
-        std::unique_lock<std::shared_mutex> no_heavy_ops_meanwhile(capture_mutex(), std::try_to_lock);
-        if (!no_heavy_ops_meanwhile.owns_lock()) {
-            static const int tries = ab_knob("MANTA_CAPTURE_TRIES", CAPTURE_TRIES);
-            if (++w->capture_tries < tries) return false;
-            no_heavy_ops_meanwhile.lock();
-        }
-        w->capture_tries = 0;
-        bool invalidated = false;
-        const bool ok = build_graphs_locked(w, invalidated);
-        if (!ok) {
-            if (invalidated) {
-                // streams that joined an invalidated capture are not trusted again: the slot is destroyed after this pass, its
-                // streams and its workspaces' streams abandoned (~ProveWs)
-                w->poisoned = true;
-            } else {
-                // a deterministic failure (instantiation error, out of memory): destroying the slot would only repeat two eager
-                // passes, every hipMalloc and the failure on each call -- this kind of slot stays eager, here and in later slots
-                std::lock_guard<std::mutex> g(mu_);
-                no_graph_keys_.insert(slot_key(w->k, w->z3, w->flavour));
-            }
-        }
-        return ok;
-    }
-    bool build_graphs_locked(ProveWs *w, bool &invalidated) {
-        if (w->linear3) {
-            const MsmArgs a = msm_args(w);
-            w->mw[4]->capturing = true; // linear captures: nothing inside them waits on a `done` event
-            bool ok = capture_segment(w->stream, &w->g_all, [&] {
-                const int rc = enqueue_witness_map_body(w);
-                return rc ? rc : enqueue_msm(w, a, 4, false);
-            });
-            w->mw[4]->capturing = false;
-            if (ok) {
-                w->mw[0]->capturing = true;
-                ok = capture_segment(msm_stream(w, 0), &w->g_msm[0], [&] { return enqueue_msm(w, a, 0, false); });
-                w->mw[0]->capturing = false;
-            }
-            if (ok) {
-                w->mw[2]->capturing = true;
-                ok = capture_segment(msm_stream(w, 2), &w->g_g2, [&] { return enqueue_part_b(w, false); });
-                w->mw[2]->capturing = false;
-            }
-            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
-            if (!ok) {
-                invalidated = capture_invalidated(); // (of the segment that failed: the chain stops at the first failure)
-                w->drop_graphs();
-                w->no_graph = true;
-            }
-            w->graphs_ready = ok;
-            return ok;
-        }
-        if (graph_mode_for(w->k) == GRAPH_SINGLE) {
-            // (Round 4, measured and withdrawn: the combined MSM of a z3 slot captured as a LINEAR graph of its own and replayed next to
-            // the G2 one started with the upload instead of 210-290 us into the proof and was worth 2-3 % of a sequential proof -- but
-            // with other contexts' passes in flight on the GPU the proof's C element came out WRONG, on a pooled high-priority
-            // stream as on the workspace's own (test_rccl_branch_with_a_one_rank_group caught it; the branch form below is right under
-            // the same load). Three graphs per proof are not worth an unexplained dependency on the runtime's graph executor.)
-            bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_part_a(w, false); });
-            if (ok1) {
-                w->mw[2]->capturing = true; // a linear capture: nothing waits on its `done` event
-                ok1 = capture_segment(msm_stream(w, 2), &w->g_g2, [&] { return enqueue_part_b(w, false); });
-                w->mw[2]->capturing = false;
-            }
-            for (int i = 0; i < 5; ++i) w->mw[i]->pending = 0;
-            if (!ok1) {
-                invalidated = capture_invalidated();
-                w->drop_graphs();
-                w->no_graph = true;
-            }
-            w->graphs_ready = ok1;
-            return ok1;
-        }
-        bool ok = capture_segment(w->stream, &w->g_wm, [&] { return enqueue_witness_map_body(w); });
-        const MsmArgs a = msm_args(w);
-        for (int i = 0; ok && i < 5; ++i) {
-            if (!runs(w, i)) continue;
-            w->mw[i]->capturing = true; // no event records inside the capture: the replay path records `done`
-            ok = capture_segment(msm_stream(w, i), &w->g_msm[i], [&] {
-                return w->me[i]->msm_launch(a.bs[i], a.sc[i], a.cnt[i], i == 4 ? SCALARS_WORK : SCALARS_MONT, 0, w->mw[i], w->k, a.stride[i], i != 4);
-            });
-            w->mw[i]->capturing = false;
-            w->mw[i]->pending = 0;
-        }
-        if (!ok) {
-            invalidated = capture_invalidated();
-            w->drop_graphs();
-            w->no_graph = true;
-        }
-        w->graphs_ready = ok;
-        return ok;
-    }
-
+    ProverImpl *peer(size_t g) const { return static_cast<ProverImpl *>(peers_[g]); }
     // ---- one proof. Concurrent callers on one context are COALESCED: while COALESCE_INFLIGHT passes are on the GPU, further
     // calls queue up, and the next caller to find a pass slot free takes everything queued (up to BATCH_CHUNK) as ONE batched
     // pass -- the wallet / ledger simulation of the reference drives one ProvingContext from six threads
@@ -1378,14 +257,14 @@ class ProverImpl : public Prover {
         // shared against set_r1cs on every shard for the length of the pass
         std::vector<std::shared_lock<std::shared_mutex>> locks;
         locks.emplace_back(shape_mu_);
-        for (ProverImpl *q : peers_) locks.emplace_back(q->shape_mu_);
+        for (ProverKey *q : peers_) locks.emplace_back(q->shape_mu_);
         if (!have_r1cs_) return MG_ERR_STATE;
         if (ex_) return prove_pass_rccl((u32)k64, z, r, s, proofs_out, z_list); // the partial points meet through RCCL
         // every shard gets the whole assignment (1.1 MB for PrivateTransfer) and recomputes the witness map -- cheaper
         // than broadcasting h -- then multiplies its slices; shard 0 launches last and assembles
         std::vector<Pass> pp(peers_.size());
         int rc = MG_OK;
-        for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peers_[g]->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
+        for (size_t g = 0; g < peers_.size() && !rc; ++g) rc = peer(g)->launch_pass(pp[g], (u32)k64, z, r, s, nullptr);
         Pass p;
         const auto t_enq = std::chrono::steady_clock::now();
         if (!rc) rc = launch_pass(p, (u32)k64, z, r, s, proofs_out, z_list, true, company);
@@ -1563,131 +442,6 @@ class ProverImpl : public Prover {
         p.w = nullptr;
     }
 
-    // The host side of a pass is ~0.15 ms per proof (two 254-bit scalar multiplications in one doubling chain, four table
-    // multiplications, three serialisations with a field inversion each): nothing next to a single proof, but 5 ms of a
-    // 32-proof pass whose GPU side is 8.6 ms. Batches spread it over up to four library threads.
-    // (exception-safe: a worker that throws -- bad_alloc -- is caught in its own thread, every thread is joined, and the
-    // failure is rethrown on the calling thread, where the C ABI turns it into a status code; a thread that cannot be
-    // started just leaves its share to the caller)
-    struct JoinAll {
-        std::vector<std::thread> &th;
-        ~JoinAll() {
-            for (auto &t : th)
-                if (t.joinable()) t.join();
-        }
-    };
-    template <class Fn> static void for_each_proof(u32 k, Fn &&fn) {
-        const u32 nt = k >= 4 ? 4u : k; // (a thread start is ~30 us against ~150 us of work per proof)
-        if (nt == 1) {
-            for (u32 q = 0; q < k; ++q) fn(q);
-            return;
-        }
-        std::atomic<bool> failed{false};
-        std::atomic<u32> next{0}; // proofs are handed out one at a time: threads that never started cost nothing
-        auto body = [&]() noexcept {
-            try {
-                for (u32 q; (q = next.fetch_add(1)) < k;) fn(q);
-            } catch (...) {
-                failed.store(true);
-            }
-        };
-        {
-            std::vector<std::thread> th;
-            JoinAll guard{th};
-            try {
-                for (u32 t = 1; t < nt; ++t) th.emplace_back(body);
-            } catch (...) { // std::system_error: fewer helpers
-            }
-            body();
-        }
-        if (failed.load()) throw std::runtime_error("prove: host assembly failed");
-    }
-
-    // ---- the host side of a pass, shared by the single-process paths (finish_pass) and the process-per-GPU one (assemble)
-    struct Blind {
-        u64 rc4[4], sc4[4], rs4[4];
-        HostPoint t_rd, t_sd, t_rsd, t_sd2;
-    };
-    // r*delta_g1, s*delta_g1, (r s)*delta_g1, s*delta_g2: fixed-base (64 table additions each)
-    void compute_blinds(u32 k, const uint64_t *r, const uint64_t *s, Blind *bl) const {
-        for_each_proof(k, [&](u32 q) {
-            Blind &b = bl[q];
-            u64 rs_m[4];
-            fr_->fr_to_canonical(r + 4 * q, b.rc4);
-            fr_->fr_to_canonical(s + 4 * q, b.sc4);
-            fr_->fr_mul(r + 4 * q, s + 4 * q, rs_m);
-            fr_->fr_to_canonical(rs_m, b.rs4);
-            g1_->hp_table_mul(delta1_tab_, b.rc4, &b.t_rd);
-            g1_->hp_table_mul(delta1_tab_, b.sc4, &b.t_sd);
-            g1_->hp_table_mul(delta1_tab_, b.rs4, &b.t_rsd);
-            g2_->hp_table_mul(delta2_tab_, b.sc4, &b.t_sd2);
-        });
-    }
-    // res[i * k + q] = MSM i (a, b_g1, b_g2, l, h) of proof q; writes A and C of every proof
-    // `pre` (single proofs on a z3 slot): g_a and s g_a + r g1_b - rs delta were computed by assemble_g1_early while the h chain ran
-    struct EarlyG1 {
-        HostPoint g_a, g_c;
-    };
-    void assemble_g1_early(const HostPoint *res /* k = 1 */, Blind &b, const uint64_t *rq, EarlyG1 *e, uint8_t *out) const {
-        const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0;
-        e->g_a = res[0];
-        g1_->hp_add(&e->g_a, &a0_alpha_);
-        g1_->hp_add(&e->g_a, &b.t_rd);
-        HostPoint g1_b;
-        g1_->hp_set_inf(&g1_b);
-        if (!r_zero) {
-            g1_b = res[1];
-            g1_->hp_add(&g1_b, &b10_beta_);
-            g1_->hp_add(&g1_b, &b.t_sd);
-        }
-        g1_->hp_mul2(&e->g_a, b.sc4, &g1_b, b.rc4, &e->g_c);
-        g1_->hp_neg(&b.t_rsd);
-        g1_->hp_add(&e->g_c, &b.t_rsd);
-        g1_->hp_add(&e->g_c, &res[3]);
-        g1_->hp_serialize(&e->g_a, out, true); // A is final (its inversion too runs beside the h chain)
-    }
-    void assemble_g1_late(const HostPoint *res /* k = 1 */, EarlyG1 *e, uint8_t *out) const {
-        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
-        g1_->hp_add(&e->g_c, &res[4]);
-        g1_->hp_serialize(&e->g_c, out + b1 + b2, true);
-    }
-    void assemble_g1(u32 k, const HostPoint *res, Blind *bl, const uint64_t *r, uint8_t *proofs_out) const {
-        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
-        for_each_proof(k, [&](u32 q) {
-            Blind &b = bl[q];
-            const uint64_t *rq = r + 4 * q;
-            const bool r_zero = (rq[0] | rq[1] | rq[2] | rq[3]) == 0; // g1_b is not used iff r == 0 (App. B.1)
-            HostPoint g_a = res[0 * (size_t)k + q];
-            g1_->hp_add(&g_a, &a0_alpha_);
-            g1_->hp_add(&g_a, &b.t_rd);
-            HostPoint g1_b;
-            g1_->hp_set_inf(&g1_b);
-            if (!r_zero) {
-                g1_b = res[1 * (size_t)k + q];
-                g1_->hp_add(&g1_b, &b10_beta_);
-                g1_->hp_add(&g1_b, &b.t_sd);
-            }
-            HostPoint g_c;
-            g1_->hp_mul2(&g_a, b.sc4, &g1_b, b.rc4, &g_c); // s*g_a + r*g1_b, one doubling chain
-            g1_->hp_neg(&b.t_rsd);
-            g1_->hp_add(&g_c, &b.t_rsd);
-            g1_->hp_add(&g_c, &res[3 * (size_t)k + q]);
-            g1_->hp_add(&g_c, &res[4 * (size_t)k + q]);
-            uint8_t *out = proofs_out + (size_t)q * (2 * b1 + b2);
-            g1_->hp_serialize(&g_a, out, true);
-            g1_->hp_serialize(&g_c, out + b1 + b2, true);
-        });
-    }
-    void assemble_g2(u32 k, const HostPoint *res, const Blind *bl, uint8_t *proofs_out) const {
-        const int b1 = g1_->point_bytes(true), b2 = g2_->point_bytes(true);
-        for_each_proof(k, [&](u32 q) {
-            HostPoint g2_b = res[2 * (size_t)k + q];
-            g2_->hp_add(&g2_b, &b20_beta_);
-            g2_->hp_add(&g2_b, &bl[q].t_sd2);
-            g2_->hp_serialize(&g2_b, proofs_out + (size_t)q * (2 * b1 + b2) + b1, true);
-        });
-    }
-
     // ---- process-per-GPU sharding (manta_rs_amd/distributed.py ShardedProver): this context is
     // shard g of G in its own process. partials_launch runs the pass on this shard's slices and leaves the five partial MSM
     // results of every proof on the DEVICE, folded there (msm_fold_device), as arkworks-format XYZZ points in slots of
@@ -1824,7 +578,7 @@ class ProverImpl : public Prover {
         Exchange *x = new Exchange();
         x->api = api;
         x->shard.push_back(this);
-        x->shard.insert(x->shard.end(), peers_.begin(), peers_.end());
+        for (size_t g = 0; g < peers_.size(); ++g) x->shard.push_back(peer(g));
         const int G = (int)x->shard.size();
         std::vector<int> devs(G);
         for (int g = 0; g < G; ++g) devs[g] = x->shard[g]->dev_;
@@ -1838,6 +592,7 @@ class ProverImpl : public Prover {
         x->comm.assign(G, nullptr);
         x->words = (size_t)BATCH_CHUNK * 5 * slot_words();
         ex_ = x;
+        has_exchange_ = true;
         if (!nccl_ok(api->CommInitAll(x->comm.data(), G, devs.data()), "ncclCommInitAll")) {
             x->comm.clear();
             exchange_destroy();
@@ -1852,6 +607,7 @@ class ProverImpl : public Prover {
             if (c) ex_->api->CommDestroy(c);
         delete ex_;
         ex_ = nullptr;
+        has_exchange_ = false;
     }
     void ex_free(ExSet *e) {
         for (size_t g = 0; g < e->st.size(); ++g) {
@@ -2015,7 +771,7 @@ class ProverImpl : public Prover {
         ProveWs *w = p.w;
         if (!w || rc) {
             if (peer_passes)
-                for (size_t g = 0; g < peers_.size(); ++g) peers_[g]->abandon_pass((*peer_passes)[g]);
+                for (size_t g = 0; g < peers_.size(); ++g) peer(g)->abandon_pass((*peer_passes)[g]);
             if (w) abandon_pass(p);
             return rc ? rc : MG_ERR_HIP;
         }
@@ -2024,7 +780,7 @@ class ProverImpl : public Prover {
         } catch (...) { // bad_alloc in the host assembly: drain and return every slot of the pass, then report upwards
             abandon_pass(p);
             if (peer_passes)
-                for (size_t g = 0; g < peers_.size(); ++g) peers_[g]->abandon_pass((*peer_passes)[g]);
+                for (size_t g = 0; g < peers_.size(); ++g) peer(g)->abandon_pass((*peer_passes)[g]);
             throw;
         }
     }
@@ -2044,7 +800,7 @@ class ProverImpl : public Prover {
             if (peer_passes && !peers_.empty()) { // the exchange step of the sharded path: partial points are summed here
                 tmp.resize((size_t)5 * k);
                 for (size_t g = 0; g < peers_.size(); ++g) {
-                    rc2 = peers_[g]->collect_part((*peer_passes)[g], part_a, tmp.data());
+                    rc2 = peer(g)->collect_part((*peer_passes)[g], part_a, tmp.data());
                     if (!rc) rc = rc2;
                     for (int i = 0; i < 5 && !rc2; ++i) {
                         if (in_part_a(i) != part_a) continue;
@@ -2125,7 +881,7 @@ class ProverImpl : public Prover {
         if (peer_passes)
             for (size_t g = 0; g < peers_.size(); ++g) {
                 Pass &pg = (*peer_passes)[g];
-                if (pg.w) peers_[g]->ws_release(pg.w);
+                if (pg.w) peer(g)->ws_release(pg.w);
                 pg.w = nullptr;
             }
         if (rc) return rc;
