@@ -304,15 +304,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             p.Wb = p.W;
         }
         p.B = 1u << (p.c - 1);
-        // entries per lane. Large MSMs: the grid is a whole number of rounds of 2 wavefronts per SIMD (256 CUs x
-        // 4 SIMDs x 2 x 64 = 131 072 lanes) -- the accumulate kernel holds two waves per SIMD, so 1.5 rounds leave
-        // half the SIMDs idle for a third of the kernel (measured at 2^20, stand-alone kernel: L = 128 -> 2.94 ms,
-        // L = 170 (1536 waves) -> 3.71 ms, L = 192 -> 4.14 ms; 328 / 322 / 327 Mscalar/s pipelined, 248 / 212 / 194
-        // one MSM at a time). Longer chunks mean fewer partials for the merge levels, hence as few rounds as keep
-        // L <= 192. Proof-sized MSMs are latency chains -- L mixed additions, then the merge levels -- and shorter
-        // chunks shorten the chain (PrivateTransfer: L = 4 / 6 / 8 / 11 / 16 -> 581 / 610 / 595 / 573 / 564
-        // proofs/s), so they get twice the lanes, never fewer than 6 entries each. Batched proofs: most digit
-        // entries are invalid (sorted last), so the lanes are kept plentiful (L <= 96).
+        // entries per lane. Large MSMs: the grid is a whole number of rounds of 2 wavefronts per SIMD (256 CUs x 4 SIMDs x 2 x 64 =
+        // 131 072 lanes) -- the accumulate kernel holds two waves per SIMD, so 1.5 rounds leave half the SIMDs idle for a third of
+        // the kernel; longer chunks mean fewer partials for the merge levels, hence as few rounds as keep L <= 192. Proof-sized
+        // MSMs are latency chains (L mixed additions, then the merge levels): shorter chunks, twice the lanes, never fewer than 6
+        // entries each. Batched proofs: most digit entries are invalid (sorted last), so the lanes are kept plentiful (L <= 96).
+        // (sweeps: profiles/history/code_comment_measurements.md "chunk length")
         const size_t M = n * (size_t)p.W * batch;
         size_t L;
         if (M < ((size_t)8 << 20)) {
@@ -389,8 +386,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     }
     // entries folded serially per lane in the first merge level. Large MSMs: 4 (throughput). Proof-sized MSMs: 16 --
     // the level then has few enough logical waves (<= coop_waves()) for the cooperative kernel, whose additions
-    // cost a third: 15 cooperative serial steps + the scan beat 3 plain steps + the scan and shrink the next level
-    // (PrivateTransfer: G = 4 / 8 / 16 / 32 -> 865 / 927 / 955 / 832 proofs/s).
+    // cost a third: 15 cooperative serial steps + the scan beat 3 plain steps + the scan and shrink the next level.
     static u32 merge_g1(size_t M) {
         static const u32 g = [] {
             const int v = ab_knob("MANTA_MERGE_G", 0);
@@ -647,14 +643,11 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         hipStream_t side = nullptr; // plain sums of the front levels run beside the weighted chain (stand-alone MSMs)
         {
             const RedKnobs &rk = red_knobs();
-            // (never for the MSMs of a proof slot -- ws->in_graph_slot: their launches are captured into hipGraphs, and a pass captured
-            // with the front levels in it made hipGraphLaunch segfault on ROCm 7.0, the multi-branch-graph defect described in
-            // runtime.cpp; eagerly launched, the batched prover gains 2-3 % from them: profiles/r03_batched_front_levels.txt)
-            // On by default (MANTA_RED_S unset = 8 buckets per lane, 16 from 2^16 buckets on) wherever a window segment has >= min_items buckets: same box, three runs each,
-            // 2^20 BLS12-381 G1, c = 16 tables -- scan kernels only 364-367 Mscalar/s three in flight / 3.62-3.66 ms one at a time,
-            // with one front level 364-376 / 3.42-3.51; plain bases (16 windows x 32 768 buckets) 4.98 -> 4.36 ms
-            // (profiles/r03_front_levels_ab.txt). The plain sums ride on ONE high-priority side stream per engine: a side stream per
-            // workspace aliased the runtime's four normal-priority hardware queues and cost the pipelined rate 10-15 % by itself.
+            // Work-efficient front levels: on (8 buckets per lane, 16 from 2^16 buckets on) wherever a window segment has >= min_items
+            // buckets (profiles/r03_front_levels_ab.txt). Not for the MSMs of a proof slot (ws->in_graph_slot): a policy since round 6
+            // -- inside captured passes they are right (the crash was the side stream, below) and gain nothing
+            // (profiles/r06_front_levels_in_graph.txt). The plain sums of stand-alone MSMs ride on ONE high-priority side stream per
+            // engine (a side stream per workspace aliased the runtime's shared hardware queues).
             const int lgS_eff = rk.lgS >= 0 ? rk.lgS : 3;
             // (MANTA_FRONT_IN_GRAPH, diagnosis builds only: the front levels inside a proof slot's captures -- DESIGN section 6)
             static const bool front_in_graph = ab_knob("MANTA_FRONT_IN_GRAPH", 0) != 0;
@@ -668,9 +661,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                 hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
                 const bool being_captured = hipStreamIsCapturing(s, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone;
                 if (!ws->capturing && !ws->run_on && !ws->in_graph_slot && !being_captured && rk.side) {
-                    // ONE side stream per engine, high priority (= the runtime's other pool of hardware queues): a stream per
-                    // workspace put six streams on the four normal-priority queues and cost the pipelined rate 15 % through
-                    // aliasing alone, whether or not the side stream was used (measured: 308 against 365 Mscalar/s)
+                    // ONE side stream per engine, high priority (= the runtime's other pool of hardware queues)
                     if (!(side = engine_side_stream())) return MG_ERR_HIP;
                     if (!ws->side_fork) {
                         MG_HIP(hipEventCreateWithFlags(&ws->side_fork, hipEventDisableTiming));
@@ -700,10 +691,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                     u32 stride = pl.B, off = 0, n = pl.B, shift = 0, ne = 0;
                     while (n >= rk.min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
                         // the big first levels are throughput-bound: short stretches = enough lanes for two wavefronts per SIMD;
-                        // below that a level is a latency chain either way and longer stretches save a level
-                        // (2^16 buckets -- c = 17 tables --: 16 per lane leaves the scan kernels the 4 096 items they take at c = 16;
-                        // 8 per lane left 8 192 and a non-cooperative tile kernel of 0.36 ms: 3.65-3.79 ms one MSM at a time against
-                        // 3.44-3.50, 362-365 Mscalar/s three in flight against 371; 32: 357-368)
+                        // below that a level is a latency chain either way and longer stretches save a level (2^16 buckets: 16 per lane
+                        // leaves the scan kernels the 4 096 items they take at c = 16)
                         const int lg = (size_t)segs * n >= ((size_t)1 << 18) ? rk.lgS0 : (rk.lgS < 0 && n >= (1u << 16) ? 4 : lgS_eff);
                         const u32 lanes = cdiv(n, 1u << lg);
                         u32 *A = take((size_t)segs * lanes), *Sx = take((size_t)segs * lanes);

@@ -80,9 +80,8 @@ class ProverImpl : public ProverSlots {
     // ---- one proof. Concurrent callers on one context are COALESCED: while COALESCE_INFLIGHT passes are on the GPU, further
     // calls queue up, and the next caller to find a pass slot free takes everything queued (up to BATCH_CHUNK) as ONE batched
     // pass -- the wallet / ledger simulation of the reference drives one ProvingContext from six threads
-    // (manta-pay/src/bin/simulation.rs:36-38, simulation/mod.rs:75-79), each proving one transfer at a time; measured on
-    // MI355X, PrivateTransfer shape, single calls from 1 / 2 / 3 / 4 / 6 threads without coalescing: 964 / 1 254 / 1 130 /
-    // 1 108 / 1 068 proofs/s (the passes only share the GPU's queues), against ~3 900 for explicit batches. A lone caller
+    // (manta-pay/src/bin/simulation.rs:36-38, simulation/mod.rs:75-79), each proving one transfer at a time; without coalescing
+    // their passes only share the GPU's queues (a quarter of the rate of explicit batches). A lone caller
     // is never delayed (it leads a pass of one at once); batch sizes are rounded up to a power of two by repeating the first
     // request (slots and captured graphs exist per batch size), the surplus proofs are dropped. Proof bytes do not depend
     // on how calls were grouped. Sharded contexts and MANTA_COALESCE=0 take the direct path.
@@ -187,17 +186,14 @@ class ProverImpl : public ProverSlots {
     // kernels are the same; every (assignment, window) pair is its own bucket segment and the NTT / SpMV grids get a
     // batch dimension, so a pass costs one chain of latency-bound launches instead of k. A longer batch is streamed
     // through as passes of BATCH_CHUNK with BATCH_INFLIGHT of them in flight on their own slots (library threads): the
-    // witness-map head and the bucket-reduce tail of one pass then overlap the accumulate kernels of the others --
-    // measured on MI355X for the PrivateTransfer shape, passes of 32: 2 280 proofs/s with one pass in flight, 3 350 with
-    // two, 3 820 with three, 3 680 with four; passes of 16 or 64 are no better. (Splitting ONE pass of 32 into two
-    // halves in flight was measured too and gains nothing: the smaller passes lose what the overlap wins.)
+    // witness-map head and the bucket-reduce tail of one pass then overlap the accumulate kernels of the others (three in flight
+    // is the measured optimum; passes of 16 or 64 are no better).
     static constexpr u64 BATCH_CHUNK = 32;
     int prove_batch(u64 k64, const uint64_t *z, const uint64_t *r, const uint64_t *s, uint8_t *proofs_out) override {
         if (k64 == 0 || k64 > 1024 || !z || !r || !s || !proofs_out) return MG_ERR_ARG;
         if (task_mask_ != 0x1f || lone_range_shard()) return MG_ERR_STATE;
         if (k64 <= BATCH_CHUNK) return prove_pass(k64, z, r, s, proofs_out);
-        // (passes of exactly BATCH_CHUNK proofs plus one remainder: equalising the pass sizes -- 256 proofs as 9 x 29 instead
-        // of 8 x 32 -- was measured and is slower: every distinct pass size needs its own workspaces and captured graphs)
+        // (passes of exactly BATCH_CHUNK proofs plus one remainder: every distinct pass size needs its own workspaces and graphs)
         const u64 fl = (u64)batch_inflight(), per = BATCH_CHUNK;
         const u64 chunks = (k64 + per - 1) / per;
         const size_t pbytes = 2 * (size_t)g1_->point_bytes(true) + (size_t)g2_->point_bytes(true); // compressed A, B, C
@@ -234,8 +230,7 @@ class ProverImpl : public ProverSlots {
         }
         return first_rc.load();
     }
-    // two callers streaming a batch each would otherwise put six passes in flight, which is slower than three (measured:
-    // 2 x 256 proofs 3 465 proofs/s against 3 650-3 840 for one caller)
+    // two callers streaming a batch each would otherwise put six passes in flight, which is slower than three
     std::mutex gate_mu_;
     std::condition_variable gate_cv_;
     int gate_busy_ = 0;

@@ -129,9 +129,8 @@ class ProverKey : public Prover {
     // buckets to fold and no doubling chain -- tuned on MI355X)
     int pre_c_for(u64 n) const {
         if (tn_.window_bits_narrow > 0) return tn_.window_bits_narrow; // tuning override: ONE width for every bucket table of the key
-        // Measured on MI355X for the PrivateTransfer shape (n = 35k / 65k): c = 6..8 -> 2.0 ms per proof,
-        // c = 9..13 -> 2.5-2.7 ms, c = 14 -> 3.0 ms. Few buckets keep the latency-bound bucket reduce short
-        // (B = 128: two tiles); the extra windows only add perfectly parallel mixed additions.
+        // proof-sized queries: few buckets keep the latency-bound bucket reduce short (B = 128: two tiles); the extra windows only
+        // add perfectly parallel mixed additions
         if (n <= (1u << 17)) return 8;
         if (n <= (1u << 19)) return 12;
         return 17; // 255 = 15 x 17, 254 < 15 x 17: fifteen windows on both curves (digits_kernel negates scalars above r / 2)
@@ -319,8 +318,8 @@ class ProverKey : public Prover {
         if ((rc = try_full(g1_, b1q, zn, f_z1b, &b1_bs_full_))) return rc;
         if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
         }
-        if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions (c = 10: +7 % measured over c = 8)
-            int cw = 11; // (with three passes in flight: 10 / 11 / 12 -> 3 405-3 606 / 3 688-3 729 / 3 517-3 548 proofs/s, two runs each)
+        if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions
+            int cw = 11;
             if (tn_.window_bits_wide) cw = tn_.window_bits_wide; // tuning override
             if ((rc = g1_->bases_create(aq, zn, false, cw, &a_bs_wide_, true))) return rc;
             if ((rc = g1_->bases_create(b1q, zn, false, cw, &b1_bs_wide_, true))) return rc;
@@ -433,9 +432,7 @@ class ProverKey : public Prover {
                 if (src < h_len_) std::memcpy(&perm[(p - lo) * w1], &h_query_host_[src * w1], w1 * 4);
             }
             // The h MSM is the one with dense, uniform scalars -- half of all the mixed additions of a proof at
-            // c = 8. Wider windows halve them, but lengthen its bucket reduce: measured on PrivateTransfer,
-            // c_h = 8/10/12/14/16 -> 2033 / 2202 / 2219 / 2363 / 2287 proofs/s batched (k = 32); for single proofs the
-            // reduce chain matters more (with the cooperative reduce: c_h = 8/10/12 -> 839 / 859 / 862 proofs/s).
+            // c = 8. Wider windows halve them, but lengthen its bucket reduce; for single proofs the reduce chain matters more.
             // The tables are small (80 MB), so single proofs and batches each get their own width.
             int ch = pre_c_for(D), ch_wide = ch;
             if (lg >= 16 && lg <= 17) ch = 12; // dense 2^16 scalars: a third fewer mixed additions, 32 reduce tiles (+3 %)

@@ -14,10 +14,8 @@ class ProverSlots : public ProverAssembly {
     // pass (company 2), the G2 MSM beside single proofs only (company 1: two host threads). The streams come from
     // stream_set_acquire (runtime.cpp): three DIFFERENT hardware queues per slot, and the two slots that two host threads keep in
     // flight share none -- before, which chains of the two proofs met on one queue was decided by the order in which the process
-    // had created its streams, and two threads ran at 976 or 1 364 proofs/s from process to process (profiles/r05_hw_queues.txt).
-    // A normal-priority chain costs a lone proof 18 %: flavour 1 keeps all three high. Which chain yields beside others is measured:
-    // two threads 1 412-1 435 proofs/s with the combined MSM normal, 1 511-1 531 with the G2 MSM normal; six threads (singles beside
-    // coalesced passes) 1 794-1 898 against 1 624-1 700.
+    // had created its streams (profiles/r05_hw_queues.txt). A normal-priority chain costs a lone proof 18 %: flavour 1 keeps all
+    // three high; which chain yields beside others was measured per company (same file, item 7).
     // MANTA_Z3_LINEAR: 0 never linear, 1 lone proofs only (round 5's first version), 2 no flavour 3, 3 (default) all of the above.
     int lin_flavour(u32 k, bool z3, int company) const {
         const int z3_linear = tn_.linear_chains;
@@ -279,8 +277,7 @@ class ProverSlots : public ProverAssembly {
             const int v = ab_knob("MANTA_FULL_MAX_K", 1);
             return (u32)(v >= 0 ? v : 1);
         }();
-        // (passes of one proof only: on full tables passes of 2-8 proofs are SLOWER than on the narrow bucket tables -- 2.65 against 1.9 ms
-        // for two, six signer threads 1 300 against 1 650 proofs/s -- measured with MANTA_FULL_MAX_K = 4 / 8, round 4)
+        // (passes of one proof only: on full tables passes of 2-8 proofs are slower than on the narrow bucket tables)
         return z3_bs_full_ && k == 1 && full_max_k >= 1 && peers_.empty() && !has_exchange_;
     }
     static hipStream_t msm_stream(const ProveWs *w, int i) { return w->mw[i]->run_on ? w->mw[i]->run_on : w->mw[i]->stream; }
@@ -317,9 +314,6 @@ class ProverSlots : public ProverAssembly {
         for (int i = 0; i < 5; ++i) {
             if (!in_part_a(i) || !runs(w, i)) continue;
             hipStream_t ms = msm_stream(w, i);
-            // (round 5, measured and dropped: for LARGE proofs -- 2^20 variables -- the a / b_g1 / l MSMs launched BEHIND the witness
-            // map instead of beside it: the witness map falls from 5.9 to 3.8 ms and each of the three MSMs from 4-7 to 2-3 ms, but the
-            // proof goes from 10.5 to 11.0 ms -- the chip is busy either way: profiles/r05_config2_ab.txt)
             if (ms != w->stream) MG_HIP(hipStreamWaitEvent(ms, i == 4 ? w->h_ready : w->fork, 0));
             if ((rc = enqueue_msm(w, a, i, use_graphs))) return rc;
         }
@@ -368,7 +362,6 @@ class ProverSlots : public ProverAssembly {
         }
         if (w->g_all && w->g_g2) { // "single" mode replay
             // the G2 graph goes first: it is the longest chain and its launch is the cheaper of the two
-            // (measured: 1.47 ms per PrivateTransfer proof against 1.68 with the other order)
             if (g2s != w->stream) MG_HIP(hipStreamWaitEvent(g2s, w->z_ready, 0));
             MG_HIP(hipGraphLaunch(w->g_g2, g2s));
             MG_HIP(hipGraphLaunch(w->g_all, w->stream));
@@ -468,11 +461,8 @@ class ProverSlots : public ProverAssembly {
             return ok;
         }
         if (graph_mode_for(w->k) == GRAPH_SINGLE) {
-            // (Round 4, measured and withdrawn: the combined MSM of a z3 slot captured as a LINEAR graph of its own and replayed next to
-            // the G2 one started with the upload instead of 210-290 us into the proof and was worth 2-3 % of a sequential proof -- but
-            // with other contexts' passes in flight on the GPU the proof's C element came out WRONG, on a pooled high-priority
-            // stream as on the workspace's own (test_rccl_branch_with_a_one_rank_group caught it; the branch form below is right under
-            // the same load). Three graphs per proof are not worth an unexplained dependency on the runtime's graph executor.)
+            // (the forked form; single proofs of z3 slots take the three linear graphs above since the memset-node defect was found:
+            // profiles/r05_linear_graph_defect.txt)
             bool ok1 = capture_segment(w->stream, &w->g_all, [&] { return enqueue_part_a(w, false); });
             if (ok1) {
                 w->mw[2]->capturing = true; // a linear capture: nothing waits on its `done` event
