@@ -30,11 +30,12 @@ __global__ void queue_probe_set(unsigned *flag, unsigned token) { __atomic_store
 // memory (flag, result) owned by the caller; token_counter: the caller's running token. Must not run beside a stream capture (the
 // caller holds HeavyOp): it synchronises the two streams.
 int streams_share_queue(hipStream_t a, hipStream_t b, unsigned *mem, unsigned *token_counter) {
-    // a "shared" verdict must repeat, and with a LONGER bound each time (0.5, 2, 8 ms): a host stall between the two launches, or a
+    // a "shared" verdict must repeat twice, the last time with a LONGER bound (0.5, 0.5, 2 ms): a host stall between the two launches, or a
     // busy GPU on which B's one-thread kernel waits for a wave slot behind other ranks' / this process's own proofs, fakes one
     // (independent queues reported as shared collapse the classes for the life of the process)
     long long ticks = 50000LL; // 100 MHz: 0.5 ms
-    for (int attempt = 0; attempt < 3; ++attempt, ticks *= 4) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (attempt == 2) ticks *= 4; // (a true "shared" verdict costs 3 ms: ~50 ms for the first context of a device)
         const unsigned token = ++*token_counter;
         hipLaunchKernelGGL(queue_probe_wait, dim3(1), dim3(1), 0, a, mem, token, mem + 1, ticks);
         hipLaunchKernelGGL(queue_probe_set, dim3(1), dim3(1), 0, b, mem, token);
