@@ -7,14 +7,14 @@ for ln in open(sys.argv[1]):
     m = re.match(r"(.*?)\s+(\w+)\s+launches=(\d+)\s+sum=(\S+)\s+per_launch=(\S+)", ln)
     if not m:
         continue
-    k = re.sub(r"^void ", "", m.group(1)).replace("mg::", "")
+    k = re.sub(r"^void ", "", m.group(1)).replace("(anonymous namespace)::", "").replace("mg::", "")
     k = re.sub(r"\(.*", "", k)[:58]
     rows.setdefault(k, {})[m.group(2)] = (int(m.group(3)), float(m.group(5)))
 dur = {}
 for ln in open(sys.argv[2]):
     m = re.match(r"(\S.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", ln)
     if m:
-        k = re.sub(r"\(.*", "", m.group(1).replace("mg::", ""))[:58]
+        k = re.sub(r"\(.*", "", m.group(1).replace("(anonymous namespace)::", "").replace("mg::", ""))[:58]
         dur[k] = (int(m.group(2)), float(m.group(4)))
 cols = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
         "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "FETCH_SIZE", "WRITE_SIZE"]
