@@ -233,7 +233,7 @@ struct MsmWorkspace {
     hipEvent_t done = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr; // optional timing of the dominant (accumulate) kernel
     bool timed = false;
-    bool in_graph_slot = false; // owned by a proof slot whose launches are captured into hipGraphs (prover.cpp)
+    bool in_graph_slot = false; // owned by a proof slot (prover_passes.h): its launches never use the engine's side stream
     bool capturing = false; // msm_launch is being stream-captured: enqueue kernels and copies only, no event records
     // notify: after the staged result a 4-byte token is copied to *h_flag (pinned), so that a host that zeroed it before the
     // launch can see THIS chain end without a stream or event wait (a chain inside a captured multi-branch graph has neither)

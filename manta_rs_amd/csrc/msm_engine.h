@@ -644,14 +644,12 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
         {
             const RedKnobs &rk = red_knobs();
             // Work-efficient front levels: on (8 buckets per lane, 16 from 2^16 buckets on) wherever a window segment has >= min_items
-            // buckets (profiles/r03_front_levels_ab.txt). Not for the MSMs of a proof slot (ws->in_graph_slot): a policy since round 6
-            // -- inside captured passes they are right (the crash was the side stream, below) and gain nothing
-            // (profiles/r06_front_levels_in_graph.txt). The plain sums of stand-alone MSMs ride on ONE high-priority side stream per
-            // engine (a side stream per workspace aliased the runtime's shared hardware queues).
+            // buckets (profiles/r03_front_levels_ab.txt) -- since round 6 inside a proof slot's captured graphs too (the crash of
+            // rounds 3-5 was the side stream, below): nothing at manta-pay sizes, whose windows stay below the threshold, -2.4 % on
+            // the 2^20 proof of BASELINE configs[2] (profiles/r06_front_levels_in_graph.txt). The plain sums of STAND-ALONE MSMs ride
+            // on ONE high-priority side stream per engine (a side stream per workspace aliased the runtime's shared hardware queues).
             const int lgS_eff = rk.lgS >= 0 ? rk.lgS : 3;
-            // (MANTA_FRONT_IN_GRAPH, diagnosis builds only: the front levels inside a proof slot's captures -- DESIGN section 6)
-            static const bool front_in_graph = ab_knob("MANTA_FRONT_IN_GRAPH", 0) != 0;
-            if (lgS_eff > 0 && rn >= rk.min_items && (!ws->in_graph_slot || front_in_graph)) {
+            if (lgS_eff > 0 && rn >= rk.min_items) {
                 // The side stream is for STAND-ALONE launches only, and never for a stream that is being captured. Round 6 root cause
                 // (profiles/r06_front_levels_in_graph.txt): inside the forked capture of a proof slot the four G1 MSMs are four
                 // branches, and the ONE side stream of the engine was forked from and joined into each of them in turn -- the

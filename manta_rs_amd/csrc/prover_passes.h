@@ -70,7 +70,7 @@ class ProverSlots : public ProverAssembly {
                 delete w;
                 return nullptr;
             }
-            w->mw[i]->in_graph_slot = graph_mode_for(k) == GRAPH_SINGLE; // (multi-branch capture: no front levels)
+            w->mw[i]->in_graph_slot = true; // (a slot's launches are captured: the engine's side stream must never join them)
         }
         // z3 slots: the combined a | b_g1 | l MSM announces its end through a pinned flag (MsmWorkspace::notify), so that the host
         // can fold its three results into s A + r B1 -- the one long piece of host work of a proof, ~0.1 ms -- while the h chain is
@@ -87,7 +87,6 @@ class ProverSlots : public ProverAssembly {
             w->linear3 = true;
             w->mw[0]->run_on = w->side[1]; // the combined MSM: a high-priority pooled stream of its own
             w->mw[4]->run_on = w->stream;  // the h MSM follows the witness map on the main stream
-            for (int i = 0; i < 5; ++i) w->mw[i]->in_graph_slot = false; // (single-stream captures only: front levels allowed)
         } else
         if (prove_streams() == 3) {
             w->mw[0]->run_on = w->side[1];

@@ -287,13 +287,13 @@ def test_front_levels_inside_captured_passes(gpu, min_items):
     MANTA_RED_MIN=1024, deleted the knob and kept the restriction. Root cause (round 6, profiles/r06_front_levels_in_graph.txt): the
     engine's ONE side stream joined the forked capture from several branches, the runtime's per-stream lists of parallel capture
     streams became cyclic, and hipStreamEndCapture recursed until the stack was gone. The side stream no longer joins any capture;
-    with that, passes of 8 proofs whose MSMs run their front levels INSIDE the slot's graphs (diagnosis twin, MANTA_FRONT_IN_GRAPH=1)
+    with that the front levels run INSIDE the slot's graphs wherever a window is long enough, and passes of 8 proofs (diagnosis twin)
     are the oracle's -- eager, eager, capture, replay, replay -- for thresholds 128 / 1 024 (front levels in every MSM of the
     pass) and 16 384 (the default: none qualifies), in the forked topology and in the split one."""
     import subprocess
     import sys
     for extra in ({}, {"MANTA_GRAPH_BATCH": "split"}):
-        env = H.knob_env(dict({"MANTA_FRONT_IN_GRAPH": "1", "MANTA_RED_MIN": str(min_items)}, **extra), strip_prefix="MANTA_")
+        env = H.knob_env(dict({"MANTA_RED_MIN": str(min_items)}, **extra), strip_prefix="MANTA_")
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "diag_front_in_graph.py"), "8", "to_public"], env=env, capture_output=True,
                              text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1,5 +1,5 @@
 """dev tool (round 6): the work-efficient front levels of the bucket reduce INSIDE the captured graphs of a batched
-pass (MANTA_FRONT_IN_GRAPH=1, diagnosis twin) with the threshold lowered so that the pass's MSMs qualify (MANTA_RED_MIN): what fails?
+pass (diagnosis twin) with the threshold lowered so that the pass's MSMs qualify (MANTA_RED_MIN): what failed in rounds 3-5?
 Runs passes of K proofs -- eager, eager, capture, replay, replay -- and reports status, the library's error text and the first
 differing proof against the oracle.   python tools/diag_front_in_graph.py [K=32] [shape=private_transfer]"""
 import os, sys
