@@ -139,12 +139,21 @@ def soak(seconds=600.0, threads=6, recycle_every=4.0, pool=6, shapes=("to_privat
         sc = synth.msm_scalars(curve, n, "W", seed=910 + group)
         msm_sets.append((api.Bases(curve, group, pts, precompute_window_bits=pre), api.DeviceBuffer.from_numpy(sc), n, O.msm(curve, group, pts, sc, algo=1)))
 
+    if os.environ.get("SOAK_TOUCH_MSM"):  # diagnosis: ONE stand-alone MSM before the run (creates its stream), none during it
+        b0, d0, n0, w0 = msm_sets[0]
+        assert (api.VariableBaseMSM.launch(b0, d0, n0, sparse=True).finish() == w0).all()
+
     def msm_worker():
         while time.perf_counter() < deadline and not stop.is_set() and not os.environ.get("SOAK_NO_MSM"):
             for b, d, n, want in msm_sets:
                 try:
+                    t_a = time.perf_counter()
                     jobs = [api.VariableBaseMSM.launch(b, d, n, sparse=True) for _ in range(3)]
+                    t_b = time.perf_counter()
                     bad = sum(0 if (j.finish() == want).all() else 1 for j in jobs)
+                    with slock:
+                        stats["msm_launch_s"] = stats.get("msm_launch_s", 0.0) + (t_b - t_a)
+                        stats["msm_finish_s"] = stats.get("msm_finish_s", 0.0) + (time.perf_counter() - t_b)
                 except Exception as e:  # noqa: BLE001
                     with slock:
                         stats["errors"] += 1
