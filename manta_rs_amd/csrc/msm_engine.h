@@ -405,12 +405,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
     // not pay: the 2^19-bucket reduce is eight more dependent launches and a third sort pass.
     struct RedKnobs {
         int lgS0, lgS, lgSP;
-        u32 min_items;
+        u32 min_items;       // stand-alone MSMs and single proofs: a window segment takes front levels from this many buckets on
+        u32 min_items_batch; // passes of several scalar vectors (batched proofs): from this many on
         bool side;
     };
     static const RedKnobs &red_knobs() {
         static const RedKnobs k = [] {
-            RedKnobs r{2, -1, 3, 16384u, true}; // lgS = -1: automatic (below)
+            RedKnobs r{2, -1, 3, 16384u, 2048u, true}; // lgS = -1: automatic (below)
             auto env = [](const char *n, int lo, int hi, int dflt) {
                 const int v = ab_knob(n, dflt);
                 return v < lo ? lo : (v > hi ? hi : v);
@@ -418,7 +419,13 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             r.lgS0 = env("MANTA_RED_S0", 1, 8, r.lgS0);
             r.lgS = env("MANTA_RED_S", -1, 8, r.lgS);
             r.lgSP = env("MANTA_RED_SP", 1, 8, r.lgSP);
+            // Batched passes (round 6, with the front levels legal inside a slot's graphs): 12-bit windows for a / b_g1 / b_g2 / l
+            // (2 048 buckets per proof and MSM) and front levels from 2 048 buckets on -- the h MSM's 8 192 too -- against 11-bit
+            // windows and scan tiles only: +3.4 % (W) / +4.2 % (dense) proofs/s, profiles/r06_batched_windows_front_levels.txt.
+            // (an explicit MANTA_RED_MIN rules both thresholds unless MANTA_RED_MIN_BATCH says otherwise)
+            const bool explicit_min = ab_knob("MANTA_RED_MIN", -1) >= 0;
             r.min_items = (u32)env("MANTA_RED_MIN", 128, 1 << 30, (int)r.min_items);
+            r.min_items_batch = (u32)env("MANTA_RED_MIN_BATCH", 128, 1 << 30, explicit_min ? (int)r.min_items : (int)r.min_items_batch);
             r.side = env("MANTA_RED_SIDE", 0, 1, 1) != 0;
             return r;
         }();
@@ -443,6 +450,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                    MsmWorkspace *ws, u32 batch = 1, size_t scalar_stride_words = 0, bool sparse = false) override {
         if (!bs || !d_scalars || !ws || n == 0 || n > bs->n_orig || batch == 0 || batch > 65535) return MG_ERR_ARG;
         if (bs->curve != CURVE_ID || bs->group != GROUP) return MG_ERR_ARG;
+        const bool batched_pass = batch > 1; // several scalar vectors against the same bases (a pass of several proofs)
         const u32 nsets = bs->n_sets; // concatenated queries over one scalar vector: nsets results per vector
         if (nsets > 1 && n > bs->set_len) return MG_ERR_ARG;
         const size_t n_scalars = n;        // scalars supplied by the caller (indexed by original position)
@@ -649,7 +657,8 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
             // the 2^20 proof of BASELINE configs[2] (profiles/r06_front_levels_in_graph.txt). The plain sums of STAND-ALONE MSMs ride
             // on ONE high-priority side stream per engine (a side stream per workspace aliased the runtime's shared hardware queues).
             const int lgS_eff = rk.lgS >= 0 ? rk.lgS : 3;
-            if (lgS_eff > 0 && rn >= rk.min_items) {
+            const u32 min_items = batched_pass ? rk.min_items_batch : rk.min_items;
+            if (lgS_eff > 0 && rn >= min_items) {
                 // The side stream is for STAND-ALONE launches only, and never for a stream that is being captured. Round 6 root cause
                 // (profiles/r06_front_levels_in_graph.txt): inside the forked capture of a proof slot the four G1 MSMs are four
                 // branches, and the ONE side stream of the engine was forked from and joined into each of them in turn -- the
@@ -687,7 +696,7 @@ template <class Curve, int CURVE_ID, int GROUP> class GroupEngineT : public Grou
                     };
                     const u32 *in = ws->buckets.as<u32>();
                     u32 stride = pl.B, off = 0, n = pl.B, shift = 0, ne = 0;
-                    while (n >= rk.min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
+                    while (n >= min_items && ne < (u32)MsmWorkspace::MAX_EXTRA) {
                         // the big first levels are throughput-bound: short stretches = enough lanes for two wavefronts per SIMD;
                         // below that a level is a latency chain either way and longer stretches save a level (2^16 buckets: 16 per lane
                         // leaves the scan kernels the 4 096 items they take at c = 16)
