@@ -319,7 +319,9 @@ class ProverKey : public Prover {
         if ((rc = try_full(g1_, lq, ln, f_l, &l_bs_full_))) return rc;
         }
         if (small) { // batched passes are throughput-bound: wider windows = fewer mixed additions
-            int cw = 12; // (11 until round 6: the wider windows pay since the front levels of the bucket reduce run inside the graphs)
+            // (11 everywhere until round 6: from 2^15 scalars on -- PrivateTransfer -- the wider windows pay since the front levels of
+            // the bucket reduce run inside the graphs; the smaller shapes keep 11: profiles/r06_batched_windows_front_levels.txt)
+            int cw = zn >= (1u << 15) ? 12 : 11;
             if (tn_.window_bits_wide) cw = tn_.window_bits_wide; // tuning override
             if ((rc = g1_->bases_create(aq, zn, false, cw, &a_bs_wide_, true))) return rc;
             if ((rc = g1_->bases_create(b1q, zn, false, cw, &b1_bs_wide_, true))) return rc;

@@ -27,7 +27,7 @@ struct Tuning { // field for field `mg_tuning`
     int32_t queue_aware;          // 1 (default): single-proof slots get streams on measured hardware queues (queues.hip)
     int32_t msm_dedicated_queues; // stand-alone MSMs on streams with a hardware queue of their own: 1 (default) while no context is alive, 2 always, 0 never
     int32_t window_bits_narrow;   // key tables, 0 = the library's choice: latency tables of a / b_g1 / l (default 8 at manta-pay sizes)
-    int32_t window_bits_wide;     //   batched-pass tables (default 12)
+    int32_t window_bits_wide;     //   batched-pass tables (default 12 from 2^15 scalars on, else 11)
     int32_t window_bits_h;        //   the h query (default 12 / log2(D) - 2)
     int32_t window_bits_g2;       //   b_g2 (default 6)
     int64_t full_table_bytes;     // HBM budget of a context's full tables; -1 = the default (a tenth of the device), 0 = none
