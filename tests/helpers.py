@@ -43,3 +43,26 @@ def knob_env(knobs, base=None, strip_prefix=None):
         assert os.path.exists(diag), "manta_rs_amd/csrc/Makefile builds the diagnosis twin next to the library"
         env.setdefault("MANTA_LIB", diag)
     return env
+
+
+def proof_diff(got, want, knobs=None, child_stdout=None, tag="parity"):
+    """A readable account of a proof mismatch: which proofs of the list differ and in which of A | B | C (BN254: 32 | 64 | 32 bytes,
+    hex strings) -- and the child's whole output saved under gpurun_out/ so that an intermittent failure on the GPU box leaves evidence
+    (round 6: one unexplained wrong B element in one child of one suite run, 230 repetitions clean: tools/first_proof_stress.py)."""
+    rows = []
+    for i, (g, w) in enumerate(zip(got, want)):
+        if g != w:
+            n = len(w) // 4
+            rows.append((i, [k for k, (a, b) in zip("ABC", ((0, n), (n, 3 * n), (3 * n, 4 * n))) if g[a:b] != w[a:b]]))
+    msg = "knobs %r: %d of %d proofs differ: %s (lengths %d / %d)" % (knobs, len(rows), len(want), rows[:8], len(got), len(want))
+    if child_stdout is not None:
+        try:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            path = os.path.join(root, "gpurun_out", "%s_failure.txt" % tag)
+            with open(path, "a") as f:
+                f.write("==== %s\n%s\n" % (msg, child_stdout))
+            msg += " -- child output appended to " + path
+        except OSError:
+            pass
+    return msg

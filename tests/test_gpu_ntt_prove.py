@@ -233,11 +233,16 @@ def test_round5_knobs_do_not_change_results(gpu):
         out = subprocess.run([sys.executable, "-c", _R5_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, (knobs, out.stdout[-2000:] + out.stderr[-2000:])
         lines = out.stdout.split("\n")
-        assert [ln.split()[1] for ln in lines if ln.startswith("PROOF")] == want, knobs
+        got = [ln.split()[1] for ln in lines if ln.startswith("PROOF")]
+        assert got == want, H.proof_diff(got, want, knobs, out.stdout, "round5_knobs_single")
         batches = [ln[6:] for ln in lines if ln.startswith("BATCH")]
-        assert len(batches) == 4 and all(b == want_batch for b in batches), knobs
+        assert len(batches) == 4, knobs
+        for b in batches:
+            assert b == want_batch, H.proof_diff(b.split(), want_batch.split(), knobs, out.stdout, "round5_knobs_batch")
         conc = [ln.split() for ln in lines if ln.startswith("CONC")]
-        assert len(conc) == 20 and all(two[int(j)] == h for _, j, h in conc), knobs
+        assert len(conc) == 20, knobs
+        assert all(two[int(j)] == h for _, j, h in conc), H.proof_diff([h for _, j, h in conc], [two[int(j)] for _, j, h in conc], knobs, out.stdout,
+                                                                         "round5_knobs_threads")
 
 
 def test_captured_graphs_survive_other_contexts(gpu):
