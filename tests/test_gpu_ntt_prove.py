@@ -226,8 +226,9 @@ def test_round5_knobs_do_not_change_results(gpu):
     want_batch = " ".join(two * 4)
     variants = ({}, {"MANTA_Z3_LINEAR": "0"}, {"MANTA_Z3_ORDER": "zba"}, {"MANTA_NTT_FUSE": "0"}, {"MANTA_NTT_FUSE": "1"}, {"MANTA_NTT_FUSE": "2"},
                 {"MANTA_NTT_TWL": "0", "MANTA_NTT_FUSE": "0"}, {"MANTA_ACC_SINGLE": "0"}, {"MANTA_ACC_SINGLE": "2"}, {"MANTA_ACC_SINGLE": "3"},
-                {"MANTA_SORT_LOW": "0"}, {"MANTA_GRAPH_BATCH": "split"}, {"MANTA_GRAPH_BATCH": "off"}, {"MANTA_QUEUE_AWARE": "0"},
-                {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_LINEAR": "2"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
+                {"MANTA_SORT_LOW": "0"}, {"MANTA_Z3_LINEAR": "1"}, {"MANTA_Z3_LINEAR": "2"}, {"MANTA_Z3_HIGH": "1"}, {"MANTA_Z3_HIGH": "0"})
+    # (MANTA_GRAPH_BATCH split / off and MANTA_QUEUE_AWARE=0 moved to the tuning sweep of tests/test_gpu_profiles.py in round 6: they are
+    # variables of the shipped library's table now)
     for knobs in variants:
         env = H.knob_env(knobs, strip_prefix="MANTA_")  # tuning-table names: the shipped library; A/B switches: the diagnosis twin
         out = subprocess.run([sys.executable, "-c", _R5_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=900)
